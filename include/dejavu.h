@@ -1,0 +1,156 @@
+/*
+ * dejavu.h -- C ABI of the MI355X scene-familiarity engine (libdejavu_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of navsim
+ * (Linux-cpp-lisp/navigation-by-deja-vu): scoring sensor patches against the
+ * stored-view library and picking the most familiar heading.  Plain C types
+ * only; every host pointer is caller-owned and borrowed for the duration of the
+ * call; outputs are caller-allocated; functions return DV_OK or a negative code
+ * and never throw.  A context is single-threaded (one call in flight) and bound
+ * to one GPU: multi-GPU runs use one process and one context per GPU.
+ *
+ * Reference interfaces replaced (citations into the reference repository):
+ *   navsim/util.pyx:10-25        sads_familiarity(chem_weight)(scenes) -> func
+ *   navsim/util.pyx:28-73        sads_hsv_metric(familiar_scenes, scene, fambuf, chem_weight)
+ *   navsim/NavBySceneFamiliarity.py:283-316   heading loop of step_forward
+ *   navsim/NavBySceneFamiliarity.py:140       library hand-off at train_from_path
+ */
+#ifndef DEJAVU_H
+#define DEJAVU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dv_ctx dv_ctx;
+
+enum {
+    DV_OK = 0,
+    DV_ERR_INVALID = -1,   /* bad argument (NULL, shape, chem_weight outside [0,1], A too large) */
+    DV_ERR_HIP = -2,       /* a HIP runtime call failed; see dv_last_error */
+    DV_ERR_STATE = -3,     /* no library set / no step to read back */
+    DV_ERR_OOM = -4        /* device or host allocation failed */
+};
+
+#define DV_MAX_HEADINGS 64      /* headings scored per library pass */
+#define DV_MAX_HUE_PLANES 4     /* distinct chemical hues handled by the one-hot layout */
+
+/* dv_step flags */
+#define DV_STEP_FORCE_RESOLVE 1u   /* run the exact tie resolver even for a single candidate */
+
+/* dv_step_result.flags */
+#define DV_RES_RESOLVED   1u       /* exact tie resolver ran; best_fam / exact_fam are bit-exact */
+#define DV_RES_EXACT_ALL  2u       /* every score of this step is the exact sequential double */
+#define DV_RES_OVERFLOW   4u       /* candidate list overflowed; step was redone in exact mode */
+
+/*
+ * Result of one step (replaces NavBySceneFamiliarity.py:313-316).
+ * angle_fam[a]  = max over the (local) library of the familiarity of heading a
+ *                 (:313); within 1e-12 relative of the reference's double, and
+ *                 bit-exact for headings whose exact_fam is finite.
+ * angle_view[a] = first view index (global = first_view + local) attaining it.
+ * best_heading  = np.argmax(angle_familiarity) of the reference, bit-identical
+ *                 (:315): near-ties are re-scored with the reference's exact
+ *                 sequential double arithmetic before deciding.
+ * exact_fam[a]  = exact max over the candidate views of heading a, -inf when
+ *                 heading a has no candidate (only filled when RESOLVED).
+ */
+typedef struct dv_step_result {
+    int32_t best_heading;
+    uint32_t flags;
+    int64_t best_view;
+    double best_fam;
+    double approx_max;          /* max over headings and views of the integer-sum score */
+    double delta;               /* half-width of the candidate window around approx_max */
+    int64_t n_candidates;       /* (heading, view) pairs inside the window */
+    int32_t n_headings;
+    int32_t reserved;
+    double angle_fam[DV_MAX_HEADINGS];
+    int64_t angle_view[DV_MAX_HEADINGS];
+    double exact_fam[DV_MAX_HEADINGS];
+    int64_t exact_view[DV_MAX_HEADINGS];
+} dv_step_result;
+
+typedef struct dv_lib_info {
+    int64_t n_views;            /* F (local shard) */
+    int64_t first_view;         /* global index of local view 0 */
+    int32_t h, w;
+    int32_t n_planes;           /* bytes stored per pixel on the device */
+    int32_t n_hue_planes;       /* one-hot saturation planes (0 when chem_weight == 0) */
+    int32_t generic_hue;        /* 1: more than DV_MAX_HUE_PLANES hues, H/S kept as planes */
+    int32_t has_value_plane;    /* 0 when chem_weight == 1 */
+    int64_t tile_bytes;         /* bytes the scoring kernel streams per pass */
+    double chem_weight;
+    uint8_t hues[DV_MAX_HUE_PLANES];
+} dv_lib_info;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int dv_create(dv_ctx **out, int device_id);
+void dv_destroy(dv_ctx *ctx);
+/* Message of the last failure on ctx (or of the last failed dv_create when ctx is NULL). */
+const char *dv_last_error(const dv_ctx *ctx);
+/* Run on a caller-provided hipStream_t (NULL restores the context's own stream). */
+int dv_set_stream(dv_ctx *ctx, void *hip_stream);
+/* exact != 0: every score is the reference's sequential-double value (slower fp64 kernel). */
+int dv_set_exact(dv_ctx *ctx, int exact);
+
+/* ---- library (NavBySceneFamiliarity.py:122,140; util.pyx:10-13) ------- */
+/*
+ * views: uint8[F,h,w,3] C-contiguous, channels H,S,V.  Copied, re-tiled into
+ * the device layout and released before return.  chem_weight must be in [0,1]
+ * (util.pyx:12).  first_view is the global index of views[0] when the library
+ * is sharded across GPUs (0 otherwise).
+ */
+int dv_set_library(dv_ctx *ctx, const uint8_t *views, int64_t n_views, int h, int w,
+                   int channels, double chem_weight, int64_t first_view);
+/* Same library as navsim_amd.synth.synth_views(seed, n_views, h, w, first_view), generated on the GPU. */
+int dv_generate_library(dv_ctx *ctx, uint64_t seed, int64_t n_views, int h, int w,
+                        double chem_weight, int64_t first_view);
+int dv_clear_library(dv_ctx *ctx);
+int dv_get_library_info(const dv_ctx *ctx, dv_lib_info *out);
+/* Copy the stored planes of local views [v0, v0+n) back as uint8[n, n_planes, h*w] (layout check). */
+int dv_read_planes(dv_ctx *ctx, int64_t v0, int64_t n, uint8_t *out);
+
+/* ---- scoring ----------------------------------------------------------- */
+/* func(scene, fambuf) of util.pyx:14-20: fambuf[f] for one patch uint8[h,w,3] against every local view. */
+int dv_score(dv_ctx *ctx, const uint8_t *patch, double *fambuf);
+/*
+ * One navigation step's scoring (NavBySceneFamiliarity.py:283-316) for
+ * patches uint8[A,h,w,3], A <= DV_MAX_HEADINGS.
+ * scene_fam: double[F] or NULL -- min over headings per view (:301-303).
+ */
+int dv_step(dv_ctx *ctx, const uint8_t *patches, int n_headings, uint32_t flags,
+            dv_step_result *result, double *scene_fam);
+/* Re-run the exact resolver on the candidates of the last step (sharded runs, cross-rank ties). */
+int dv_resolve(dv_ctx *ctx, dv_step_result *result);
+
+/* ---- resident / asynchronous form (benchmarks, pipelined callers) ------ */
+/* Upload patches and prepare their device layout; no host synchronisation. */
+int dv_upload_patches(dv_ctx *ctx, const uint8_t *patches, int n_headings);
+/* Generate patches on the device: synth_views(seed + 1, n_headings, h, w). */
+int dv_generate_patches(dv_ctx *ctx, uint64_t seed, int n_headings);
+/* Enqueue one step on the resident patches (scoring, reductions, tie resolver); no host synchronisation. */
+int dv_step_enqueue(dv_ctx *ctx, uint32_t flags);
+/* Wait for the last enqueued step and copy its result (and optionally scene_fam[F]). */
+int dv_step_wait(dv_ctx *ctx, dv_step_result *result, double *scene_fam);
+int dv_synchronize(dv_ctx *ctx);
+
+/* ---- measurement ------------------------------------------------------- */
+/* hipEvent pair on the context's stream around whatever is enqueued between the two calls. */
+int dv_timer_start(dv_ctx *ctx);
+int dv_timer_stop(dv_ctx *ctx, float *elapsed_ms);
+/* enable != 0: bracket every launch of the scoring kernel with hipEvents. */
+int dv_profile_kernel(dv_ctx *ctx, int enable);
+/* Sum and count of the bracketed scoring-kernel launches since the last read; resets. */
+int dv_profile_read(dv_ctx *ctx, double *total_ms, int64_t *n_launches);
+/* Streaming-read microbenchmark over n_bytes of device memory (achievable HBM ceiling). */
+int dv_stream_read_gbps(dv_ctx *ctx, int64_t n_bytes, int iters, double *gbps);
+
+const char *dv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEJAVU_H */

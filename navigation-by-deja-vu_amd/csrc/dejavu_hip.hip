@@ -1,0 +1,581 @@
+// dejavu_hip.hip -- host side of libdejavu_hip.so: the C ABI of include/dejavu.h.
+//
+// One context = one GPU = one stream.  All device buffers are allocated when the library
+// is set (nothing is allocated inside a step), results come back through one pinned-host
+// record, and a step is five launches on one stream:
+//   memset(step state) -> k_sad_tiles (the HBM stream) -> k_finish -> k_resolve -> k_decide.
+#include "dejavu_kernels.h"
+#include "../../include/dejavu.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace dv;
+
+static_assert(sizeof(StepResultDev) == sizeof(dv_step_result), "device/host result records differ");
+static_assert(kMaxHeadings == DV_MAX_HEADINGS && kMaxHues == DV_MAX_HUE_PLANES, "header constants differ");
+
+static thread_local std::string g_create_error;
+
+struct dv_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int exact = 0;
+
+    // library
+    bool have_lib = false;
+    LibCfg cfg{};
+    int h = 0, w = 0;
+    uint4* d_tiles = nullptr;
+    size_t tile_bytes = 0;
+
+    // per-step buffers (sized at set_library)
+    unsigned char* d_raw_patches = nullptr;   // [64][P][3]
+    unsigned* d_prep = nullptr;               // [npl][Q][4][64]
+    int* d_hsconst = nullptr;                 // [64]
+    double* d_fam = nullptr;                  // [64][Fpad]
+    double* d_scene = nullptr;                // [Fpad]
+    StepState* d_state = nullptr;
+    unsigned long long* d_cand = nullptr;     // [kCandCap]
+    double* d_cand_exact = nullptr;           // [kCandCap]
+    StepResultDev* d_result = nullptr;
+    StepResultDev* h_result = nullptr;        // pinned
+    double* h_scene = nullptr;                // pinned staging for scene_fam
+    int A = 0, APAD = 0;                      // resident patches
+    bool step_pending = false;
+    bool last_want_scene = false;
+    double delta = 0.0;
+
+    // measurement
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int profile = 0;
+    std::vector<hipEvent_t> pev;              // pairs
+    size_t pev_used = 0;
+};
+
+static int fail(dv_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? DV_ERR_OOM : DV_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                             \
+    } while (0)
+
+static void free_library(dv_ctx* c) {
+    auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst); F(c->d_fam); F(c->d_scene);
+    F(c->d_state); F(c->d_cand); F(c->d_cand_exact); F(c->d_result);
+    if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; }
+    if (c->h_scene) { (void)hipHostFree(c->h_scene); c->h_scene = nullptr; }
+    c->have_lib = false;
+    c->A = 0;
+    c->step_pending = false;
+}
+
+extern "C" const char* dv_version(void) { return "dejavu-mi355x 0.1 (gfx950)"; }
+
+extern "C" const char* dv_last_error(const dv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int dv_create(dv_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, DV_ERR_INVALID, "dv_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, DV_ERR_INVALID, "dv_create: device %d of %d", device_id, n);
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    dv_ctx* c = new (std::nothrow) dv_ctx();
+    if (!c) return fail(nullptr, DV_ERR_OOM, "dv_create: out of host memory");
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->t0);
+    if (e == hipSuccess) e = hipEventCreate(&c->t1);
+    if (e != hipSuccess) {
+        fail(nullptr, DV_ERR_HIP, "dv_create: %s", hipGetErrorString(e));
+        delete c;
+        return DV_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return DV_OK;
+}
+
+extern "C" void dv_destroy(dv_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_library(c);
+    for (auto e : c->pev) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int dv_set_stream(dv_ctx* c, void* s) {
+    if (!c) return DV_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return DV_OK;
+}
+
+extern "C" int dv_set_exact(dv_ctx* c, int exact) {
+    if (!c) return DV_ERR_INVALID;
+    c->exact = exact ? 1 : 0;
+    return DV_OK;
+}
+
+extern "C" int dv_synchronize(dv_ctx* c) {
+    if (!c) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DV_OK;
+}
+
+// ------------------------------------------------------------------ library
+static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t first,
+                         int n_hues, const unsigned char* hues, int generic) {
+    free_library(c);
+    LibCfg& g = c->cfg;
+    g = LibCfg{};
+    g.F = F;
+    g.Fpad = (F + 63) / 64 * 64;
+    g.first = first;
+    g.P = h * w;
+    g.Q = (g.P + 15) / 16;
+    g.cw = cw;
+    g.whs = 0.5 * cw;
+    g.wv = 1 - cw;
+    g.generic = (cw > 0.0 && generic) ? 1 : 0;
+    g.nhs = cw > 0.0 ? (g.generic ? 2 : n_hues) : 0;
+    g.hasv = cw < 1.0 ? 1 : 0;
+    g.npl = g.nhs + g.hasv;
+    for (int k = 0; k < kMaxHues; ++k) g.hues[k] = (!g.generic && k < g.nhs) ? hues[k] : 0;
+    c->h = h;
+    c->w = w;
+    // cw == 1 with an all-zero-saturation library stores nothing; keep one (zero) plane so that the
+    // kernels have something to stream (it contributes |0 - 0| = 0).
+    if (g.npl == 0) { g.hasv = 1; g.npl = 1; }
+    c->tile_bytes = (size_t)(g.Fpad / 64) * g.npl * g.Q * 64 * sizeof(uint4);
+    const double n = (double)g.P;
+    c->delta = 4.0 * (n + 8.0) * std::ldexp(1.0, -53) * n;
+
+    HIP_TRY(c, hipMalloc(&c->d_tiles, c->tile_bytes));
+    HIP_TRY(c, hipMalloc(&c->d_raw_patches, (size_t)kMaxHeadings * g.P * 3));
+    HIP_TRY(c, hipMalloc(&c->d_prep, (size_t)g.npl * g.Q * 4 * kMaxHeadings * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc(&c->d_hsconst, kMaxHeadings * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_fam, (size_t)kMaxHeadings * g.Fpad * sizeof(double)));
+    HIP_TRY(c, hipMalloc(&c->d_scene, (size_t)g.Fpad * sizeof(double)));
+    HIP_TRY(c, hipMalloc(&c->d_state, sizeof(StepState)));
+    HIP_TRY(c, hipMalloc(&c->d_cand, kCandCap * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc(&c->d_cand_exact, kCandCap * sizeof(double)));
+    HIP_TRY(c, hipMalloc(&c->d_result, sizeof(StepResultDev)));
+    HIP_TRY(c, hipHostMalloc(&c->h_result, sizeof(StepResultDev)));
+    HIP_TRY(c, hipHostMalloc(&c->h_scene, (size_t)g.Fpad * sizeof(double)));
+    HIP_TRY(c, hipMemsetAsync(c->d_hsconst, 0, kMaxHeadings * sizeof(int), c->stream));
+    c->have_lib = true;
+    return DV_OK;
+}
+
+static int check_lib_args(dv_ctx* c, int64_t F, int h, int w, double cw) {
+    if (!c) return DV_ERR_INVALID;
+    if (F < 1 || h < 1 || w < 1) return fail(c, DV_ERR_INVALID, "library needs n_views, h, w >= 1 (got %lld, %d, %d)", (long long)F, h, w);
+    if (!(cw >= 0.0 && cw <= 1.0)) return fail(c, DV_ERR_INVALID, "chem_weight %g outside [0, 1]", cw);
+    if ((int64_t)h * w > (1 << 22)) return fail(c, DV_ERR_INVALID, "sensor of %d x %d pixels is too large", h, w);
+    if (F >= (1ll << 40)) return fail(c, DV_ERR_INVALID, "too many views");
+    return DV_OK;
+}
+
+extern "C" int dv_set_library(dv_ctx* c, const uint8_t* views, int64_t F, int h, int w, int channels,
+                              double cw, int64_t first) {
+    int rc = check_lib_args(c, F, h, w, cw);
+    if (rc) return rc;
+    if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
+    if (channels != 3) return fail(c, DV_ERR_INVALID, "views must have 3 channels (H,S,V), got %d", channels);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_library(c);
+
+    const size_t raw_bytes = (size_t)F * h * w * 3;
+    unsigned char* d_raw = nullptr;
+    unsigned* d_bitmap = nullptr;
+    HIP_TRY(c, hipMalloc(&d_raw, raw_bytes));
+    auto cleanup = [&]() { (void)hipFree(d_raw); if (d_bitmap) (void)hipFree(d_bitmap); };
+    hipError_t e = hipMemcpyAsync(d_raw, views, raw_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(c, DV_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+
+    unsigned bitmap[8] = {0};
+    if (cw > 0.0) {
+        e = hipMalloc(&d_bitmap, sizeof bitmap);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bitmap, 0, sizeof bitmap, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_hue_scan, dim3(1024), dim3(256), 0, c->stream, d_raw, (long long)F * h * w, d_bitmap);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(bitmap, d_bitmap, sizeof bitmap, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { cleanup(); return fail(c, DV_ERR_HIP, "hue scan: %s", hipGetErrorString(e)); }
+    }
+    unsigned char hues[256];
+    int n_hues = 0;
+    for (int v = 0; v < 256; ++v)
+        if (bitmap[v >> 5] & (1u << (v & 31))) hues[n_hues++] = (unsigned char)v;
+    const int generic = n_hues > kMaxHues;
+
+    rc = alloc_library(c, F, h, w, cw, first, n_hues, hues, generic);
+    if (rc) { cleanup(); free_library(c); return rc; }
+    const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.npl * c->cfg.Q * 64;
+    hipLaunchKernelGGL(k_retile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_tiles, c->cfg);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "retile: %s", hipGetErrorString(e)); }
+    return DV_OK;
+}
+
+extern "C" int dv_generate_library(dv_ctx* c, uint64_t seed, int64_t F, int h, int w, double cw, int64_t first) {
+    int rc = check_lib_args(c, F, h, w, cw);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned char hues[2] = {0, 127};   // synth.hsv_from_words: H = bit * 127, S > 0 in both
+    rc = alloc_library(c, F, h, w, cw, first, 2, hues, 0);
+    if (rc) { free_library(c); return rc; }
+    const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.npl * c->cfg.Q * 64;
+    hipLaunchKernelGGL(k_generate_tiles, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_tiles,
+                       c->cfg, (unsigned long long)seed);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DV_OK;
+}
+
+extern "C" int dv_clear_library(dv_ctx* c) {
+    if (!c) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_library(c);
+    return DV_OK;
+}
+
+extern "C" int dv_get_library_info(const dv_ctx* c, dv_lib_info* o) {
+    if (!c || !o) return DV_ERR_INVALID;
+    if (!c->have_lib) return DV_ERR_STATE;
+    memset(o, 0, sizeof *o);
+    o->n_views = c->cfg.F;
+    o->first_view = c->cfg.first;
+    o->h = c->h;
+    o->w = c->w;
+    o->n_planes = c->cfg.npl;
+    o->n_hue_planes = c->cfg.generic ? 0 : c->cfg.nhs;
+    o->generic_hue = c->cfg.generic;
+    o->has_value_plane = c->cfg.hasv;
+    o->tile_bytes = (int64_t)c->tile_bytes;
+    o->chem_weight = c->cfg.cw;
+    for (int k = 0; k < kMaxHues; ++k) o->hues[k] = c->cfg.hues[k];
+    return DV_OK;
+}
+
+extern "C" int dv_read_planes(dv_ctx* c, int64_t v0, int64_t n, uint8_t* out) {
+    if (!c || !out) return DV_ERR_INVALID;
+    if (!c->have_lib) return fail(c, DV_ERR_STATE, "no library set");
+    if (v0 < 0 || n < 1 || v0 + n > c->cfg.F) return fail(c, DV_ERR_INVALID, "view range [%lld, %lld) outside the library", (long long)v0, (long long)(v0 + n));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const long long total = n * c->cfg.npl * (long long)c->cfg.P;
+    unsigned char* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, (size_t)total));
+    hipLaunchKernelGGL(k_read_planes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_tiles, d, c->cfg,
+                       (long long)v0, (long long)n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)total, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, DV_ERR_HIP, "read_planes: %s", hipGetErrorString(e));
+    return DV_OK;
+}
+
+// ------------------------------------------------------------------ patches
+static int prep_patches(dv_ctx* c, int A) {
+    c->A = A;
+    c->APAD = A <= 16 ? 16 : (A <= 32 ? 32 : 64);
+    const long long total = (long long)c->cfg.npl * c->cfg.Q * 4 * c->APAD;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_prep, dim3(nb + A), dim3(256), 0, c->stream, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, A,
+                       c->APAD);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+static int check_step_args(dv_ctx* c, int A) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib) return fail(c, DV_ERR_STATE, "no library set (call dv_set_library first)");
+    if (A < 1 || A > kMaxHeadings) return fail(c, DV_ERR_INVALID, "n_headings %d outside [1, %d]", A, kMaxHeadings);
+    return DV_OK;
+}
+
+extern "C" int dv_upload_patches(dv_ctx* c, const uint8_t* patches, int A) {
+    int rc = check_step_args(c, A);
+    if (rc) return rc;
+    if (!patches) return fail(c, DV_ERR_INVALID, "patches is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_raw_patches, patches, (size_t)A * c->cfg.P * 3, hipMemcpyHostToDevice, c->stream));
+    return prep_patches(c, A);
+}
+
+extern "C" int dv_generate_patches(dv_ctx* c, uint64_t seed, int A) {
+    int rc = check_step_args(c, A);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const long long n = (long long)A * c->cfg.P;
+    hipLaunchKernelGGL(k_generate_patches, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_raw_patches, A,
+                       c->cfg.P, (unsigned long long)seed);
+    HIP_TRY(c, hipGetLastError());
+    return prep_patches(c, A);
+}
+
+// ------------------------------------------------------------------ scoring launches
+template <int NHS, int HASV>
+static void launch_tiles_apad(dv_ctx* c, int nw) {
+    const dim3 grid((unsigned)(c->cfg.Fpad / 64)), block(64 * nw);
+#define DV_LAUNCH(AP)                                                                                           \
+    hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_hsconst, \
+                       c->d_fam, c->d_state->amax, c->cfg, c->A)
+    if (c->APAD == 16) DV_LAUNCH(16);
+    else if (c->APAD == 32) DV_LAUNCH(32);
+    else DV_LAUNCH(64);
+#undef DV_LAUNCH
+}
+
+template <int HAS_HS, int HASV>
+static void launch_generic_apad(dv_ctx* c, int nw) {
+    const dim3 grid((unsigned)(c->cfg.Fpad / 64)), block(64 * nw);
+#define DV_LAUNCH(AP)                                                                                             \
+    hipLaunchKernelGGL((k_sad_generic<HAS_HS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_hsconst, \
+                       c->d_fam, c->d_state->amax, c->cfg, c->A)
+    if (c->APAD == 16) DV_LAUNCH(16);
+    else if (c->APAD == 32) DV_LAUNCH(32);
+    else DV_LAUNCH(64);
+#undef DV_LAUNCH
+}
+
+static int launch_scoring(dv_ctx* c) {
+    const LibCfg& g = c->cfg;
+    const int nw = 4;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) {
+        if (c->pev_used + 2 > c->pev.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t e;
+                HIP_TRY(c, hipEventCreate(&e));
+                c->pev.push_back(e);
+            }
+        }
+        e0 = c->pev[c->pev_used];
+        e1 = c->pev[c->pev_used + 1];
+        c->pev_used += 2;
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+    }
+    if (c->exact) {
+        hipLaunchKernelGGL(k_exact_all, dim3((unsigned)(g.Fpad / 64), (unsigned)((c->A + 3) / 4)), dim3(64, 4), 0, c->stream,
+                           c->d_tiles, c->d_raw_patches, c->d_fam, c->d_state->amax, c->cfg, c->A);
+    } else if (g.generic) {
+        if (g.hasv) launch_generic_apad<1, 1>(c, nw); else launch_generic_apad<1, 0>(c, nw);
+    } else {
+        const int key = g.nhs * 2 + g.hasv;
+        switch (key) {
+            case 1: launch_tiles_apad<0, 1>(c, nw); break;
+            case 2: launch_tiles_apad<1, 0>(c, nw); break;
+            case 3: launch_tiles_apad<1, 1>(c, nw); break;
+            case 4: launch_tiles_apad<2, 0>(c, nw); break;
+            case 5: launch_tiles_apad<2, 1>(c, nw); break;
+            case 6: launch_tiles_apad<3, 0>(c, nw); break;
+            case 7: launch_tiles_apad<3, 1>(c, nw); break;
+            case 8: launch_tiles_apad<4, 0>(c, nw); break;
+            case 9: launch_tiles_apad<4, 1>(c, nw); break;
+            default: return fail(c, DV_ERR_STATE, "unsupported plane configuration nhs=%d hasv=%d", g.nhs, g.hasv);
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+    return DV_OK;
+}
+
+static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene, bool resolve_only) {
+    const LibCfg& g = c->cfg;
+    const int force = (flags & DV_STEP_FORCE_RESOLVE) ? 1 : 0;
+    if (!resolve_only) {
+        HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(StepState), c->stream));
+        int rc = launch_scoring(c);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_finish, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_state,
+                           c->d_cand, c->d_scene, c->cfg, c->A, c->exact ? -1.0 : c->delta, want_scene ? 1 : 0);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (!c->exact) {
+        hipLaunchKernelGGL(k_resolve, dim3(256), dim3(64), 0, c->stream, c->d_tiles, c->d_raw_patches, c->d_state, c->d_cand,
+                           c->d_cand_exact, c->cfg, force);
+        HIP_TRY(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result, c->cfg,
+                       c->A, c->exact ? 0.0 : c->delta, c->exact, force);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, sizeof(StepResultDev), hipMemcpyDeviceToHost, c->stream));
+    if (want_scene)
+        HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    c->step_pending = true;
+    c->last_want_scene = want_scene;
+    return DV_OK;
+}
+
+extern "C" int dv_step_enqueue(dv_ctx* c, uint32_t flags) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib || c->A < 1) return fail(c, DV_ERR_STATE, "no library or no resident patches");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_step(c, flags, true, false);
+}
+
+static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam) {
+    if (!c->step_pending) return fail(c, DV_ERR_STATE, "no step enqueued");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_result->flags & DV_RES_OVERFLOW) {
+        // More near-ties than the candidate list holds: redo this step with exact scores everywhere.
+        const int was_exact = c->exact;
+        c->exact = 1;
+        int rc = enqueue_step(c, 0, c->last_want_scene, false);
+        c->exact = was_exact;
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->h_result->flags |= DV_RES_OVERFLOW;
+    }
+    if (result) memcpy(result, c->h_result, sizeof *result);
+    if (scene_fam) {
+        if (!c->last_want_scene) return fail(c, DV_ERR_STATE, "scene familiarity was not requested for this step");
+        memcpy(scene_fam, c->h_scene, (size_t)c->cfg.F * sizeof(double));
+    }
+    return DV_OK;
+}
+
+extern "C" int dv_step_wait(dv_ctx* c, dv_step_result* result, double* scene_fam) {
+    if (!c) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return wait_step(c, result, scene_fam);
+}
+
+extern "C" int dv_step(dv_ctx* c, const uint8_t* patches, int A, uint32_t flags, dv_step_result* result,
+                       double* scene_fam) {
+    int rc = dv_upload_patches(c, patches, A);
+    if (rc) return rc;
+    if (!result) return fail(c, DV_ERR_INVALID, "result is NULL");
+    rc = enqueue_step(c, flags, scene_fam != nullptr, false);
+    if (rc) return rc;
+    return wait_step(c, result, scene_fam);
+}
+
+extern "C" int dv_resolve(dv_ctx* c, dv_step_result* result) {
+    if (!c || !result) return DV_ERR_INVALID;
+    if (!c->have_lib || !c->step_pending) return fail(c, DV_ERR_STATE, "no step to resolve");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->h_result->flags & (DV_RES_EXACT_ALL | DV_RES_RESOLVED)) {   // already exact
+        memcpy(result, c->h_result, sizeof *result);
+        return DV_OK;
+    }
+    int rc = enqueue_step(c, DV_STEP_FORCE_RESOLVE, false, true);
+    if (rc) return rc;
+    return wait_step(c, result, nullptr);
+}
+
+extern "C" int dv_score(dv_ctx* c, const uint8_t* patch, double* fambuf) {
+    int rc = dv_upload_patches(c, patch, 1);
+    if (rc) return rc;
+    if (!fambuf) return fail(c, DV_ERR_INVALID, "fambuf is NULL");
+    HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(StepState), c->stream));
+    rc = launch_scoring(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(fambuf, c->d_fam, (size_t)c->cfg.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->step_pending = false;
+    return DV_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+extern "C" int dv_timer_start(dv_ctx* c) {
+    if (!c) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->t0, c->stream));
+    return DV_OK;
+}
+
+extern "C" int dv_timer_stop(dv_ctx* c, float* ms) {
+    if (!c || !ms) return DV_ERR_INVALID;
+    HIP_TRY(c, hipEventRecord(c->t1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->t1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return DV_OK;
+}
+
+extern "C" int dv_profile_kernel(dv_ctx* c, int enable) {
+    if (!c) return DV_ERR_INVALID;
+    c->profile = enable ? 1 : 0;
+    c->pev_used = 0;
+    return DV_OK;
+}
+
+extern "C" int dv_profile_read(dv_ctx* c, double* total_ms, int64_t* n) {
+    if (!c || !total_ms || !n) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < c->pev_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->pev[i], c->pev[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *n = (int64_t)(c->pev_used / 2);
+    c->pev_used = 0;
+    return DV_OK;
+}
+
+extern "C" int dv_stream_read_gbps(dv_ctx* c, int64_t n_bytes, int iters, double* gbps) {
+    if (!c || !gbps || n_bytes < 16 || iters < 1) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint4* buf = nullptr;
+    unsigned* sink = nullptr;
+    const long long n16 = n_bytes / 16;
+    HIP_TRY(c, hipMalloc(&buf, (size_t)n16 * 16));
+    hipError_t e = hipMalloc(&sink, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(buf, 0x5a, (size_t)n16 * 16, c->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) {
+        const dim3 grid(256 * 8), block(256);
+        hipLaunchKernelGGL(k_stream_read, grid, block, 0, c->stream, buf, n16, sink);   // warm-up
+        e = hipEventRecord(c->t0, c->stream);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) {
+            hipLaunchKernelGGL(k_stream_read, grid, block, 0, c->stream, buf, n16, sink);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(c->t1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->t1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->t0, c->t1);
+    }
+    (void)hipFree(buf);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return fail(c, DV_ERR_HIP, "stream_read: %s", hipGetErrorString(e));
+    *gbps = (double)n16 * 16.0 * iters / (ms * 1e-3) / 1e9;
+    return DV_OK;
+}

@@ -1,0 +1,663 @@
+// dejavu_kernels.h -- gfx950 (CDNA4) device code of the scene-familiarity engine.
+//
+// Device layout of the stored-view library ("tiles"), owned by this library:
+//
+//   tiles[g][plane][q][lane] : uint4 (16 B)
+//     g     = view group, 64 consecutive views           (g = f / 64, lane = f % 64)
+//     plane = one byte per pixel: one-hot saturation planes, then the value plane
+//     q     = chunk of 16 consecutive pixels of the flattened h*w sensor (zero padded)
+//
+// One wave64 handles one view group: lane <-> view, so a wave-wide dwordx4 load is 1 KiB
+// contiguous, every lane accumulates its own view's sums with v_sad_u8 (4 pixels per
+// lane-op) and no cross-lane reduction is needed until the final max over views.  The patch
+// operand of each v_sad_u8 is the same for all 64 lanes, so it is read with scalar loads
+// (s_load_dwordx8/16 -> SGPR operand): the patches never occupy VGPRs or LDS bandwidth.
+//
+// Hue-aware saturation term of the reference (navsim/util.pyx:48-56):
+//     hs = (H_s == H_f) ? |S_s - S_f| : S_s + S_f
+// equals the L1 distance between the one-hot vectors S*e_H, so with the library's hue set
+// K = {hues with S > 0} stored as |K| planes  S_k = (H == k ? S : 0):
+//     hs = sum_k |S_s,k - S_f,k|  +  (H_s not in K ? S_s : 0)
+// which is |K| v_sad_u8 per 4 pixels plus a per-heading constant.  Exact for all inputs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace dv {
+
+constexpr int kMaxHeadings = 64;
+constexpr int kMaxHues = 4;
+constexpr int kCandCap = 4096;
+
+struct LibCfg {
+    long long F;        // local views
+    long long Fpad;     // padded to a multiple of 64
+    long long first;    // global index of local view 0
+    int P;              // h*w
+    int Q;              // ceil(P/16)
+    int npl;            // planes stored per pixel
+    int nhs;            // one-hot saturation planes (or 2 = H,S when generic)
+    int hasv;           // value plane present
+    int generic;        // H and S kept as planes (more than kMaxHues hues)
+    unsigned char hues[kMaxHues];
+    double cw;          // chem_weight
+    double whs;         // 0.5 * cw          (util.pyx:59,68)
+    double wv;          // 1 - cw            (util.pyx:69)
+};
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ unsigned long long ordered_key(double d) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_to_double(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// Same bit fields as navsim_amd/synth.py:hsv_from_words.
+__device__ __forceinline__ void synth_hsv(unsigned long long z, unsigned& H, unsigned& S, unsigned& V) {
+    const unsigned lvl = (unsigned)(((z & 0xFFFFull) * 5ull) >> 16);
+    const unsigned levels[5] = {0u, 63u, 127u, 191u, 255u};
+    V = levels[lvl];
+    H = (unsigned)((z >> 16) & 1ull) * 127u;
+    S = (unsigned)((z >> 17) & 1ull) * 127u;
+}
+// Byte stored in plane `pl` for a pixel (H,S,V).
+__device__ __forceinline__ unsigned plane_byte(const LibCfg& c, int pl, unsigned H, unsigned S, unsigned V) {
+    if (c.generic) {
+        if (pl < c.nhs) return pl == 0 ? H : S;
+        return V;
+    }
+    if (pl < c.nhs) return (H == c.hues[pl]) ? S : 0u;
+    return V;
+}
+// Reference's per-pixel term in its exact operation order (navsim/util.pyx:48-72).
+__device__ __forceinline__ double px_term(int hs, int dv, double cw, double wv) {
+    double t = (double)hs;
+    t *= 0.5;
+    t *= cw;
+    t += wv * (double)dv;
+    t /= 255.;
+    return t;
+}
+// Integer hue/saturation term and |dV| of one pixel from the stored planes of a view
+// (bytes lib[pl]) and the raw patch pixel (H,S,V).
+__device__ __forceinline__ void px_ints(const LibCfg& c, const unsigned* lib, unsigned H, unsigned S, unsigned V,
+                                        int& hs, int& dv) {
+    hs = 0;
+    dv = 0;
+    if (c.cw > 0.0) {
+        if (c.generic) {
+            const int lh = (int)lib[0], ls = (int)lib[1];
+            hs = ((int)H == lh) ? abs((int)S - ls) : (int)S + ls;
+        } else {
+            bool in_set = false;
+            for (int k = 0; k < c.nhs; ++k) {
+                const bool mine = (H == c.hues[k]);
+                in_set |= mine;
+                hs += abs((mine ? (int)S : 0) - (int)lib[k]);
+            }
+            if (!in_set) hs += (int)S;
+        }
+    }
+    if (c.hasv) dv = abs((int)V - (int)lib[c.nhs]);
+}
+
+// ------------------------------------------------------------------ library construction
+// Marks every hue that occurs with S > 0 in the raw library (uint8[n_px][3]).
+__global__ void k_hue_scan(const unsigned char* __restrict__ raw, long long n_px, unsigned* __restrict__ bitmap) {
+    __shared__ unsigned local[8];
+    if (threadIdx.x < 8) local[threadIdx.x] = 0;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += stride) {
+        const unsigned H = raw[i * 3 + 0], S = raw[i * 3 + 1];
+        if (S > 0) atomicOr(&local[H >> 5], 1u << (H & 31));
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && local[threadIdx.x]) atomicOr(&bitmap[threadIdx.x], local[threadIdx.x]);
+}
+
+// raw uint8[F][P][3] -> tiles.  One thread per 16-byte chunk (g, plane, q, lane).
+__global__ void k_retile(const unsigned char* __restrict__ raw, uint4* __restrict__ tiles, LibCfg c) {
+    const long long total = (c.Fpad / 64) * (long long)c.npl * c.Q * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    long long r = t >> 6;
+    const int q = (int)(r % c.Q); r /= c.Q;
+    const int pl = (int)(r % c.npl);
+    const long long g = r / c.npl;
+    const long long f = g * 64 + lane;
+    unsigned w[4] = {0, 0, 0, 0};
+    if (f < c.F) {
+        const unsigned char* v = raw + f * (long long)c.P * 3;
+        for (int i = 0; i < 16; ++i) {
+            const int px = q * 16 + i;
+            if (px < c.P) {
+                const unsigned b = plane_byte(c, pl, v[px * 3 + 0], v[px * 3 + 1], v[px * 3 + 2]);
+                w[i >> 2] |= b << (8 * (i & 3));
+            }
+        }
+    }
+    tiles[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Synthetic library straight into tiles: view f, pixel p <- splitmix64((first+f)*P + p + seed*GOLDEN).
+__global__ void k_generate_tiles(uint4* __restrict__ tiles, LibCfg c, unsigned long long seed) {
+    const long long total = (c.Fpad / 64) * (long long)c.npl * c.Q * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    long long r = t >> 6;
+    const int q = (int)(r % c.Q); r /= c.Q;
+    const int pl = (int)(r % c.npl);
+    const long long g = r / c.npl;
+    const long long f = g * 64 + lane;
+    unsigned w[4] = {0, 0, 0, 0};
+    if (f < c.F) {
+        const unsigned long long base = (unsigned long long)(c.first + f) * (unsigned long long)c.P +
+                                        seed * 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < 16; ++i) {
+            const int px = q * 16 + i;
+            if (px < c.P) {
+                unsigned H, S, V;
+                synth_hsv(splitmix64(base + (unsigned long long)px), H, S, V);
+                w[i >> 2] |= plane_byte(c, pl, H, S, V) << (8 * (i & 3));
+            }
+        }
+    }
+    tiles[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Raw synthetic patches uint8[A][P][3] (stream seed+1, like synth.synth_patches).
+__global__ void k_generate_patches(unsigned char* __restrict__ raw, int A, int P, unsigned long long seed) {
+    const long long n = (long long)A * P;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned H, S, V;
+    synth_hsv(splitmix64((unsigned long long)i + (seed + 1ull) * 0x9E3779B97F4A7C15ull), H, S, V);
+    raw[i * 3 + 0] = (unsigned char)H;
+    raw[i * 3 + 1] = (unsigned char)S;
+    raw[i * 3 + 2] = (unsigned char)V;
+}
+
+// tiles -> planes uint8[n][npl][P] for local views [v0, v0+n)   (layout read-back)
+__global__ void k_read_planes(const uint4* __restrict__ tiles, unsigned char* __restrict__ out, LibCfg c,
+                              long long v0, long long n) {
+    const long long total = n * c.npl * (long long)c.P;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int px = (int)(t % c.P);
+    long long r = t / c.P;
+    const int pl = (int)(r % c.npl);
+    const long long f = v0 + r / c.npl;
+    const long long idx = (((f >> 6) * c.npl + pl) * c.Q + (px >> 4)) * 64 + (f & 63);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(tiles + idx);
+    out[t] = b[px & 15];
+}
+
+// ------------------------------------------------------------------ per-step patch preparation
+// raw patches uint8[A][P][3] -> prep[pl][q][j][APAD] dwords (byte b of dword j = pixel 16q+4j+b),
+// hsconst[a] = sum over pixels whose hue is outside the library's hue set of S  (one-hot layout).
+__global__ void k_prep(const unsigned char* __restrict__ raw, unsigned* __restrict__ prep,
+                       int* __restrict__ hsconst, LibCfg c, int A, int APAD) {
+    const int nprep_blocks = gridDim.x - A;
+    if ((int)blockIdx.x < nprep_blocks) {
+        const long long total = (long long)c.npl * c.Q * 4 * APAD;
+        const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= total) return;
+        const int a = (int)(t % APAD);
+        long long r = t / APAD;
+        const int j = (int)(r & 3); r >>= 2;
+        const int q = (int)(r % c.Q);
+        const int pl = (int)(r / c.Q);
+        unsigned w = 0;
+        if (a < A) {
+            const unsigned char* p = raw + (long long)a * c.P * 3;
+            for (int b = 0; b < 4; ++b) {
+                const int px = q * 16 + j * 4 + b;
+                if (px < c.P) w |= plane_byte(c, pl, p[px * 3], p[px * 3 + 1], p[px * 3 + 2]) << (8 * b);
+            }
+        }
+        prep[t] = w;
+    } else {
+        const int a = blockIdx.x - nprep_blocks;
+        __shared__ int part[256];
+        int s = 0;
+        if (!c.generic && c.cw > 0.0) {
+            const unsigned char* p = raw + (long long)a * c.P * 3;
+            for (int px = threadIdx.x; px < c.P; px += blockDim.x) {
+                const unsigned H = p[px * 3];
+                bool in_set = false;
+                for (int k = 0; k < c.nhs; ++k) in_set |= (H == c.hues[k]);
+                if (!in_set) s += p[px * 3 + 1];
+            }
+        }
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) hsconst[a] = part[0];
+    }
+}
+
+// ------------------------------------------------------------------ the scoring kernel
+// Epilogue shared by the integer kernels: LDS holds the per-view integer sums of this view
+// group, red[s][a][lane]; converts them to the familiarity double, stores fam[a][f] and
+// folds the per-heading maximum into amax[a] (order-preserving 64-bit key, atomicMax).
+template <int HAS_HS, int HASV, int APAD>
+__device__ __forceinline__ void score_epilogue(const unsigned* red, const int* __restrict__ hsconst,
+                                               double* __restrict__ fam, unsigned long long* __restrict__ amax,
+                                               const LibCfg& c, int A, long long g) {
+    for (int idx = threadIdx.x; idx < A * 64; idx += blockDim.x) {
+        const int a = idx >> 6, ln = idx & 63;
+        const long long f = g * 64 + ln;
+        double acc = 0.0;
+        if (HAS_HS) acc = c.whs * (double)((long long)red[a * 64 + ln] + (long long)hsconst[a]);
+        if (HASV) {
+            const double v = c.wv * (double)red[(HAS_HS ? APAD : 0) * 64 + a * 64 + ln];
+            acc = HAS_HS ? acc + v : v;
+        }
+        const double val = (double)c.P - acc / 255.;
+        unsigned long long key = 0;
+        if (f < c.F) {
+            fam[(long long)a * c.Fpad + f] = val;
+            key = ordered_key(val);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other > key ? other : key;
+        }
+        if (ln == 0) atomicMax(&amax[a], key);
+    }
+}
+
+// One-hot layout.  NHS saturation planes + optional value plane; APAD headings per pass.
+// grid.x = view groups; block = 64*NW threads, the NW waves split the pixel chunks q.
+template <int NHS, int HASV, int APAD>
+__global__ void __launch_bounds__(256)
+k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, const int* __restrict__ hsconst,
+            double* __restrict__ fam, unsigned long long* __restrict__ amax, LibCfg c, int A) {
+    constexpr int NPL = NHS + HASV;
+    constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
+    __shared__ unsigned red[NSUM * APAD * 64];
+    for (int i = threadIdx.x; i < NSUM * APAD * 64; i += blockDim.x) red[i] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const long long g = blockIdx.x;
+    const int Q = c.Q;
+    const int q0 = (int)(((long long)wave * Q) / nw), q1 = (int)(((long long)(wave + 1) * Q) / nw);
+
+    const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
+
+    unsigned acc_hs[NHS > 0 ? APAD : 1];
+    unsigned acc_v[HASV ? APAD : 1];
+#pragma unroll
+    for (int a = 0; a < (NHS > 0 ? APAD : 1); ++a) acc_hs[a] = 0;
+#pragma unroll
+    for (int a = 0; a < (HASV ? APAD : 1); ++a) acc_v[a] = 0;
+
+    // Register ring PF chunks deep: the loads of chunk q+PF are in flight while chunk q is scored,
+    // so a wave hides HBM latency on its own even when few waves share the SIMD.
+    constexpr int PF = 2;
+    uint4 ring[PF + 1][NPL];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        const int qq = (q0 + s < q1) ? q0 + s : (q1 > q0 ? q1 - 1 : q0);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = base[(long long)(pl * Q + qq) * 64];
+    }
+    for (int q = q0; q < q1; q += PF + 1) {
+#pragma unroll
+        for (int s = 0; s <= PF; ++s) {
+            const int qc = q + s;
+            const int qn = (qc + PF < q1) ? qc + PF : q1 - 1;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) ring[(s + PF) % (PF + 1)][pl] = base[(long long)(pl * Q + qn) * 64];
+            if (qc < q1) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * APAD;
+                    const unsigned lw[4] = {ring[s][pl].x, ring[s][pl].y, ring[s][pl].z, ring[s][pl].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int a = 0; a < APAD; ++a) {
+                            if (pl < NHS) acc_hs[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_hs[a]);
+                            else acc_v[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_v[a]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (NHS > 0) {
+#pragma unroll
+        for (int a = 0; a < APAD; ++a) atomicAdd(&red[a * 64 + lane], acc_hs[a]);
+    }
+    if (HASV) {
+#pragma unroll
+        for (int a = 0; a < APAD; ++a) atomicAdd(&red[(NHS > 0 ? APAD : 0) * 64 + a * 64 + lane], acc_v[a]);
+    }
+    __syncthreads();
+    score_epilogue<(NHS > 0), HASV, APAD>(red, hsconst, fam, amax, c, A, g);
+}
+
+// Generic-hue layout (planes H,S[,V]): per-byte hue compare done with bit tricks.
+template <int HAS_HS, int HASV, int APAD>
+__global__ void __launch_bounds__(256)
+k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, const int* __restrict__ hsconst,
+              double* __restrict__ fam, unsigned long long* __restrict__ amax, LibCfg c, int A) {
+    constexpr int NPL = (HAS_HS ? 2 : 0) + HASV;
+    constexpr int NSUM = HAS_HS + HASV;
+    __shared__ unsigned red[NSUM * APAD * 64];
+    for (int i = threadIdx.x; i < NSUM * APAD * 64; i += blockDim.x) red[i] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const long long g = blockIdx.x;
+    const int Q = c.Q;
+    const int q0 = (int)(((long long)wave * Q) / nw), q1 = (int)(((long long)(wave + 1) * Q) / nw);
+    const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
+
+    unsigned acc_hs[HAS_HS ? APAD : 1];
+    unsigned acc_v[HASV ? APAD : 1];
+#pragma unroll
+    for (int a = 0; a < (HAS_HS ? APAD : 1); ++a) acc_hs[a] = 0;
+#pragma unroll
+    for (int a = 0; a < (HASV ? APAD : 1); ++a) acc_v[a] = 0;
+
+    for (int q = q0; q < q1; ++q) {
+        uint4 L[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) L[pl] = base[(long long)(pl * Q + q) * 64];
+        if constexpr (HAS_HS != 0) {
+            const unsigned* ph = prep + ((long long)(0 * Q + q) * 4) * APAD;
+            const unsigned* ps = prep + ((long long)(1 * Q + q) * 4) * APAD;
+            const unsigned lh[4] = {L[0].x, L[0].y, L[0].z, L[0].w};
+            const unsigned ls[4] = {L[1].x, L[1].y, L[1].z, L[1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) {
+                    const unsigned x = lh[j] ^ ph[j * APAD + a];
+                    unsigned t = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;  // 0x80 where hue differs
+                    const unsigned ne = (t - (t >> 7)) | t;                                  // 0xFF where hue differs
+                    const unsigned sp = ps[j * APAD + a];
+                    unsigned s = acc_hs[a];
+                    s = __builtin_amdgcn_sad_u8(sp & ~ne, ls[j] & ~ne, s);   // same hue: |S_s - S_f|
+                    s = __builtin_amdgcn_sad_u8(sp & ne, 0u, s);             // different hue: S_s + S_f
+                    s = __builtin_amdgcn_sad_u8(ls[j] & ne, 0u, s);
+                    acc_hs[a] = s;
+                }
+            }
+        }
+        if constexpr (HASV != 0) {
+            constexpr int VP = HAS_HS ? 2 : 0;
+            const unsigned* pv = prep + ((long long)(VP * Q + q) * 4) * APAD;
+            const unsigned lv[4] = {L[VP].x, L[VP].y, L[VP].z, L[VP].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) acc_v[a] = __builtin_amdgcn_sad_u8(lv[j], pv[j * APAD + a], acc_v[a]);
+            }
+        }
+    }
+    __syncthreads();
+    if (HAS_HS) {
+#pragma unroll
+        for (int a = 0; a < APAD; ++a) atomicAdd(&red[a * 64 + lane], acc_hs[a]);
+    }
+    if (HASV) {
+#pragma unroll
+        for (int a = 0; a < APAD; ++a) atomicAdd(&red[(HAS_HS ? APAD : 0) * 64 + a * 64 + lane], acc_v[a]);
+    }
+    __syncthreads();
+    score_epilogue<HAS_HS, HASV, APAD>(red, hsconst, fam, amax, c, A, g);
+}
+
+// ------------------------------------------------------------------ exact (sequential fp64) scoring
+// fam[a][f] = the reference's value bit for bit: per-pixel terms in the reference's operation
+// order, accumulated sequentially in row-major pixel order (navsim/util.pyx:44-73).
+// grid = (view groups, ceil(A/4)), block = (64, 4): lane <-> view, threadIdx.y <-> heading.
+__global__ void __launch_bounds__(256)
+k_exact_all(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw_patches,
+            double* __restrict__ fam, unsigned long long* __restrict__ amax, LibCfg c, int A) {
+    const int lane = threadIdx.x;
+    const int a = blockIdx.y * 4 + threadIdx.y;
+    if (a >= A) return;
+    const long long g = blockIdx.x;
+    const long long f = g * 64 + lane;
+    const uint4* base = tiles + g * (long long)c.npl * c.Q * 64 + lane;
+    const unsigned char* pa = raw_patches + (long long)a * c.P * 3;
+    double diff = 0.0;
+    for (int q = 0; q < c.Q; ++q) {
+        uint4 L[kMaxHues + 1];
+        for (int pl = 0; pl < c.npl; ++pl) L[pl] = base[(long long)(pl * c.Q + q) * 64];
+        for (int i = 0; i < 16; ++i) {
+            const int px = q * 16 + i;
+            if (px >= c.P) break;
+            unsigned lib[kMaxHues + 1];
+            for (int pl = 0; pl < c.npl; ++pl) {
+                const unsigned w = (i < 4) ? L[pl].x : (i < 8) ? L[pl].y : (i < 12) ? L[pl].z : L[pl].w;
+                lib[pl] = (w >> (8 * (i & 3))) & 0xffu;
+            }
+            int hs, dv;
+            px_ints(c, lib, pa[px * 3], pa[px * 3 + 1], pa[px * 3 + 2], hs, dv);
+            diff += px_term(hs, dv, c.cw, c.wv);
+        }
+    }
+    const double val = (double)c.P - diff;
+    unsigned long long key = 0;
+    if (f < c.F) {
+        fam[(long long)a * c.Fpad + f] = val;
+        key = ordered_key(val);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if (lane == 0) atomicMax(&amax[a], key);
+}
+
+// ------------------------------------------------------------------ reductions after scoring
+struct StepState {                       // zeroed by one hipMemsetAsync before every step
+    unsigned long long amax[kMaxHeadings];      // ordered key of max_f fam[a][f]
+    unsigned long long aview[kMaxHeadings];     // ~f of the first view attaining it (0 = none)
+    unsigned long long ncand;                   // candidates found (may exceed kCandCap)
+    unsigned long long pad;
+};
+
+// One thread per view: scene_fam[f] = min_a fam[a][f] (NavBySceneFamiliarity.py:301-303),
+// first view attaining each heading's maximum, and the candidate list: every (a,f) whose
+// integer-sum score is within `delta` of the global maximum.
+__global__ void k_finish(const double* __restrict__ fam, StepState* __restrict__ st,
+                         unsigned long long* __restrict__ cand, double* __restrict__ scene,
+                         LibCfg c, int A, double delta, int want_scene) {
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= c.F) return;
+    unsigned long long gkey = 0;
+    for (int a = 0; a < A; ++a) gkey = st->amax[a] > gkey ? st->amax[a] : gkey;
+    const double thr = key_to_double(gkey) - delta;
+    double smin = __longlong_as_double(0x7ff0000000000000ll);
+    for (int a = 0; a < A; ++a) {
+        const double v = fam[(long long)a * c.Fpad + f];
+        smin = v < smin ? v : smin;
+        if (ordered_key(v) == st->amax[a]) atomicMax(&st->aview[a], ~(unsigned long long)f);
+        if (delta >= 0.0 && v >= thr) {
+            const unsigned long long pos = atomicAdd(&st->ncand, 1ull);
+            if (pos < (unsigned long long)kCandCap) cand[pos] = ((unsigned long long)a << 40) | (unsigned long long)f;
+        }
+    }
+    if (want_scene) scene[f] = smin;
+}
+
+// One single-wave block per candidate (a,f): the reference's exact value.  Lanes compute the per-pixel
+// terms of 1024 pixels at a time into LDS; the sequential double accumulation over them is
+// then done identically by every lane (broadcast reads).
+__global__ void __launch_bounds__(64)
+k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw_patches,
+          const StepState* __restrict__ st, const unsigned long long* __restrict__ cand,
+          double* __restrict__ cand_exact, LibCfg c, int force) {
+    __shared__ double terms[1024];
+    const unsigned long long n_all = st->ncand;
+    const int n = (int)(n_all < (unsigned long long)kCandCap ? n_all : (unsigned long long)kCandCap);
+    if (n_all > (unsigned long long)kCandCap) return;       // overflow: host redoes the step in exact mode
+    if (n < 2 && !force) return;
+    const int lane = threadIdx.x;
+    for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
+        const unsigned long long cf = cand[ci];
+        const int a = (int)(cf >> 40);
+        const long long f = (long long)(cf & 0xffffffffffull);
+        const uint4* base = tiles + (f >> 6) * (long long)c.npl * c.Q * 64 + (f & 63);
+        const unsigned char* pa = raw_patches + (long long)a * c.P * 3;
+        double diff = 0.0;
+        for (int qb = 0; qb < c.Q; qb += 64) {
+            const int q = qb + lane;
+            if (q < c.Q) {
+                uint4 L[kMaxHues + 1];
+                for (int pl = 0; pl < c.npl; ++pl) L[pl] = base[(long long)(pl * c.Q + q) * 64];
+                for (int i = 0; i < 16; ++i) {
+                    const int px = q * 16 + i;
+                    double t = 0.0;
+                    if (px < c.P) {
+                        unsigned lib[kMaxHues + 1];
+                        for (int pl = 0; pl < c.npl; ++pl) {
+                            const unsigned w = (i < 4) ? L[pl].x : (i < 8) ? L[pl].y : (i < 12) ? L[pl].z : L[pl].w;
+                            lib[pl] = (w >> (8 * (i & 3))) & 0xffu;
+                        }
+                        int hs, dv;
+                        px_ints(c, lib, pa[px * 3], pa[px * 3 + 1], pa[px * 3 + 2], hs, dv);
+                        t = px_term(hs, dv, c.cw, c.wv);
+                    }
+                    terms[lane * 16 + i] = t;
+                }
+            }
+            __syncthreads();
+            int npx = c.P - qb * 16;
+            npx = npx > 1024 ? 1024 : npx;
+            for (int i = 0; i < npx; ++i) diff += terms[i];
+            __syncthreads();
+        }
+        if (lane == 0) cand_exact[ci] = (double)c.P - diff;
+    }
+}
+
+struct StepResultDev {                   // mirrors dv_step_result (include/dejavu.h)
+    int best_heading;
+    unsigned flags;
+    long long best_view;
+    double best_fam;
+    double approx_max;
+    double delta;
+    long long n_candidates;
+    int n_headings;
+    int reserved;
+    double angle_fam[kMaxHeadings];
+    long long angle_view[kMaxHeadings];
+    double exact_fam[kMaxHeadings];
+    long long exact_view[kMaxHeadings];
+};
+
+// Single wave: np.argmax over headings with the reference's first-maximum rule
+// (NavBySceneFamiliarity.py:315), on exact values wherever the integer scores cannot decide.
+__global__ void k_decide(const StepState* __restrict__ st, const unsigned long long* __restrict__ cand,
+                         const double* __restrict__ cand_exact, StepResultDev* __restrict__ out,
+                         LibCfg c, int A, double delta, int exact_all, int force) {
+    __shared__ unsigned long long ekey[kMaxHeadings];
+    __shared__ unsigned long long eview[kMaxHeadings];
+    const int lane = threadIdx.x;
+    if (lane < kMaxHeadings) { ekey[lane] = 0; eview[lane] = 0; }
+    __syncthreads();
+    const unsigned long long n_all = st->ncand;
+    const bool overflow = n_all > (unsigned long long)kCandCap;
+    const int n = overflow ? 0 : (int)n_all;
+    const bool resolved = !exact_all && !overflow && (n >= 2 || (force && n >= 1));
+    if (resolved) {
+        for (int i = lane; i < n; i += blockDim.x) atomicMax(&ekey[cand[i] >> 40], ordered_key(cand_exact[i]));
+        __syncthreads();
+        for (int i = lane; i < n; i += blockDim.x) {
+            const int a = (int)(cand[i] >> 40);
+            if (ordered_key(cand_exact[i]) == ekey[a]) atomicMax(&eview[a], ~(cand[i] & 0xffffffffffull));
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        unsigned flags = 0;
+        if (resolved) flags |= 1u;
+        if (exact_all) flags |= 2u;
+        if (overflow) flags |= 4u;
+        unsigned long long gkey = 0;
+        int best = 0;
+        unsigned long long bkey = 0;
+        for (int a = 0; a < A; ++a) {
+            const unsigned long long k = st->amax[a];
+            gkey = k > gkey ? k : gkey;
+            double v = key_to_double(k);
+            long long view = (long long)(~st->aview[a]) + c.first;
+            double ex = __longlong_as_double(0xfff0000000000000ll);
+            long long exv = -1;
+            unsigned long long dk = k;                      // key used for the decision
+            if (resolved) {
+                if (ekey[a]) {
+                    ex = key_to_double(ekey[a]);
+                    exv = (long long)(~eview[a]) + c.first;
+                    v = ex;
+                    view = exv;
+                    dk = ekey[a];
+                } else {
+                    dk = 0;                                  // no candidate: cannot be the maximum
+                }
+            }
+            out->angle_fam[a] = v;
+            out->angle_view[a] = view;
+            out->exact_fam[a] = ex;
+            out->exact_view[a] = exv;
+            if (dk > bkey) { bkey = dk; best = a; }          // strict '>' keeps the first maximum
+        }
+        for (int a = A; a < kMaxHeadings; ++a) {
+            out->angle_fam[a] = 0.0; out->angle_view[a] = -1;
+            out->exact_fam[a] = 0.0; out->exact_view[a] = -1;
+        }
+        out->best_heading = best;
+        out->flags = flags;
+        out->best_view = out->angle_view[best];
+        out->best_fam = out->angle_fam[best];
+        out->approx_max = key_to_double(gkey);
+        out->delta = delta;
+        out->n_candidates = (long long)n_all;
+        out->n_headings = A;
+        out->reserved = 0;
+    }
+}
+
+// Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.
+__global__ void k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c2 = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c2.x ^ c2.y ^ c2.z ^ c2.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = src[i]; acc += a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
+}  // namespace dv

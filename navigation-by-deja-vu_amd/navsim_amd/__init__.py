@@ -1,0 +1,22 @@
+"""navsim_amd -- MI355X-native scene-familiarity engine behind the navsim API.
+
+    from navsim_amd import NavBySceneFamiliarity, StopNavigationException, sads_familiarity
+
+mirrors `from navsim import ...` of the reference (navsim/__init__.py:1-3,
+scripts/run_experiment.py:84).  Scoring runs only on the GPU through libdejavu_hip.so
+(include/dejavu.h); importing this package does not need a GPU, scoring does.
+"""
+from .agent import (NavBySceneFamiliarity, StopNavigationException, ReachedEndOfTrainingPathException,
+                    NavigatingFailedException, TooFarFromTrainingPathException,
+                    OutOfLandscapeBoundsException, fill_sensor_from, downscale_chem)
+from .util import sads_familiarity, hip_sads_familiarity
+from .engine import FamiliarityEngine
+from ._native import EngineError
+from . import synth
+
+__all__ = [
+    "NavBySceneFamiliarity", "StopNavigationException", "ReachedEndOfTrainingPathException",
+    "NavigatingFailedException", "TooFarFromTrainingPathException", "OutOfLandscapeBoundsException",
+    "sads_familiarity", "hip_sads_familiarity", "FamiliarityEngine", "EngineError",
+    "fill_sensor_from", "downscale_chem", "synth",
+]

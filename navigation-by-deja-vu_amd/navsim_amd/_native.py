@@ -1,0 +1,135 @@
+"""ctypes binding of libdejavu_hip.so (C ABI: include/dejavu.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module raises,
+and so does everything that scores views.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdejavu_hip.so")
+
+DV_MAX_HEADINGS = 64
+DV_MAX_HUE_PLANES = 4
+DV_STEP_FORCE_RESOLVE = 1
+DV_STEP_WANT_SCENE = 2
+DV_RES_RESOLVED = 1
+DV_RES_EXACT_ALL = 2
+DV_RES_OVERFLOW = 4
+
+ERROR_NAMES = {-1: "DV_ERR_INVALID", -2: "DV_ERR_HIP", -3: "DV_ERR_STATE", -4: "DV_ERR_OOM"}
+
+
+class EngineError(RuntimeError):
+    """A call into libdejavu_hip.so failed (HIP runtime error, bad state, out of memory)."""
+
+
+class StepResult(ctypes.Structure):
+    _fields_ = [
+        ("best_heading", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("best_view", ctypes.c_int64),
+        ("best_fam", ctypes.c_double),
+        ("approx_max", ctypes.c_double),
+        ("delta", ctypes.c_double),
+        ("n_candidates", ctypes.c_int64),
+        ("n_headings", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("angle_fam", ctypes.c_double * DV_MAX_HEADINGS),
+        ("angle_view", ctypes.c_int64 * DV_MAX_HEADINGS),
+        ("exact_fam", ctypes.c_double * DV_MAX_HEADINGS),
+        ("exact_view", ctypes.c_int64 * DV_MAX_HEADINGS),
+    ]
+
+
+class LibInfo(ctypes.Structure):
+    _fields_ = [
+        ("n_views", ctypes.c_int64),
+        ("first_view", ctypes.c_int64),
+        ("h", ctypes.c_int32),
+        ("w", ctypes.c_int32),
+        ("n_planes", ctypes.c_int32),
+        ("n_hue_planes", ctypes.c_int32),
+        ("generic_hue", ctypes.c_int32),
+        ("has_value_plane", ctypes.c_int32),
+        ("tile_bytes", ctypes.c_int64),
+        ("chem_weight", ctypes.c_double),
+        ("hues", ctypes.c_uint8 * DV_MAX_HUE_PLANES),
+    ]
+
+
+_ctx_p = ctypes.c_void_p
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); every symbol include/dejavu.h declares
+PROTOTYPES = {
+    "dv_create": (ctypes.c_int, [ctypes.POINTER(_ctx_p), ctypes.c_int]),
+    "dv_destroy": (None, [_ctx_p]),
+    "dv_last_error": (ctypes.c_char_p, [_ctx_p]),
+    "dv_set_stream": (ctypes.c_int, [_ctx_p, ctypes.c_void_p]),
+    "dv_set_exact": (ctypes.c_int, [_ctx_p, ctypes.c_int]),
+    "dv_set_library": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_double, ctypes.c_int64]),
+    "dv_generate_library": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_double, ctypes.c_int64]),
+    "dv_clear_library": (ctypes.c_int, [_ctx_p]),
+    "dv_get_library_info": (ctypes.c_int, [_ctx_p, ctypes.POINTER(LibInfo)]),
+    "dv_read_planes": (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, _u8p]),
+    "dv_score": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
+    "dv_step": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
+    "dv_resolve": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult)]),
+    "dv_upload_patches": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int]),
+    "dv_generate_patches": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int]),
+    "dv_step_enqueue": (ctypes.c_int, [_ctx_p, ctypes.c_uint32]),
+    "dv_step_wait": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult), _f64p]),
+    "dv_synchronize": (ctypes.c_int, [_ctx_p]),
+    "dv_timer_start": (ctypes.c_int, [_ctx_p]),
+    "dv_timer_stop": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float)]),
+    "dv_profile_kernel": (ctypes.c_int, [_ctx_p, ctypes.c_int]),
+    "dv_profile_read": (ctypes.c_int, [_ctx_p, _f64p, _i64p]),
+    "dv_stream_read_gbps": (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int, _f64p]),
+    "dv_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdejavu_hip.so and declare its prototypes.  Raises EngineError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "HIP library not built: %s is missing (run `make -C navigation-by-deja-vu_amd/csrc` or "
+            "__graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise EngineError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def as_u8(a, what):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8:
+        # mirrors the reference's "Buffer dtype mismatch" ValueError (navsim/util.pyx:31-33)
+        raise ValueError("Buffer dtype mismatch for %s, expected 'uint8_t' but got '%s'" % (what, a.dtype))
+    return a
+
+
+def u8ptr(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def f64ptr(a):
+    return a.ctypes.data_as(_f64p)

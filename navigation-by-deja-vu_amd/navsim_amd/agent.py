@@ -1,0 +1,332 @@
+"""NavBySceneFamiliarity -- the navsim agent API on top of the MI355X familiarity engine.
+
+Keeps the reference agent's constructor arguments, attributes, methods and stop exceptions
+(navsim/NavBySceneFamiliarity.py:22-329) so that experiment drivers written for navsim run
+unchanged; the heading loop of `step_forward` (:283-316) becomes ONE call into the HIP engine.
+Plotting/animation (:332-661) is out of scope.
+
+The sensor model (`get_sensor_mat`, :151-192, with util.pyx:91-168 behind it) is restated here in
+NumPy on the host; it produces the kernel's input and is pinned byte-for-byte by
+tests/golden/t5_sensor.npz.  Moving it onto the GPU is the next row of the scope table.
+"""
+import math
+
+import numpy as np
+
+from .util import sads_familiarity
+
+
+# ---- stop conditions (names and codes of navsim/NavBySceneFamiliarity.py:22-49) ----------------
+class StopNavigationException(Exception):
+    def get_reason(self):
+        raise NotImplementedError()
+
+    def get_code(self):
+        raise NotImplementedError()
+
+    def __str__(self):
+        return self.get_reason()
+
+
+class ReachedEndOfTrainingPathException(StopNavigationException):
+    def get_reason(self):
+        return "agent reached end of training path"
+
+    def get_code(self):
+        return 1
+
+
+class NavigatingFailedException(StopNavigationException):
+    pass
+
+
+class TooFarFromTrainingPathException(NavigatingFailedException):
+    def get_reason(self):
+        return "agent went too far from training path"
+
+    def get_code(self):
+        return -1
+
+
+class OutOfLandscapeBoundsException(NavigatingFailedException):
+    def get_reason(self):
+        return "agent went too close to boundary of landscape"
+
+    def get_code(self):
+        return -2
+
+
+# ---- sensor model ------------------------------------------------------------------------------
+def _c_round(v):
+    """C round(): nearest integer, halves away from zero (util.pyx:122,131,166-167)."""
+    t = np.trunc(v)
+    return t + np.where(np.abs(v - t) >= 0.5, np.copysign(1.0, v), 0.0)
+
+
+def fill_sensor_from(sensor, xpos, ypos, angle, landscape):
+    """Rotated nearest-neighbour crop of the landscape into `sensor` (util.pyx:137-168).
+
+    Sensor pixel (i, j) looks at offset (j - w/2, i - h/2) rotated by -(pi/2 - angle); the
+    landscape is indexed [y, x].  Like the reference (bounds check on, wraparound on) negative
+    indices wrap silently and indices past the end raise IndexError.
+    """
+    rot = -(0.5 * math.pi - angle)
+    c, s = math.cos(rot), math.sin(rot)          # libm, as the reference's cimported cos/sin
+    n0, n1 = sensor.shape[0], sensor.shape[1]
+    px = np.arange(n1, dtype=np.float64)[None, :] - 0.5 * n1
+    py = np.arange(n0, dtype=np.float64)[:, None] - 0.5 * n0
+    rx = px * c - py * s
+    ry = px * s + py * c
+    ix = _c_round(rx + xpos).astype(np.int64)
+    iy = _c_round(ry + ypos).astype(np.int64)
+    sensor[...] = landscape[iy, ix]
+
+
+def downscale_chem(image, factor_rows, factor_cols):
+    """Block downscale with chemistry semantics (util.pyx:91-134).
+
+    Per block: V = round(mean V); H = hue with the largest summed saturation (first maximum, hue 0
+    on all-zero); S = round((sum // factor_rows) * factor_cols) wrapped to uint8 -- the
+    reference's `conc / factor_rows*factor_cols` is C integer division followed by a multiply
+    (util.pyx:131), and its uint8 cast wraps modulo 256.
+    """
+    fr, fc = int(factor_rows), int(factor_cols)
+    nb_r, nb_c = image.shape[0] // fr, image.shape[1] // fc
+    out = np.empty((nb_r, nb_c, image.shape[2]), dtype=np.uint8)
+    blocks = image[:nb_r * fr, :nb_c * fc].reshape(nb_r, fr, nb_c, fc, image.shape[2])
+    blocks = blocks.transpose(0, 2, 1, 3, 4).reshape(nb_r, nb_c, fr * fc, image.shape[2])
+    vsum = blocks[..., 2].astype(np.float64).sum(axis=2)          # integer-valued: exact in any order
+    out[..., 2] = _c_round(vsum / (fr * fc)).astype(np.int64).astype(np.uint8)
+    if fr * fc == 1:
+        out[..., 0] = blocks[..., 0, 0]
+        # hue of a zero-saturation pixel loses the argmax to hue 0 (util.pyx:126-130)
+        out[..., 0][blocks[..., 0, 1] == 0] = 0
+        out[..., 1] = blocks[..., 0, 1]
+        return out
+    conc = np.zeros((nb_r, nb_c, 256), dtype=np.int64)
+    rr, cc = np.meshgrid(np.arange(nb_r), np.arange(nb_c), indexing="ij")
+    for k in range(fr * fc):
+        np.add.at(conc, (rr, cc, blocks[..., k, 0].astype(np.int64)), blocks[..., k, 1].astype(np.int64))
+    which = np.argmax(conc, axis=2)
+    top = np.take_along_axis(conc, which[..., None], axis=2)[..., 0]
+    out[..., 0] = which.astype(np.uint8)
+    out[..., 1] = ((top // fr) * fc & 0xFF).astype(np.uint8)
+    return out
+
+
+class NavBySceneFamiliarity(object):
+    """Agent that walks a landscape by scene familiarity (navsim/NavBySceneFamiliarity.py:57-329).
+
+    `familiarity_model` is the reference's plug-in point: any `model(scenes) -> func(scene, fambuf)`
+    with `func.max_familiarity` works (:72,140,299).  The default is the HIP engine; when the model's
+    `func` carries an `.engine`, `step_forward` scores all headings with one fused device step.
+    `track_scene_familiarity=False` skips the per-view minimum the reference only plots (:301-303).
+    """
+
+    def __init__(self,
+                 landscape,
+                 sensor_dimensions,
+                 step_size,
+                 n_test_angles=60,
+                 sensor_pixel_dimensions=[1, 1],
+                 max_distance_to_training_path=np.inf,
+                 n_sensor_levels=5,
+                 mask_middle_n=0,
+                 threshold_factor=2.,
+                 coverage_threshold_factor=0.8,
+                 saccade_degrees=180.,
+                 sensor_px_per_mm=None,
+                 familiarity_model=None,
+                 track_scene_familiarity=True):
+        self.landscape = landscape
+        self.position = (0., 0.)
+        self.angle = 0.
+
+        self.n_test_angles = n_test_angles
+        self.mask_middle_n = mask_middle_n
+        self.threshold_factor = threshold_factor
+        self.coverage_threshold_factor = coverage_threshold_factor
+        self.sensor_px_per_mm = sensor_px_per_mm
+        self.track_scene_familiarity = track_scene_familiarity
+
+        self.saccade_degrees = saccade_degrees
+        half_sweep = saccade_degrees / 2
+        self.angle_offsets = np.linspace(-(np.pi * half_sweep / 180.), np.pi * half_sweep / 180., self.n_test_angles)
+
+        self.sensor_dimensions = np.asarray(sensor_dimensions)
+        self.sensor_pixel_dimensions = np.asarray(sensor_pixel_dimensions)
+        extent = self.sensor_dimensions * self.sensor_pixel_dimensions      # landscape px, (w, h)
+        assert np.all(extent % 2 == 0)
+        self._sensor_r = np.max(extent / 2)
+        self._roundbuf = np.empty((self.sensor_dimensions[1], self.sensor_dimensions[0]), dtype=np.float32)
+        self._landscape_glimpse_buf = np.empty((extent[1], extent[0], 3), dtype=np.uint8)
+        self.n_sensor_pixels = np.prod(self.sensor_dimensions)
+
+        if not isinstance(n_sensor_levels, tuple):
+            n_sensor_levels = (256, 256, n_sensor_levels)
+        assert len(n_sensor_levels) == 3
+        assert all(2 <= l <= 256 for l in n_sensor_levels)
+        self.n_sensor_levels = n_sensor_levels
+
+        self.step_size = step_size
+        self.angle_familiarity = np.empty(n_test_angles)
+        self.step_familiarity = np.inf
+        self.max_distance_to_training_path = max_distance_to_training_path
+
+        self.clear_training()
+        self.familiarity_model = familiarity_model if familiarity_model is not None else sads_familiarity()
+        self.reset_error()
+
+    # ---- training (:118-148) -------------------------------------------------------------------
+    def train_from_path(self, points):
+        if self.training_path is not None:
+            raise ValueError("Tried to train NavBySceneFamiliarity more than once.")
+        points = np.asarray(points)
+        n = len(points)
+        self.familiar_scenes = np.empty((n, self.sensor_dimensions[1], self.sensor_dimensions[0],
+                                         self.landscape.shape[2]), dtype=self.landscape.dtype)
+        steps = points[1:] - points[:-1]
+        self.training_path_length = np.sum(np.linalg.norm(steps, axis=1))
+        headings = np.arctan2(steps[:, 1], steps[:, 0])
+        # view i looks towards point i+1; the last point reuses the last heading (:129-132)
+        for i in range(n):
+            self.familiar_scenes[i] = self.get_sensor_mat(points[i], headings[min(i, n - 2)])
+
+        self.scene_familiarity = np.zeros(n, dtype=np.float64)
+        self.training_path = points
+        self.reset_error()
+        # library hand-off: the model uploads the views to the GPU here (:140)
+        self._familiarity_func = self.familiarity_model(self.familiar_scenes)
+
+    def clear_training(self):
+        func = getattr(self, "_familiarity_func", None)
+        if func is not None and hasattr(func, "engine"):
+            func.engine.close()
+        self.training_path = None
+        self.familiar_scenes = None
+        self._familiarity_func = None
+        self.scene_familiarity = None
+        self.training_path_length = None
+
+    # ---- sensor (:151-192) ---------------------------------------------------------------------
+    def get_sensor_mat(self, position, angle):
+        r = self._sensor_r
+        ldims = self.landscape.shape
+        if (position[0] <= r) or (position[1] <= r) or \
+           (position[0] >= ldims[1] - r) or (position[1] >= ldims[0] - r):
+            raise OutOfLandscapeBoundsException()
+
+        fill_sensor_from(self._landscape_glimpse_buf, position[0], position[1], angle, self.landscape)
+        out = downscale_chem(self._landscape_glimpse_buf,
+                             self.sensor_pixel_dimensions[1], self.sensor_pixel_dimensions[0])
+
+        # quantise every channel to its number of levels, through float32 like the reference (:176-186)
+        buf = self._roundbuf
+        for ch in range(3):
+            levels = self.n_sensor_levels[ch]
+            buf[:] = out[:, :, ch]
+            buf /= 255
+            buf *= (levels - 1)
+            np.rint(buf, out=buf)
+            buf /= (levels - 1)
+            buf *= 255
+            out[:, :, ch] = buf          # truncating float32 -> uint8 cast
+
+        mid = out.shape[1] // 2
+        out[:, mid - self.mask_middle_n:mid + self.mask_middle_n] = 0
+        return out
+
+    # ---- error / coverage metrics (:195-276) ---------------------------------------------------
+    def reset_error(self):
+        self.stopped_with_exception = None
+        self.navigated_for_frames = 0
+        self._navigation_error = 0.0
+        self._n_navigation_error = 0
+        if self.training_path is not None:
+            self._coverage_array = np.zeros(len(self.training_path), dtype=bool)
+
+    @property
+    def navigation_error(self):
+        return np.sqrt(self._navigation_error / self._n_navigation_error)
+
+    @property
+    def percent_recapitulated(self):
+        return np.sum(self._coverage_array) / len(self._coverage_array)
+
+    def _window(self, n_consecutive_scenes):
+        return int(n_consecutive_scenes * len(self.training_path))
+
+    def percent_recapitulated_forgiving(self, n_consecutive_scenes=0.05):
+        """Furthest point i/F of the path such that the `window` scenes before i are all covered (:218-232)."""
+        win = self._window(n_consecutive_scenes)
+        total = len(self.training_path)
+        for i in range(total, win - 1, -1):
+            if np.all(self._coverage_array[i - win:i]):
+                return i / total
+        return 0.
+
+    def n_captures(self, n_consecutive_scenes=0.05):
+        """Times the agent got onto the path after being off it (:235-249)."""
+        win = self._window(n_consecutive_scenes)
+        cov = self._coverage_array
+        count = 0
+        for i in range(len(self.training_path) - win):
+            if (not cov[i]) and np.all(cov[i + 1:i + 1 + win]):
+                count += 1
+        return count
+
+    def update_error(self):
+        self.navigated_for_frames += 1
+        delta = self.training_path - self.position
+        delta *= delta
+        dist = np.sqrt(np.sum(delta, axis=1))
+        nearest = np.min(dist)
+        if nearest > self.max_distance_to_training_path:
+            raise TooFarFromTrainingPathException()
+        self._navigation_error += nearest * nearest
+        self._n_navigation_error += 1
+        reach = self.coverage_threshold_factor * self.step_size
+        if nearest <= reach:
+            self._coverage_array |= (dist <= reach)
+
+    # ---- the step (:279-329) -------------------------------------------------------------------
+    def step_forward(self, fake=False):
+        position = self.position
+        self.angle_familiarity[:] = np.nan
+        self.scene_familiarity[:] = np.inf
+        assert len(self.familiar_scenes) == len(self.scene_familiarity)
+
+        func = self._familiarity_func
+        engine = getattr(func, "engine", None)
+        if engine is not None:
+            # one fused device step for all headings: kernel + min-merge + max + argmax (:289-315)
+            patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)
+            for a_idex, angle_offset in enumerate(self.angle_offsets):
+                patches[a_idex] = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
+            res = engine.step(patches, want_scene=self.track_scene_familiarity)
+            self.angle_familiarity[:] = res["angle_familiarity"]
+            if self.track_scene_familiarity:
+                self.scene_familiarity[:] = res["scene_familiarity"]
+            best_idex = res["best_idex"]
+        else:
+            # any other plug-in: the reference's loop, one model call per heading
+            temp_fam = np.empty_like(self.scene_familiarity)
+            for a_idex, angle_offset in enumerate(self.angle_offsets):
+                smat = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
+                temp_fam[:] = np.nan
+                func(smat, temp_fam)
+                np.minimum(self.scene_familiarity, temp_fam, out=self.scene_familiarity)
+                self.angle_familiarity[a_idex] = np.max(temp_fam)
+            best_idex = np.argmax(self.angle_familiarity)
+
+        self.step_familiarity = self.angle_familiarity[best_idex]
+        angle = (self.angle + self.angle_offsets[best_idex]) % (2 * np.pi)
+        self.position = (position[0] + self.step_size * np.cos(angle),
+                         position[1] + self.step_size * np.sin(angle))
+        self.angle = angle
+        self.last_best_idex = int(best_idex)
+
+        if not fake:
+            self.update_error()
+            if np.linalg.norm(self.training_path[-1] - self.position) <= self.threshold_factor * self.step_size:
+                raise ReachedEndOfTrainingPathException()

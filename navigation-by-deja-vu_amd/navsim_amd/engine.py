@@ -1,0 +1,189 @@
+"""FamiliarityEngine -- Python face of one dv_ctx (one GPU, one stored-view library shard)."""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+
+
+class FamiliarityEngine(object):
+    """Scores sensor patches against a stored-view library resident in HBM.
+
+    Replaces, behind the reference's interfaces, navsim/util.pyx:31-73 (the kernel) and the
+    heading loop navsim/NavBySceneFamiliarity.py:283-316 (`step`).
+    """
+
+    def __init__(self, device=0, exact=False):
+        self._lib = N.load()
+        self._ctx = N._ctx_p()
+        rc = self._lib.dv_create(ctypes.byref(self._ctx), int(device))
+        if rc != 0:
+            msg = self._lib.dv_last_error(None)
+            raise N.EngineError("dv_create(device=%d) failed: %s (%s)" % (
+                device, msg.decode() if msg else "?", N.ERROR_NAMES.get(rc, rc)))
+        self.device = int(device)
+        self.n_views = 0
+        self.shape = None
+        if exact:
+            self.set_exact(True)
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.dv_last_error(self._ctx)
+            text = "%s failed: %s (%s)" % (what, msg.decode() if msg else "?", N.ERROR_NAMES.get(rc, rc))
+            if rc == -1:
+                raise ValueError(text)
+            raise N.EngineError(text)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.dv_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_exact(self, exact):
+        """exact=True: every score is the reference's sequential-double value (fp64 kernel)."""
+        self._check(self._lib.dv_set_exact(self._ctx, 1 if exact else 0), "dv_set_exact")
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.dv_set_stream(self._ctx, ctypes.c_void_p(hip_stream or 0)), "dv_set_stream")
+
+    def synchronize(self):
+        self._check(self._lib.dv_synchronize(self._ctx), "dv_synchronize")
+
+    # -- library --------------------------------------------------------------------------------
+    def set_library(self, scenes, chem_weight=0.0, first_view=0):
+        """scenes: uint8[F,h,w,3] (NavBySceneFamiliarity.py:122).  Copied to the GPU and re-tiled."""
+        scenes = N.as_u8(scenes, "familiar_scenes")
+        if scenes.ndim != 4:
+            raise ValueError("familiar_scenes must be uint8[F,h,w,3], got shape %r" % (scenes.shape,))
+        F, h, w, ch = scenes.shape
+        self._check(self._lib.dv_set_library(self._ctx, N.u8ptr(scenes), F, h, w, ch, float(chem_weight),
+                                             int(first_view)), "dv_set_library")
+        self.n_views, self.shape = F, (h, w)
+
+    def generate_library(self, seed, n_views, h, w, chem_weight=0.0, first_view=0):
+        """Same bytes as synth.synth_views(seed, n_views, h, w, first_view), generated in HBM."""
+        self._check(self._lib.dv_generate_library(self._ctx, int(seed), int(n_views), int(h), int(w),
+                                                  float(chem_weight), int(first_view)), "dv_generate_library")
+        self.n_views, self.shape = int(n_views), (int(h), int(w))
+
+    def clear_library(self):
+        self._check(self._lib.dv_clear_library(self._ctx), "dv_clear_library")
+        self.n_views, self.shape = 0, None
+
+    def library_info(self):
+        info = N.LibInfo()
+        self._check(self._lib.dv_get_library_info(self._ctx, ctypes.byref(info)), "dv_get_library_info")
+        return dict(n_views=info.n_views, first_view=info.first_view, h=info.h, w=info.w,
+                    n_planes=info.n_planes, n_hue_planes=info.n_hue_planes, generic_hue=bool(info.generic_hue),
+                    has_value_plane=bool(info.has_value_plane), tile_bytes=info.tile_bytes,
+                    chem_weight=info.chem_weight, hues=[int(x) for x in info.hues][:info.n_hue_planes])
+
+    def read_planes(self, v0, n):
+        info = self.library_info()
+        out = np.empty((n, info["n_planes"], info["h"] * info["w"]), dtype=np.uint8)
+        self._check(self._lib.dv_read_planes(self._ctx, int(v0), int(n), N.u8ptr(out)), "dv_read_planes")
+        return out
+
+    # -- scoring --------------------------------------------------------------------------------
+    def _patch_shape_ok(self, p, lead):
+        h, w = self.shape if self.shape else (None, None)
+        want = lead + (h, w, 3)
+        if self.shape is None:
+            raise N.EngineError("no library set")
+        if tuple(p.shape) != want:
+            raise ValueError("patch array has shape %r, expected %r" % (tuple(p.shape), want))
+
+    def score(self, scene, fambuf):
+        """util.pyx:14-20 func(scene, fambuf): writes float64[F] in place."""
+        scene = N.as_u8(scene, "scene")
+        self._patch_shape_ok(scene, ())
+        if not (isinstance(fambuf, np.ndarray) and fambuf.dtype == np.float64):
+            raise ValueError("Buffer dtype mismatch for fambuf, expected 'double'")
+        if fambuf.shape != (self.n_views,):
+            raise ValueError("fambuf has shape %r, expected (%d,)" % (fambuf.shape, self.n_views))
+        if fambuf.flags.c_contiguous:
+            self._check(self._lib.dv_score(self._ctx, N.u8ptr(scene), N.f64ptr(fambuf)), "dv_score")
+        else:
+            tmp = np.empty(self.n_views, dtype=np.float64)
+            self._check(self._lib.dv_score(self._ctx, N.u8ptr(scene), N.f64ptr(tmp)), "dv_score")
+            fambuf[:] = tmp
+        return fambuf
+
+    @staticmethod
+    def _result_dict(r, scene):
+        A = r.n_headings
+        return dict(best_idex=int(r.best_heading), best_view=int(r.best_view), step_familiarity=float(r.best_fam),
+                    angle_familiarity=np.array(r.angle_fam[:A]), angle_view=np.array(r.angle_view[:A]),
+                    exact_familiarity=np.array(r.exact_fam[:A]), exact_view=np.array(r.exact_view[:A]),
+                    approx_max=float(r.approx_max), delta=float(r.delta), n_candidates=int(r.n_candidates),
+                    flags=int(r.flags), scene_familiarity=scene)
+
+    def step(self, patches, want_scene=True, force_resolve=False):
+        """Heading loop of step_forward (:283-316) on patches uint8[A,h,w,3]."""
+        patches = N.as_u8(patches, "patches")
+        if patches.ndim != 4:
+            raise ValueError("patches must be uint8[A,h,w,3]")
+        self._patch_shape_ok(patches, (patches.shape[0],))
+        r = N.StepResult()
+        scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
+        self._check(self._lib.dv_step(self._ctx, N.u8ptr(patches), patches.shape[0],
+                                      N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, ctypes.byref(r),
+                                      N.f64ptr(scene) if want_scene else None), "dv_step")
+        return self._result_dict(r, scene)
+
+    def resolve(self):
+        r = N.StepResult()
+        self._check(self._lib.dv_resolve(self._ctx, ctypes.byref(r)), "dv_resolve")
+        return self._result_dict(r, None)
+
+    # -- resident form --------------------------------------------------------------------------
+    def upload_patches(self, patches):
+        patches = N.as_u8(patches, "patches")
+        self._patch_shape_ok(patches, (patches.shape[0],))
+        self._check(self._lib.dv_upload_patches(self._ctx, N.u8ptr(patches), patches.shape[0]), "dv_upload_patches")
+
+    def generate_patches(self, seed, n_headings):
+        self._check(self._lib.dv_generate_patches(self._ctx, int(seed), int(n_headings)), "dv_generate_patches")
+
+    def step_enqueue(self, want_scene=False, force_resolve=False):
+        flags = (N.DV_STEP_WANT_SCENE if want_scene else 0) | (N.DV_STEP_FORCE_RESOLVE if force_resolve else 0)
+        self._check(self._lib.dv_step_enqueue(self._ctx, flags), "dv_step_enqueue")
+
+    def step_wait(self, want_scene=False):
+        r = N.StepResult()
+        scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
+        self._check(self._lib.dv_step_wait(self._ctx, ctypes.byref(r), N.f64ptr(scene) if want_scene else None),
+                    "dv_step_wait")
+        return self._result_dict(r, scene)
+
+    # -- measurement ----------------------------------------------------------------------------
+    def timer_start(self):
+        self._check(self._lib.dv_timer_start(self._ctx), "dv_timer_start")
+
+    def timer_stop(self):
+        ms = ctypes.c_float(0)
+        self._check(self._lib.dv_timer_stop(self._ctx, ctypes.byref(ms)), "dv_timer_stop")
+        return float(ms.value)
+
+    def profile_kernel(self, enable):
+        self._check(self._lib.dv_profile_kernel(self._ctx, 1 if enable else 0), "dv_profile_kernel")
+
+    def profile_read(self):
+        tot = ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        self._check(self._lib.dv_profile_read(self._ctx, ctypes.byref(tot), ctypes.byref(n)), "dv_profile_read")
+        return float(tot.value), int(n.value)
+
+    def stream_read_gbps(self, n_bytes=1 << 30, iters=10):
+        g = ctypes.c_double(0)
+        self._check(self._lib.dv_stream_read_gbps(self._ctx, int(n_bytes), int(iters), ctypes.byref(g)),
+                    "dv_stream_read_gbps")
+        return float(g.value)

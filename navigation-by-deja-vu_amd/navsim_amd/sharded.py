@@ -1,0 +1,148 @@
+"""View-library sharding across the GPUs of a node: one process and one engine per GPU.
+
+The stored views are independent units (the reference's kernel loops `for fam_idex`,
+navsim/util.pyx:44, and a step only needs the per-heading maximum over views,
+navsim/NavBySceneFamiliarity.py:313), so rank r keeps the contiguous block
+[r*F/N, (r+1)*F/N) of the library and every rank scores the same patches.  The only exchange
+per step is one all-gather of a (3A+3)-double record per rank over RCCL (backend "nccl" on
+ROCm; xGMI is point-to-point and the message is a few hundred bytes, so this is one
+latency-bound hop), after which every rank reduces the records identically:
+
+    angle_familiarity[a] = max_r angle_fam_r[a]
+    best heading         = np.argmax rule on exact values whenever the integer scores tie
+
+Tie protocol (keeps `best_idex` bit-identical to the unsharded reference): each rank reports the
+number of (heading, view) pairs within delta of ITS OWN maximum.  A rank whose maximum is within
+delta of the global maximum is "contending"; if the contending ranks hold more than one
+candidate in total, they re-score their candidates with the exact sequential-double kernel
+(`resolve`) and a second all-gather carries the exact per-heading maxima.
+"""
+import numpy as np
+
+
+def shard_bounds(n_views, world_size, rank):
+    """Contiguous block of views owned by `rank` (np.array_split convention: first ranks get the extras)."""
+    base, extra = divmod(int(n_views), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def pack_record(res):
+    """Per-rank record exchanged each step: [approx_max, n_candidates, resolved, angle_fam[A], angle_view[A], exact_fam[A], exact_view[A]]."""
+    A = len(res["angle_familiarity"])
+    rec = np.empty(3 + 4 * A, dtype=np.float64)
+    rec[0] = res["approx_max"]
+    rec[1] = float(res["n_candidates"])
+    # 0: integer-sum scores only; 1: candidates re-scored exactly; 2: every score exact
+    rec[2] = 2.0 if (res["flags"] & 2) else (1.0 if (res["flags"] & 1) else 0.0)
+    rec[3:3 + A] = res["angle_familiarity"]
+    rec[3 + A:3 + 2 * A] = res["angle_view"]
+    rec[3 + 2 * A:3 + 3 * A] = res["exact_familiarity"]
+    rec[3 + 3 * A:3 + 4 * A] = res["exact_view"]
+    return rec
+
+
+def contending(records, delta):
+    """Indices of the ranks whose local maximum is within delta of the global maximum."""
+    gmax = np.max(records[:, 0])
+    return [r for r in range(records.shape[0]) if records[r, 0] >= gmax - delta], gmax
+
+
+def needs_resolve(records, delta):
+    ranks, _ = contending(records, delta)
+    total = sum(int(records[r, 1]) for r in ranks)
+    unresolved = [r for r in ranks if records[r, 2] == 0.0]
+    return total > 1 and len(unresolved) > 0, ranks
+
+
+def merge_records(records, delta, n_headings):
+    """Global decision from the gathered records; identical on every rank.
+
+    Returns dict(best_idex, best_view, step_familiarity, angle_familiarity[A]).
+    """
+    A = n_headings
+    ranks, _ = contending(records, delta)
+    total = sum(int(records[r, 1]) for r in ranks)
+    ang = records[:, 3:3 + A]
+    view = records[:, 3 + A:3 + 2 * A]
+    angle_fam = ang.max(axis=0)
+    if total <= 1:
+        # a single candidate pair in the whole library: the integer scores decide
+        best = int(np.argmax(angle_fam))
+        owner = int(np.argmax(ang[:, best]))
+        return dict(best_idex=best, best_view=int(view[owner, best]), step_familiarity=float(angle_fam[best]),
+                    angle_familiarity=angle_fam, resolved=False)
+    exact = np.full((records.shape[0], A), -np.inf)
+    exview = np.full((records.shape[0], A), -1.0)
+    for r in ranks:
+        if records[r, 2] == 0.0:
+            raise RuntimeError("rank %d contends for the maximum but did not resolve its candidates" % r)
+        if records[r, 2] == 2.0:                      # exact everywhere: the per-heading maxima are exact
+            exact[r], exview[r] = ang[r], view[r]
+        else:
+            exact[r] = records[r, 3 + 2 * A:3 + 3 * A]
+            exview[r] = records[r, 3 + 3 * A:3 + 4 * A]
+    ex_a = exact.max(axis=0)
+    best = int(np.argmax(ex_a))                      # first maximum, NavBySceneFamiliarity.py:315
+    owners = [r for r in ranks if exact[r, best] == ex_a[best]]
+    best_view = int(min(exview[r, best] for r in owners))
+    out_fam = np.where(np.isfinite(ex_a), ex_a, angle_fam)
+    return dict(best_idex=best, best_view=best_view, step_familiarity=float(ex_a[best]),
+                angle_familiarity=out_fam, resolved=True)
+
+
+class ShardedFamiliarity(object):
+    """One rank's share of a sharded library plus the per-step exchange.
+
+    `engine`  : FamiliarityEngine (or any object with step/resolve returning the same dicts)
+    `gather`  : callable(np.ndarray[k]) -> np.ndarray[world, k], the all-gather (torch.distributed
+                in production, see `torch_gather`; tests inject a gloo one)
+    """
+
+    def __init__(self, engine, gather, rank, world_size):
+        self.engine = engine
+        self.gather = gather
+        self.rank = rank
+        self.world_size = world_size
+        self.exchanges = 0
+
+    def set_library(self, scenes, chem_weight=0.0):
+        """Every rank passes the FULL library (or only its own block via set_library_block)."""
+        lo, hi = shard_bounds(len(scenes), self.world_size, self.rank)
+        self.engine.set_library(scenes[lo:hi], chem_weight, first_view=lo)
+        self.bounds = (lo, hi)
+
+    def step(self, patches, want_scene=False):
+        res = self.engine.step(patches, want_scene=want_scene)
+        A = len(res["angle_familiarity"])
+        delta = res["delta"]
+        records = self.gather(pack_record(res))
+        self.exchanges += 1
+        again, ranks = needs_resolve(records, delta)
+        if again:
+            if self.rank in ranks and not (res["flags"] & 3):
+                res = self.engine.resolve()
+                res["scene_familiarity"] = None
+            records = self.gather(pack_record(res))
+            self.exchanges += 1
+        out = merge_records(records, delta, A)
+        out["scene_familiarity_local"] = res.get("scene_familiarity")
+        return out
+
+
+def torch_gather(device=None):
+    """All-gather over torch.distributed (RCCL when the tensors live on the GPU, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+
+    def gather(vec):
+        t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
+        if device is not None:
+            t = t.to(device)
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
+
+    return gather

@@ -1,0 +1,181 @@
+"""CPU tests of the host side: sensor model, agent loop, synthetic generator, C-ABI surface.
+
+The agent is driven here with a TEST-ONLY familiarity plug-in backed by the oracle (the reference's
+own plug-in point, NavBySceneFamiliarity.py:72), so that the host logic around the GPU call --
+sensor extraction, heading update, error metrics, stop conditions -- is pinned against the
+reference's golden trajectories without a GPU.  The product default (HIP engine) is tested under
+-m gpu.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import navsim_amd
+from navsim_amd import synth
+from navsim_amd import agent as agent_mod
+from oracle import oracle
+from tests.helpers import sha
+from tests.conftest import REPO
+
+
+def test_synth_is_deterministic():
+    v = synth.synth_views(3, 5, 4, 6, first_view=7)
+    assert v.shape == (5, 4, 6, 3) and v.dtype == np.uint8
+    # view f depends only on (seed, first_view + f)
+    w = synth.synth_views(3, 2, 4, 6, first_view=9)
+    assert np.array_equal(v[2:4], w)
+    assert set(np.unique(v[..., 2])) <= {0, 63, 127, 191, 255}
+    assert set(np.unique(v[..., 0])) <= {0, 127} and set(np.unique(v[..., 1])) <= {0, 127}
+    assert sha(synth.synth_views(1, 3, 2, 2)) == sha(synth.synth_views(1, 3, 2, 2))
+    assert int(synth.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0
+    assert int(synth.splitmix64(np.array([1], dtype=np.uint64))[0]) == 0x5692161D100B05E5
+
+
+def test_sensor_model_matches_reference(manifest, golden):
+    z = golden("t5_sensor.npz")
+    meta = manifest["t5_sensor"]["meta"]
+    land = synth.synth_landscape(meta["landscape"]["seed"], meta["landscape"]["size"], meta["landscape"]["grain"])
+    assert sha(land) == meta["landscape"]["sha"]
+    lands = {"land": land, "land2": z["land2"]}
+    assert sha(lands["land2"]) == meta["land2_sha"]
+    for case in manifest["t5_sensor"]["cases"]:
+        levels = case["n_sensor_levels"]
+        levels = tuple(levels) if isinstance(levels, list) else levels
+        nsf = navsim_amd.NavBySceneFamiliarity(
+            lands[case["landscape"]], case["sensor_dimensions"], 1.0, n_test_angles=4,
+            sensor_pixel_dimensions=case["sensor_pixel_dimensions"], n_sensor_levels=levels,
+            mask_middle_n=case["mask_middle_n"], familiarity_model=oracle.sads_familiarity())
+        for k, (x, y, a) in enumerate(case["poses"]):
+            mat = nsf.get_sensor_mat((x, y), a)
+            assert np.array_equal(nsf._landscape_glimpse_buf, z[case["name"] + "_glimpses"][k]), (case["name"], k)
+            assert np.array_equal(mat, z[case["name"] + "_mats"][k]), (case["name"], k)
+    # integer-division quirk of the saturation average (util.pyx:131): 8x2 block of S=255 -> 252
+    assert np.array_equal(agent_mod.downscale_chem(z["dc_quirk_in"], 8, 2), z["dc_quirk_out"])
+
+
+def _run_trajectory(case, land, model):
+    path = synth.sin_training_path(0.5, 0.2 * case["landscape"]["size"], 0.6 * case["landscape"]["size"],
+                                   arclen=1.0)[:case["n_views"]]
+    assert sha(path) == case["path_sha"]
+    nsf = navsim_amd.NavBySceneFamiliarity(
+        land, case["sensor_dimensions"], case["step_size"], n_test_angles=case["n_test_angles"],
+        sensor_pixel_dimensions=case["sensor_pixel_dimensions"], n_sensor_levels=case["n_sensor_levels"],
+        mask_middle_n=case["mask_middle_n"], saccade_degrees=case["saccade_degrees"],
+        max_distance_to_training_path=450, familiarity_model=model)
+    nsf.train_from_path(path)
+    d = path[2] - path[1]
+    nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi)) + np.deg2rad(case["start_angle_offset_deg"])
+    nsf.position = path[1] + np.array(case["start_offset"])
+    best, pos, ang, fam = [], [], [], []
+    status = 0
+    try:
+        for _ in range(case["n_steps"]):
+            nsf.step_forward()
+            best.append(nsf.last_best_idex)
+            pos.append([nsf.position[0], nsf.position[1]])
+            ang.append(nsf.angle)
+            fam.append(nsf.step_familiarity)
+    except navsim_amd.StopNavigationException as e:
+        status = e.get_code()
+    return nsf, np.array(best), np.array(pos), np.array(ang), np.array(fam), status
+
+
+def check_trajectory(case, z, model, fam_rtol):
+    land = synth.synth_landscape(case["landscape"]["seed"], case["landscape"]["size"], case["landscape"]["grain"])
+    assert sha(land) == case["landscape"]["sha"]
+    nsf, best, pos, ang, fam, status = _run_trajectory(case, land, model)
+    name = case["name"]
+    assert sha(nsf.familiar_scenes) == bytes(z[name + "_scenes_sha"]).hex()      # training views byte-identical
+    n = case["steps_recorded"]
+    assert status == case["stop_status"] and len(best) == n
+    assert np.array_equal(best, z[name + "_best"])                   # heading index: bit-identical
+    assert pos.tobytes() == z[name + "_pos"].tobytes()               # hence the same trajectory, bit for bit
+    assert ang.tobytes() == z[name + "_angle"].tobytes()
+    np.testing.assert_allclose(fam, z[name + "_fam"], rtol=fam_rtol, atol=0)
+    np.testing.assert_allclose(nsf.angle_familiarity, z[name + "_last_angle_fam"], rtol=fam_rtol)
+    np.testing.assert_allclose(nsf.scene_familiarity, z[name + "_last_scene_fam"], rtol=fam_rtol)
+    assert nsf.navigated_for_frames == case["navigated_for_frames"]
+    assert float(nsf.navigation_error) == case["navigation_error"]
+    assert float(nsf.percent_recapitulated) == case["percent_recapitulated"]
+    assert float(nsf.percent_recapitulated_forgiving(0.05)) == case["percent_forgiving"]
+    assert int(nsf.n_captures(0.05)) == case["n_captures"]
+    assert float(nsf.training_path_length) == case["training_path_length"]
+
+
+def test_agent_trajectories_match_reference_with_oracle_plugin(manifest, golden):
+    z = golden("t4_trajectory.npz")
+    for case in manifest["t4_trajectory"]:
+        check_trajectory(case, z, oracle.sads_familiarity(case["chem_weight"]), fam_rtol=0)
+
+
+def test_agent_api_and_stop_conditions():
+    land = synth.synth_landscape(5, 200, 4)
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (8, 8), 2.0, n_test_angles=4,
+                                           familiarity_model=oracle.sads_familiarity())
+    for attr in ("position", "angle", "angle_offsets", "angle_familiarity", "scene_familiarity", "step_familiarity",
+                 "familiar_scenes", "training_path", "training_path_length", "navigated_for_frames",
+                 "stopped_with_exception", "n_test_angles", "step_size", "sensor_dimensions",
+                 "sensor_pixel_dimensions", "n_sensor_levels", "mask_middle_n", "saccade_degrees"):
+        assert hasattr(nsf, attr), attr
+    assert nsf.n_sensor_levels == (256, 256, 5)
+    assert np.allclose(nsf.angle_offsets, np.linspace(-np.pi / 2, np.pi / 2, 4))
+    path = np.stack([np.linspace(50, 150, 40), np.full(40, 100.0)], axis=1)
+    nsf.train_from_path(path)
+    with pytest.raises(ValueError):
+        nsf.train_from_path(path)                       # one-shot (NavBySceneFamiliarity.py:119-120)
+    assert nsf.familiar_scenes.shape == (40, 8, 8, 3) and nsf.scene_familiarity.shape == (40,)
+    # walks to the end of the path and says so
+    nsf.position, nsf.angle = path[-1] - np.array([3.0, 0.0]), 0.0
+    with pytest.raises(navsim_amd.ReachedEndOfTrainingPathException) as ei:
+        nsf.step_forward()                              # ends within threshold_factor * step_size (:328)
+    assert ei.value.get_code() == 1 and str(ei.value) == "agent reached end of training path"
+    # out of bounds is raised before anything is scored
+    nsf.position = (2.0, 100.0)
+    with pytest.raises(navsim_amd.OutOfLandscapeBoundsException) as ei:
+        nsf.step_forward()
+    assert ei.value.get_code() == -2 and np.all(np.isnan(nsf.angle_familiarity))
+    # too far from the training path
+    nsf.clear_training()
+    far = navsim_amd.NavBySceneFamiliarity(land, (8, 8), 2.0, n_test_angles=4, max_distance_to_training_path=1.0,
+                                           familiarity_model=oracle.sads_familiarity())
+    far.train_from_path(path)
+    far.position, far.angle = (100.0, 150.0), 0.0
+    with pytest.raises(navsim_amd.TooFarFromTrainingPathException) as ei:
+        far.step_forward()
+    assert ei.value.get_code() == -1
+    assert issubclass(navsim_amd.TooFarFromTrainingPathException, navsim_amd.NavigatingFailedException)
+    assert issubclass(navsim_amd.NavigatingFailedException, navsim_amd.StopNavigationException)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The library loads and exports exactly what include/dejavu.h declares (no compute calls here)."""
+    from navsim_amd import _native
+    header = open(os.path.join(REPO, "include", "dejavu.h")).read()
+    declared = set(re.findall(r"\b(dv_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dv_version()
+    # struct layout agreed between header and binding
+    assert ctypes.sizeof(_native.StepResult) == 56 + 4 * 8 * 64
+    # dv_last_error(NULL) is safe without a context
+    assert isinstance(lib.dv_last_error(None), bytes)
+
+
+def test_no_cpu_fallback_in_product(monkeypatch):
+    """Scoring must fail loudly when the HIP library is missing."""
+    from navsim_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libdejavu_hip.so")
+    with pytest.raises(navsim_amd.EngineError):
+        navsim_amd.FamiliarityEngine()
+    src = ""
+    pkg = os.path.join(REPO, "navigation-by-deja-vu_amd", "navsim_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src += open(os.path.join(pkg, fn)).read()
+    assert "import oracle" not in src and "from oracle" not in src
