@@ -39,6 +39,7 @@ enum {
 
 /* dv_step flags */
 #define DV_STEP_FORCE_RESOLVE 1u   /* run the exact tie resolver even for a single candidate */
+#define DV_STEP_WANT_SCENE    2u   /* dv_step_enqueue: also produce scene_fam (dv_step: pass a buffer) */
 
 /* dv_step_result.flags */
 #define DV_RES_RESOLVED   1u       /* exact tie resolver ran; best_fam / exact_fam are bit-exact */

@@ -446,7 +446,7 @@ extern "C" int dv_step_enqueue(dv_ctx* c, uint32_t flags) {
     if (!c) return DV_ERR_INVALID;
     if (!c->have_lib || c->A < 1) return fail(c, DV_ERR_STATE, "no library or no resident patches");
     HIP_TRY(c, hipSetDevice(c->device));
-    return enqueue_step(c, flags, true, false);
+    return enqueue_step(c, flags, (flags & DV_STEP_WANT_SCENE) != 0, false);
 }
 
 static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam) {
@@ -455,12 +455,14 @@ static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam) {
     if (c->h_result->flags & DV_RES_OVERFLOW) {
         // More near-ties than the candidate list holds: redo this step with exact scores everywhere.
         const int was_exact = c->exact;
+        const long long n_first = c->h_result->n_candidates;
         c->exact = 1;
         int rc = enqueue_step(c, 0, c->last_want_scene, false);
         c->exact = was_exact;
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->h_result->flags |= DV_RES_OVERFLOW;
+        c->h_result->n_candidates = n_first;
     }
     if (result) memcpy(result, c->h_result, sizeof *result);
     if (scene_fam) {

@@ -255,19 +255,18 @@ __global__ void k_prep(const unsigned char* __restrict__ raw, unsigned* __restri
 // Epilogue shared by the integer kernels: LDS holds the per-view integer sums of this view
 // group, red[s][a][lane]; converts them to the familiarity double, stores fam[a][f] and
 // folds the per-heading maximum into amax[a] (order-preserving 64-bit key, atomicMax).
-template <int HAS_HS, int HASV, int APAD>
+template <int HS_RED, int HASV, int APAD>
 __device__ __forceinline__ void score_epilogue(const unsigned* red, const int* __restrict__ hsconst,
                                                double* __restrict__ fam, unsigned long long* __restrict__ amax,
                                                const LibCfg& c, int A, long long g) {
     for (int idx = threadIdx.x; idx < A * 64; idx += blockDim.x) {
         const int a = idx >> 6, ln = idx & 63;
         const long long f = g * 64 + ln;
-        double acc = 0.0;
-        if (HAS_HS) acc = c.whs * (double)((long long)red[a * 64 + ln] + (long long)hsconst[a]);
-        if (HASV) {
-            const double v = c.wv * (double)red[(HAS_HS ? APAD : 0) * 64 + a * 64 + ln];
-            acc = HAS_HS ? acc + v : v;
-        }
+        // S_hs = one-hot plane SADs + the patch pixels whose hue the library never uses
+        long long shs = hsconst[a];
+        if (HS_RED) shs += (long long)red[a * 64 + ln];
+        double acc = c.whs * (double)shs;
+        if (HASV) acc = acc + c.wv * (double)red[(HS_RED ? APAD : 0) * 64 + a * 64 + ln];
         const double val = (double)c.P - acc / 255.;
         unsigned long long key = 0;
         if (f < c.F) {
@@ -354,7 +353,7 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
         for (int a = 0; a < APAD; ++a) atomicAdd(&red[(NHS > 0 ? APAD : 0) * 64 + a * 64 + lane], acc_v[a]);
     }
     __syncthreads();
-    score_epilogue<(NHS > 0), HASV, APAD>(red, hsconst, fam, amax, c, A, g);
+    score_epilogue<(NHS > 0 ? 1 : 0), HASV, APAD>(red, hsconst, fam, amax, c, A, g);
 }
 
 // Generic-hue layout (planes H,S[,V]): per-byte hue compare done with bit tricks.

@@ -131,7 +131,26 @@ def test_tie_cases_take_the_resolver(eng, manifest):
         seen[case["name"]] = (r["n_candidates"], r["flags"])
         assert r["best_idex"] == case["best_idex"]
     assert any(f & 1 for _, f in seen.values()), seen        # resolver ran somewhere
-    assert seen["s_dup"][1] & 4, seen                        # duplicate library overflows -> exact redo
+    assert seen["s_dup"][0] > 1000 and seen["s_dup"][1] & 1, seen
+
+
+def test_candidate_overflow_falls_back_to_exact(eng):
+    """More near-ties than the candidate list holds: the step is redone with exact scores."""
+    base = synth.synth_views(3, 1, 8, 8)[0]
+    lib = np.repeat(base[None], 1000, axis=0)
+    lib[500, 2, 2, 2] ^= 0x40
+    patches = np.repeat(base[None], 8, axis=0)
+    patches[:, 0, 0, 2] ^= 0x80
+    patches[3, 7, 7, 2] ^= 0x01
+    for cw in (0.0, 0.5):
+        eng.set_library(lib, cw)
+        r = eng.step(patches, want_scene=True)
+        want = oracle.step(lib, patches, cw)
+        assert r["flags"] & 4 and r["flags"] & 2, r["flags"]
+        assert r["n_candidates"] > 4096
+        assert r["best_idex"] == want["best_idex"] and r["best_view"] == want["best_view"]
+        assert r["angle_familiarity"].tobytes() == want["angle_familiarity"].tobytes()
+        assert r["scene_familiarity"].tobytes() == want["scene_familiarity"].tobytes()
 
 
 SHAPES = [
