@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- view-comparisons/s of the scene-familiarity hot path on MI355X.
+
+One "step" = one navigation step's scoring: A sensor patches against every stored view of the
+library resident in HBM (scoring kernel, per-view/per-heading reductions, tie resolver, result
+read-back), i.e. what replaces navsim/NavBySceneFamiliarity.py:283-316 + navsim/util.pyx:31-73.
+
+Workload at N=1: BASELINE.json configs[1] -- 64x64 sensor, 50 000 stored views, 16 headings,
+synthetic views (navsim_amd.synth, generated on the device).  With N>1 every rank holds its own
+50 000-view shard of an N*50 000-view library (weak scaling) and the per-step exchange is one
+all-gather of per-heading records over RCCL (navsim_amd/sharded.py).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "navigation-by-deja-vu_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def cpu_baseline(h, w, A, cw, seed, budget_views):
+    """The oracle (C restatement of util.pyx:31-73, 1 thread) on a bounded sample of the same workload."""
+    from navsim_amd import synth
+    from oracle import oracle
+    lib = synth.synth_views(seed, budget_views, h, w)
+    patches = synth.synth_patches(seed, A, h, w)
+    fam = np.empty(budget_views)
+    oracle.sads_hsv(lib[:64], patches[0], cw, fam[:64].copy())      # warm the library / page in
+    t0 = time.perf_counter()
+    for a in range(A):
+        oracle.sads_hsv(lib, patches[a], cw, fam)
+    dt = time.perf_counter() - t0
+    return dict(value=budget_views * A / dt, unit="view-comparisons/s", cores=1, kind="port",
+                sample="%d of the stored views x %d headings, %dx%d sensor, chem_weight %g, %.1f s of one host core; "
+                       "linear in views (util.pyx:44)" % (budget_views, A, w, h, cw, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--views", type=int, default=50000, help="stored views per GPU")
+    ap.add_argument("--sensor", type=int, default=64, help="sensor is SENSOR x SENSOR pixels")
+    ap.add_argument("--headings", type=int, default=16)
+    ap.add_argument("--chem-weight", type=float, default=0.25,
+                    help="0 < cw < 1 keeps all three reference bytes per pixel (H,S,V) algorithmically live")
+    ap.add_argument("--seed", type=int, default=20261004)
+    ap.add_argument("--cpu-views", type=int, default=12288, help="views in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    import navsim_amd
+    from navsim_amd import sharded
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        gather = sharded.torch_gather(device=torch.device("cuda", local_rank))
+    else:
+        gather = None
+
+    F, h, w, A, cw = args.views, args.sensor, args.sensor, args.headings, args.chem_weight
+    eng = navsim_amd.FamiliarityEngine(device=local_rank)
+    eng.generate_library(args.seed, F, h, w, cw, first_view=rank * F)     # this rank's shard, made in HBM
+    eng.generate_patches(args.seed, A)                                     # same patches on every rank
+    info = eng.library_info()
+
+    def one_step():
+        if world > 1:
+            return sharded.step_resident(eng, gather, rank)
+        eng.step_enqueue(want_scene=False)
+        return eng.step_wait(want_scene=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    eng.profile_kernel(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms_total, kern_n = eng.profile_read()
+    eng.profile_kernel(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        comparisons = float(world) * F * A * args.steps
+        kern_ms = kern_ms_total / max(kern_n, 1)
+        algo_bytes = float(F) * h * w * info["n_planes"]      # library bytes one launch must read
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "view-comparisons/sec (sensor x library x headings)",
+            "value": comparisons / dt,
+            "unit": "view-comparisons/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g "
+                            "(BASELINE.json configs[1])" % (w, h, F, A, cw),
+                "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
+                "bytes_per_pixel": info["n_planes"], "parallelism": "library sharded x%d" % world,
+                "exchange": "none" if world == 1 else "1 all-gather of per-heading records per step (RCCL)",
+            },
+            "nav_steps_per_s": args.steps / dt,
+            "best_heading": int(res["best_idex"]),
+            "roofline": {
+                "bound": "hbm", "kernel": "k_sad_tiles", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kern_ms, "launches_timed": kern_n,
+            },
+        }
+        if world == 1 and args.cpu_views > 0:
+            out["cpu_baseline"] = cpu_baseline(h, w, A, cw, args.seed, min(args.cpu_views, F))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

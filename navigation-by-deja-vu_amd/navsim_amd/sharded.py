@@ -146,3 +146,17 @@ def torch_gather(device=None):
         return out.cpu().numpy()
 
     return gather
+
+
+def step_resident(engine, gather, rank):
+    """One sharded step on patches already resident on the device (benchmark / pipelined form)."""
+    engine.step_enqueue(want_scene=False)
+    res = engine.step_wait(want_scene=False)
+    A = len(res["angle_familiarity"])
+    records = gather(pack_record(res))
+    again, ranks = needs_resolve(records, res["delta"])
+    if again:
+        if rank in ranks and not (res["flags"] & 3):
+            res = engine.resolve()
+        records = gather(pack_record(res))
+    return merge_records(records, res["delta"], A)
