@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -40,6 +41,10 @@ struct dv_ctx {
     unsigned char* d_raw_patches = nullptr;   // [64][P][3]
     unsigned* d_prep = nullptr;               // [npl][Q][4][64]
     int* d_hsconst = nullptr;                 // [64]
+    unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
+    unsigned long long* d_pmax = nullptr;     // [64][max(G, Fpad/256)] partial maxima
+    int nchunk = 1;                           // pixel chunks per view group (work items = G * nchunk)
+    int target_waves = 6000;                  // waves the scoring grid aims for (DEJAVU_TARGET_WAVES)
     double* d_fam = nullptr;                  // [64][Fpad]
     double* d_scene = nullptr;                // [Fpad]
     StepState* d_state = nullptr;
@@ -81,6 +86,7 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst); F(c->d_fam); F(c->d_scene);
+    F(c->d_part); F(c->d_pmax);
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact); F(c->d_result);
     if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; }
     if (c->h_scene) { (void)hipHostFree(c->h_scene); c->h_scene = nullptr; }
@@ -112,6 +118,10 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
         return DV_ERR_HIP;
     }
     c->stream = c->own_stream;
+    if (const char* tw = getenv("DEJAVU_TARGET_WAVES")) {
+        const int v = atoi(tw);
+        if (v > 0) c->target_waves = v;
+    }
     *out = c;
     return DV_OK;
 }
@@ -180,6 +190,17 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_raw_patches, (size_t)kMaxHeadings * g.P * 3));
     HIP_TRY(c, hipMalloc(&c->d_prep, (size_t)g.npl * g.Q * 4 * kMaxHeadings * sizeof(unsigned)));
     HIP_TRY(c, hipMalloc(&c->d_hsconst, kMaxHeadings * sizeof(int)));
+    // Work items = (view group, pixel chunk); enough of them to fill the chip with ~target_waves waves.
+    {
+        const long long G = g.Fpad / 64;
+        long long n = (c->target_waves + G / 2) / G;
+        if (n < 1) n = 1;
+        if (n > g.Q) n = g.Q;
+        if (n > 32) n = 32;
+        c->nchunk = (int)n;
+    }
+    HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nchunk * 2 * kMaxHeadings * g.Fpad * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc(&c->d_pmax, (size_t)kMaxHeadings * (g.Fpad / 64) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_fam, (size_t)kMaxHeadings * g.Fpad * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_scene, (size_t)g.Fpad * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_state, sizeof(StepState)));
@@ -350,11 +371,10 @@ extern "C" int dv_generate_patches(dv_ctx* c, uint64_t seed, int A) {
 
 // ------------------------------------------------------------------ scoring launches
 template <int NHS, int HASV>
-static void launch_tiles_apad(dv_ctx* c, int nw) {
-    const dim3 grid((unsigned)(c->cfg.Fpad / 64)), block(64 * nw);
-#define DV_LAUNCH(AP)                                                                                           \
-    hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_hsconst, \
-                       c->d_fam, c->d_state->amax, c->cfg, c->A)
+static void launch_tiles_apad(dv_ctx* c) {
+    const dim3 grid((unsigned)((c->cfg.Fpad / 64 + 3) / 4), (unsigned)c->nchunk), block(256);
+#define DV_LAUNCH(AP) \
+    hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg)
     if (c->APAD == 16) DV_LAUNCH(16);
     else if (c->APAD == 32) DV_LAUNCH(32);
     else DV_LAUNCH(64);
@@ -362,20 +382,19 @@ static void launch_tiles_apad(dv_ctx* c, int nw) {
 }
 
 template <int HAS_HS, int HASV>
-static void launch_generic_apad(dv_ctx* c, int nw) {
-    const dim3 grid((unsigned)(c->cfg.Fpad / 64)), block(64 * nw);
-#define DV_LAUNCH(AP)                                                                                             \
-    hipLaunchKernelGGL((k_sad_generic<HAS_HS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_hsconst, \
-                       c->d_fam, c->d_state->amax, c->cfg, c->A)
+static void launch_generic_apad(dv_ctx* c) {
+    const dim3 grid((unsigned)((c->cfg.Fpad / 64 + 3) / 4), (unsigned)c->nchunk), block(256);
+#define DV_LAUNCH(AP) \
+    hipLaunchKernelGGL((k_sad_generic<HAS_HS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg)
     if (c->APAD == 16) DV_LAUNCH(16);
     else if (c->APAD == 32) DV_LAUNCH(32);
     else DV_LAUNCH(64);
 #undef DV_LAUNCH
 }
 
+// Scoring: integer-sum kernel + combine (or the exact fp64 kernel), then amax[a] without atomics.
 static int launch_scoring(dv_ctx* c) {
     const LibCfg& g = c->cfg;
-    const int nw = 4;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
         if (c->pev_used + 2 > c->pev.size()) {
@@ -390,28 +409,42 @@ static int launch_scoring(dv_ctx* c) {
         c->pev_used += 2;
         HIP_TRY(c, hipEventRecord(e0, c->stream));
     }
+    int n_partial = 0;
     if (c->exact) {
         hipLaunchKernelGGL(k_exact_all, dim3((unsigned)(g.Fpad / 64), (unsigned)((c->A + 3) / 4)), dim3(64, 4), 0, c->stream,
-                           c->d_tiles, c->d_raw_patches, c->d_fam, c->d_state->amax, c->cfg, c->A);
-    } else if (g.generic) {
-        if (g.hasv) launch_generic_apad<1, 1>(c, nw); else launch_generic_apad<1, 0>(c, nw);
+                           c->d_tiles, c->d_raw_patches, c->d_fam, c->d_pmax, c->cfg, c->A);
+        HIP_TRY(c, hipGetLastError());
+        n_partial = (int)(g.Fpad / 64);
     } else {
-        const int key = g.nhs * 2 + g.hasv;
-        switch (key) {
-            case 1: launch_tiles_apad<0, 1>(c, nw); break;
-            case 2: launch_tiles_apad<1, 0>(c, nw); break;
-            case 3: launch_tiles_apad<1, 1>(c, nw); break;
-            case 4: launch_tiles_apad<2, 0>(c, nw); break;
-            case 5: launch_tiles_apad<2, 1>(c, nw); break;
-            case 6: launch_tiles_apad<3, 0>(c, nw); break;
-            case 7: launch_tiles_apad<3, 1>(c, nw); break;
-            case 8: launch_tiles_apad<4, 0>(c, nw); break;
-            case 9: launch_tiles_apad<4, 1>(c, nw); break;
-            default: return fail(c, DV_ERR_STATE, "unsupported plane configuration nhs=%d hasv=%d", g.nhs, g.hasv);
+        int has_hs_sum, has_v_sum = g.hasv;
+        if (g.generic) {
+            has_hs_sum = 1;
+            if (g.hasv) launch_generic_apad<1, 1>(c); else launch_generic_apad<1, 0>(c);
+        } else {
+            has_hs_sum = g.nhs > 0 ? 1 : 0;
+            switch (g.nhs * 2 + g.hasv) {
+                case 1: launch_tiles_apad<0, 1>(c); break;
+                case 2: launch_tiles_apad<1, 0>(c); break;
+                case 3: launch_tiles_apad<1, 1>(c); break;
+                case 4: launch_tiles_apad<2, 0>(c); break;
+                case 5: launch_tiles_apad<2, 1>(c); break;
+                case 6: launch_tiles_apad<3, 0>(c); break;
+                case 7: launch_tiles_apad<3, 1>(c); break;
+                case 8: launch_tiles_apad<4, 0>(c); break;
+                case 9: launch_tiles_apad<4, 1>(c); break;
+                default: return fail(c, DV_ERR_STATE, "unsupported plane configuration nhs=%d hasv=%d", g.nhs, g.hasv);
+            }
         }
+        HIP_TRY(c, hipGetLastError());
+        if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+        n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
+        hipLaunchKernelGGL(k_combine, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
+                           c->d_fam, c->d_pmax, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum);
+        HIP_TRY(c, hipGetLastError());
     }
+    if (c->exact && c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+    hipLaunchKernelGGL(k_amax, dim3((unsigned)c->A), dim3(256), 0, c->stream, c->d_pmax, n_partial, c->d_state->amax);
     HIP_TRY(c, hipGetLastError());
-    if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
     return DV_OK;
 }
 

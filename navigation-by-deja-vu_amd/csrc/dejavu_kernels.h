@@ -252,54 +252,38 @@ __global__ void k_prep(const unsigned char* __restrict__ raw, unsigned* __restri
 }
 
 // ------------------------------------------------------------------ the scoring kernel
-// Epilogue shared by the integer kernels: LDS holds the per-view integer sums of this view
-// group, red[s][a][lane]; converts them to the familiarity double, stores fam[a][f] and
-// folds the per-heading maximum into amax[a] (order-preserving 64-bit key, atomicMax).
-template <int HS_RED, int HASV, int APAD>
-__device__ __forceinline__ void score_epilogue(const unsigned* red, const int* __restrict__ hsconst,
-                                               double* __restrict__ fam, unsigned long long* __restrict__ amax,
-                                               const LibCfg& c, int A, long long g) {
-    for (int idx = threadIdx.x; idx < A * 64; idx += blockDim.x) {
-        const int a = idx >> 6, ln = idx & 63;
-        const long long f = g * 64 + ln;
-        // S_hs = one-hot plane SADs + the patch pixels whose hue the library never uses
-        long long shs = hsconst[a];
-        if (HS_RED) shs += (long long)red[a * 64 + ln];
-        double acc = c.whs * (double)shs;
-        if (HASV) acc = acc + c.wv * (double)red[(HS_RED ? APAD : 0) * 64 + a * 64 + ln];
-        const double val = (double)c.P - acc / 255.;
-        unsigned long long key = 0;
-        if (f < c.F) {
-            fam[(long long)a * c.Fpad + f] = val;
-            key = ordered_key(val);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(key, o);
-            key = other > key ? other : key;
-        }
-        if (ln == 0) atomicMax(&amax[a], key);
-    }
+// Work item = (view group g, pixel chunk c): 64 views x the chunk's pixels x all planes.
+//   grid  = (ceil(G / NW), nchunk), block = 64*NW threads
+//   wave w of block b scores view group b*NW + w; all waves of a block work on the SAME pixel
+//   chunk, and blockIdx.x varies fastest, so waves that run at the same time on a CU read the
+//   same patch dwords in the same order -> the scalar cache serves most s_loads.
+// Why items and not one workgroup per view group: HBM delivers ~1/256 of the chip's bandwidth
+// to each CU (~25 GB/s, ~10 B/clk), so every CU must get an equal share of the bytes; 782 big
+// workgroups on 256 CUs leave the 4-workgroup CUs as a +31 % long pole (measured), thousands of
+// small items balance to a few percent.  Measured on MI355X (exp/sad_v2.hip, 64x64, 50k views,
+// 16 headings, 3 planes): pure read of the same bytes 98-101 us, this structure 126 us with
+// non-temporal loads (143 us with default-policy loads).
+// The kernel's only output is its raw integer sums: part[c][s][a][f] (u32), plain coalesced stores.
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
+    const v4u_t t = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(p));   // read once per step
+    return make_uint4(t.x, t.y, t.z, t.w);
 }
 
 // One-hot layout.  NHS saturation planes + optional value plane; APAD headings per pass.
-// grid.x = view groups; block = 64*NW threads, the NW waves split the pixel chunks q.
 template <int NHS, int HASV, int APAD>
 __global__ void __launch_bounds__(256)
-k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, const int* __restrict__ hsconst,
-            double* __restrict__ fam, unsigned long long* __restrict__ amax, LibCfg c, int A) {
+k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c) {
     constexpr int NPL = NHS + HASV;
     constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
-    __shared__ unsigned red[NSUM * APAD * 64];
-    for (int i = threadIdx.x; i < NSUM * APAD * 64; i += blockDim.x) red[i] = 0;
-
+    constexpr int PF = 1;                      // register ring: chunk q+PF is in flight while q is scored
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
-    const long long g = blockIdx.x;
+    const long long g = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (g >= c.Fpad / 64) return;
     const int Q = c.Q;
-    const int q0 = (int)(((long long)wave * Q) / nw), q1 = (int)(((long long)(wave + 1) * Q) / nw);
-
+    const int nchunk = gridDim.y;
+    const int q0 = (int)(((long long)blockIdx.y * Q) / nchunk), q1 = (int)(((long long)(blockIdx.y + 1) * Q) / nchunk);
     const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
 
     unsigned acc_hs[NHS > 0 ? APAD : 1];
@@ -309,69 +293,64 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
 #pragma unroll
     for (int a = 0; a < (HASV ? APAD : 1); ++a) acc_v[a] = 0;
 
-    // Register ring PF chunks deep: the loads of chunk q+PF are in flight while chunk q is scored,
-    // so a wave hides HBM latency on its own even when few waves share the SIMD.
-    constexpr int PF = 2;
-    uint4 ring[PF + 1][NPL];
+    if (q1 > q0) {
+        uint4 ring[PF + 1][NPL];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) {
-        const int qq = (q0 + s < q1) ? q0 + s : (q1 > q0 ? q1 - 1 : q0);
+        for (int s = 0; s < PF; ++s) {
+            const int qq = (q0 + s < q1) ? q0 + s : q1 - 1;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = base[(long long)(pl * Q + qq) * 64];
-    }
-    for (int q = q0; q < q1; q += PF + 1) {
+            for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = load_tile_nt(&base[(long long)(pl * Q + qq) * 64]);
+        }
+        for (int q = q0; q < q1; q += PF + 1) {
 #pragma unroll
-        for (int s = 0; s <= PF; ++s) {
-            const int qc = q + s;
-            const int qn = (qc + PF < q1) ? qc + PF : q1 - 1;
+            for (int s = 0; s <= PF; ++s) {
+                const int qc = q + s;
+                const int qn = (qc + PF < q1) ? qc + PF : q1 - 1;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) ring[(s + PF) % (PF + 1)][pl] = base[(long long)(pl * Q + qn) * 64];
-            if (qc < q1) {
+                for (int pl = 0; pl < NPL; ++pl)
+                    ring[(s + PF) % (PF + 1)][pl] = load_tile_nt(&base[(long long)(pl * Q + qn) * 64]);
+                if (qc < q1) {
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                    const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * APAD;
-                    const unsigned lw[4] = {ring[s][pl].x, ring[s][pl].y, ring[s][pl].z, ring[s][pl].w};
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * APAD;   // wave-uniform -> s_load
+                        const unsigned lw[4] = {ring[s][pl].x, ring[s][pl].y, ring[s][pl].z, ring[s][pl].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                        for (int a = 0; a < APAD; ++a) {
-                            if (pl < NHS) acc_hs[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_hs[a]);
-                            else acc_v[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_v[a]);
+                            for (int a = 0; a < APAD; ++a) {
+                                if (pl < NHS) acc_hs[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_hs[a]);
+                                else acc_v[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_v[a]);
+                            }
                         }
                     }
                 }
             }
         }
     }
-    __syncthreads();
+    unsigned* dst = part + ((long long)blockIdx.y * NSUM * APAD) * c.Fpad + g * 64 + lane;
     if (NHS > 0) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) atomicAdd(&red[a * 64 + lane], acc_hs[a]);
+        for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
     }
     if (HASV) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) atomicAdd(&red[(NHS > 0 ? APAD : 0) * 64 + a * 64 + lane], acc_v[a]);
+        for (int a = 0; a < APAD; ++a) dst[(long long)((NHS > 0 ? APAD : 0) + a) * c.Fpad] = acc_v[a];
     }
-    __syncthreads();
-    score_epilogue<(NHS > 0 ? 1 : 0), HASV, APAD>(red, hsconst, fam, amax, c, A, g);
 }
 
 // Generic-hue layout (planes H,S[,V]): per-byte hue compare done with bit tricks.
 template <int HAS_HS, int HASV, int APAD>
 __global__ void __launch_bounds__(256)
-k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, const int* __restrict__ hsconst,
-              double* __restrict__ fam, unsigned long long* __restrict__ amax, LibCfg c, int A) {
+k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c) {
     constexpr int NPL = (HAS_HS ? 2 : 0) + HASV;
     constexpr int NSUM = HAS_HS + HASV;
-    __shared__ unsigned red[NSUM * APAD * 64];
-    for (int i = threadIdx.x; i < NSUM * APAD * 64; i += blockDim.x) red[i] = 0;
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
-    const long long g = blockIdx.x;
+    const long long g = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (g >= c.Fpad / 64) return;
     const int Q = c.Q;
-    const int q0 = (int)(((long long)wave * Q) / nw), q1 = (int)(((long long)(wave + 1) * Q) / nw);
+    const int nchunk = gridDim.y;
+    const int q0 = (int)(((long long)blockIdx.y * Q) / nchunk), q1 = (int)(((long long)(blockIdx.y + 1) * Q) / nchunk);
     const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
 
     unsigned acc_hs[HAS_HS ? APAD : 1];
@@ -384,7 +363,7 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
     for (int q = q0; q < q1; ++q) {
         uint4 L[NPL];
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) L[pl] = base[(long long)(pl * Q + q) * 64];
+        for (int pl = 0; pl < NPL; ++pl) L[pl] = load_tile_nt(&base[(long long)(pl * Q + q) * 64]);
         if constexpr (HAS_HS != 0) {
             const unsigned* ph = prep + ((long long)(0 * Q + q) * 4) * APAD;
             const unsigned* ps = prep + ((long long)(1 * Q + q) * 4) * APAD;
@@ -417,26 +396,89 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
             }
         }
     }
-    __syncthreads();
+    unsigned* dst = part + ((long long)blockIdx.y * NSUM * APAD) * c.Fpad + g * 64 + lane;
     if (HAS_HS) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) atomicAdd(&red[a * 64 + lane], acc_hs[a]);
+        for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
     }
     if (HASV) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) atomicAdd(&red[(HAS_HS ? APAD : 0) * 64 + a * 64 + lane], acc_v[a]);
+        for (int a = 0; a < APAD; ++a) dst[(long long)((HAS_HS ? APAD : 0) + a) * c.Fpad] = acc_v[a];
     }
+}
+
+// Sums the per-chunk integer sums and converts them to the familiarity double:
+//   fam[a][f] = P - (0.5*cw*S_hs + (1-cw)*S_v) / 255        (one rounding per operation)
+// grid = (Fpad/256, A); also leaves each block's maximum in blockmax[a][blockIdx.x] (no atomics:
+// thousands of atomics on one 128-byte line serialise at the memory side, ~10 ns each).
+__global__ void __launch_bounds__(256)
+k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, double* __restrict__ fam,
+          unsigned long long* __restrict__ blockmax, LibCfg c, int nchunk, int APAD, int has_hs_sum, int has_v_sum) {
+    __shared__ unsigned long long wmax[4];
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y;
+    const int nsum = has_hs_sum + has_v_sum;
+    unsigned long long key = 0;
+    if (f < c.F) {
+        long long shs = hsconst[a];
+        long long sv = 0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const unsigned* p = part + ((long long)ch * nsum * APAD) * c.Fpad + f;
+            if (has_hs_sum) shs += (long long)p[(long long)a * c.Fpad];
+            if (has_v_sum) sv += (long long)p[(long long)((has_hs_sum ? APAD : 0) + a) * c.Fpad];
+        }
+        double acc = c.whs * (double)shs;
+        if (has_v_sum) acc = acc + c.wv * (double)sv;
+        const double val = (double)c.P - acc / 255.;
+        fam[(long long)a * c.Fpad + f] = val;
+        key = ordered_key(val);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = key;
     __syncthreads();
-    score_epilogue<HAS_HS, HASV, APAD>(red, hsconst, fam, amax, c, A, g);
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmax[0];
+        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+        blockmax[(long long)a * gridDim.x + blockIdx.x] = m;
+    }
+}
+
+// amax[a] = max over the n partial maxima of heading a.  grid = A blocks.
+__global__ void __launch_bounds__(256)
+k_amax(const unsigned long long* __restrict__ partial, int n, unsigned long long* __restrict__ amax) {
+    __shared__ unsigned long long wmax[4];
+    const int a = blockIdx.x;
+    unsigned long long key = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long k = partial[(long long)a * n + i];
+        key = k > key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmax[0];
+        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+        amax[a] = m;
+    }
 }
 
 // ------------------------------------------------------------------ exact (sequential fp64) scoring
 // fam[a][f] = the reference's value bit for bit: per-pixel terms in the reference's operation
 // order, accumulated sequentially in row-major pixel order (navsim/util.pyx:44-73).
 // grid = (view groups, ceil(A/4)), block = (64, 4): lane <-> view, threadIdx.y <-> heading.
+// Leaves each wave's maximum in groupmax[a][g].
 __global__ void __launch_bounds__(256)
 k_exact_all(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw_patches,
-            double* __restrict__ fam, unsigned long long* __restrict__ amax, LibCfg c, int A) {
+            double* __restrict__ fam, unsigned long long* __restrict__ groupmax, LibCfg c, int A) {
     const int lane = threadIdx.x;
     const int a = blockIdx.y * 4 + threadIdx.y;
     if (a >= A) return;
@@ -472,7 +514,7 @@ k_exact_all(const uint4* __restrict__ tiles, const unsigned char* __restrict__ r
         const unsigned long long other = __shfl_xor(key, o);
         key = other > key ? other : key;
     }
-    if (lane == 0) atomicMax(&amax[a], key);
+    if (lane == 0) groupmax[(long long)a * gridDim.x + g] = key;
 }
 
 // ------------------------------------------------------------------ reductions after scoring
