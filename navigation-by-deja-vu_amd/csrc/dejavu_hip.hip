@@ -43,15 +43,19 @@ struct dv_ctx {
     int* d_hsconst = nullptr;                 // [64]
     unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
     unsigned long long* d_pmax = nullptr;     // [64][max(G, Fpad/256)] partial maxima
+    int n_partial = 0;                        // partial maxima per heading left in d_pmax by the last scoring
     int nchunk = 1;                           // pixel chunks per view group (work items = G * nchunk)
-    int target_waves = 6000;                  // waves the scoring grid aims for (DEJAVU_TARGET_WAVES)
+    int target_items = 7000;                  // items the scoring grid aims for: ~27 per CU (DEJAVU_TARGET_ITEMS)
+    int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
+    int waves_per_block = 1;                  // DEJAVU_WPB
+    int prefetch = 1;                         // register ring depth of the scoring kernel, 1 or 2 (DEJAVU_PF)
     double* d_fam = nullptr;                  // [64][Fpad]
     double* d_scene = nullptr;                // [Fpad]
     StepState* d_state = nullptr;
     unsigned long long* d_cand = nullptr;     // [kCandCap]
     double* d_cand_exact = nullptr;           // [kCandCap]
-    StepResultDev* d_result = nullptr;
-    StepResultDev* h_result = nullptr;        // pinned
+    StepResultDev* h_result = nullptr;        // pinned, mapped: the kernels write the result record into it
+    StepResultDev* d_result = nullptr;        // device-side address of h_result
     double* h_scene = nullptr;                // pinned staging for scene_fam
     int A = 0, APAD = 0;                      // resident patches
     bool step_pending = false;
@@ -87,8 +91,8 @@ static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax);
-    F(c->d_state); F(c->d_cand); F(c->d_cand_exact); F(c->d_result);
-    if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; }
+    F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
+    if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; c->d_result = nullptr; }
     if (c->h_scene) { (void)hipHostFree(c->h_scene); c->h_scene = nullptr; }
     c->have_lib = false;
     c->A = 0;
@@ -118,10 +122,13 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
         return DV_ERR_HIP;
     }
     c->stream = c->own_stream;
-    if (const char* tw = getenv("DEJAVU_TARGET_WAVES")) {
-        const int v = atoi(tw);
-        if (v > 0) c->target_waves = v;
-    }
+    auto env_int = [](const char* name, int& dst, int lo, int hi) {
+        if (const char* t = getenv(name)) { const int v = atoi(t); if (v >= lo && v <= hi) dst = v; }
+    };
+    env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
+    env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
+    env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
+    env_int("DEJAVU_PF", c->prefetch, 1, 2);
     *out = c;
     return DV_OK;
 }
@@ -193,7 +200,7 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     // Work items = (view group, pixel chunk); enough of them to fill the chip with ~target_waves waves.
     {
         const long long G = g.Fpad / 64;
-        long long n = (c->target_waves + G / 2) / G;
+        long long n = (c->target_items + G - 1) / G;
         if (n < 1) n = 1;
         if (n > g.Q) n = g.Q;
         if (n > 32) n = 32;
@@ -206,10 +213,12 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_state, sizeof(StepState)));
     HIP_TRY(c, hipMalloc(&c->d_cand, kCandCap * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand_exact, kCandCap * sizeof(double)));
-    HIP_TRY(c, hipMalloc(&c->d_result, sizeof(StepResultDev)));
-    HIP_TRY(c, hipHostMalloc(&c->h_result, sizeof(StepResultDev)));
+    HIP_TRY(c, hipHostMalloc(&c->h_result, sizeof(StepResultDev), hipHostMallocMapped));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_result, c->h_result, 0));
+    memset(c->h_result, 0, sizeof(StepResultDev));
     HIP_TRY(c, hipHostMalloc(&c->h_scene, (size_t)g.Fpad * sizeof(double)));
     HIP_TRY(c, hipMemsetAsync(c->d_hsconst, 0, kMaxHeadings * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(StepState), c->stream));
     c->have_lib = true;
     return DV_OK;
 }
@@ -370,22 +379,38 @@ extern "C" int dv_generate_patches(dv_ctx* c, uint64_t seed, int A) {
 }
 
 // ------------------------------------------------------------------ scoring launches
+// Grid of the scoring kernels: single-wave workgroups (waves_per_block > 1 only for experiments), never more
+// than are resident at once.  Resident waves per CU by accumulator count: the 16-heading kernels need ~52
+// VGPRs but ~95 SGPRs (patch operands are prefetched into SGPRs), which admits 6-7 waves per SIMD.
+static dim3 scoring_grid(const dv_ctx* c, dim3& block) {
+    const int wpb = c->waves_per_block;
+    int wpc = c->waves_per_cu;
+    if (wpc == 0) wpc = c->APAD == 16 ? 28 : (c->APAD == 32 ? 20 : 12);
+    const long long n_items = (c->cfg.Fpad / 64) * (long long)c->nchunk;
+    long long waves = 256ll * wpc;
+    if (waves > n_items) waves = n_items;
+    block = dim3(64 * wpb);
+    return dim3((unsigned)((waves + wpb - 1) / wpb));
+}
+
 template <int NHS, int HASV>
 static void launch_tiles_apad(dv_ctx* c) {
-    const dim3 grid((unsigned)((c->cfg.Fpad / 64 + 3) / 4), (unsigned)c->nchunk), block(256);
-#define DV_LAUNCH(AP) \
-    hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg)
-    if (c->APAD == 16) DV_LAUNCH(16);
-    else if (c->APAD == 32) DV_LAUNCH(32);
-    else DV_LAUNCH(64);
+    dim3 block;
+    const dim3 grid = scoring_grid(c, block);
+#define DV_LAUNCH(AP, PFD) \
+    hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, PFD>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg, c->nchunk)
+    if (c->APAD == 16) { if (c->prefetch == 2) DV_LAUNCH(16, 2); else DV_LAUNCH(16, 1); }
+    else if (c->APAD == 32) { if (c->prefetch == 2) DV_LAUNCH(32, 2); else DV_LAUNCH(32, 1); }
+    else DV_LAUNCH(64, 1);
 #undef DV_LAUNCH
 }
 
 template <int HAS_HS, int HASV>
 static void launch_generic_apad(dv_ctx* c) {
-    const dim3 grid((unsigned)((c->cfg.Fpad / 64 + 3) / 4), (unsigned)c->nchunk), block(256);
+    dim3 block;
+    const dim3 grid = scoring_grid(c, block);
 #define DV_LAUNCH(AP) \
-    hipLaunchKernelGGL((k_sad_generic<HAS_HS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg)
+    hipLaunchKernelGGL((k_sad_generic<HAS_HS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg, c->nchunk)
     if (c->APAD == 16) DV_LAUNCH(16);
     else if (c->APAD == 32) DV_LAUNCH(32);
     else DV_LAUNCH(64);
@@ -412,7 +437,7 @@ static int launch_scoring(dv_ctx* c) {
     int n_partial = 0;
     if (c->exact) {
         hipLaunchKernelGGL(k_exact_all, dim3((unsigned)(g.Fpad / 64), (unsigned)((c->A + 3) / 4)), dim3(64, 4), 0, c->stream,
-                           c->d_tiles, c->d_raw_patches, c->d_fam, c->d_pmax, c->cfg, c->A);
+                           c->d_tiles, c->d_raw_patches, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->A);
         HIP_TRY(c, hipGetLastError());
         n_partial = (int)(g.Fpad / 64);
     } else {
@@ -439,35 +464,24 @@ static int launch_scoring(dv_ctx* c) {
         if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
         n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
         hipLaunchKernelGGL(k_combine, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
-                           c->d_fam, c->d_pmax, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum);
+                           c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum);
         HIP_TRY(c, hipGetLastError());
     }
     if (c->exact && c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
-    hipLaunchKernelGGL(k_amax, dim3((unsigned)c->A), dim3(256), 0, c->stream, c->d_pmax, n_partial, c->d_state->amax);
-    HIP_TRY(c, hipGetLastError());
+    c->n_partial = n_partial;
     return DV_OK;
 }
 
-static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene, bool resolve_only) {
+// One step on the resident patches: scoring (2 launches) + k_tail.  The result record lands in mapped host memory.
+static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     const LibCfg& g = c->cfg;
     const int force = (flags & DV_STEP_FORCE_RESOLVE) ? 1 : 0;
-    if (!resolve_only) {
-        HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(StepState), c->stream));
-        int rc = launch_scoring(c);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_finish, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_state,
-                           c->d_cand, c->d_scene, c->cfg, c->A, c->exact ? -1.0 : c->delta, want_scene ? 1 : 0);
-        HIP_TRY(c, hipGetLastError());
-    }
-    if (!c->exact) {
-        hipLaunchKernelGGL(k_resolve, dim3(256), dim3(64), 0, c->stream, c->d_tiles, c->d_raw_patches, c->d_state, c->d_cand,
-                           c->d_cand_exact, c->cfg, force);
-        HIP_TRY(c, hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result, c->cfg,
-                       c->A, c->exact ? 0.0 : c->delta, c->exact, force);
+    int rc = launch_scoring(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_pmax, c->n_partial,
+                       c->d_state, c->d_cand, c->d_scene, c->d_result, c->cfg, c->A, c->delta,
+                       want_scene ? 1 : 0, c->exact, force);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, sizeof(StepResultDev), hipMemcpyDeviceToHost, c->stream));
     if (want_scene)
         HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     c->step_pending = true;
@@ -475,29 +489,52 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene, bool resolve
     return DV_OK;
 }
 
+// Rare path: re-score the listed candidates with the exact kernel and decide on those values.
+static int enqueue_resolve(dv_ctx* c) {
+    hipLaunchKernelGGL(k_resolve, dim3(256), dim3(64), 0, c->stream, c->d_tiles, c->d_raw_patches, c->d_state, c->d_cand,
+                       c->d_cand_exact, c->cfg);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result, c->cfg,
+                       c->A, c->delta);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
 extern "C" int dv_step_enqueue(dv_ctx* c, uint32_t flags) {
     if (!c) return DV_ERR_INVALID;
     if (!c->have_lib || c->A < 1) return fail(c, DV_ERR_STATE, "no library or no resident patches");
     HIP_TRY(c, hipSetDevice(c->device));
-    return enqueue_step(c, flags, (flags & DV_STEP_WANT_SCENE) != 0, false);
+    return enqueue_step(c, flags, (flags & DV_STEP_WANT_SCENE) != 0);
 }
 
 static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam) {
     if (!c->step_pending) return fail(c, DV_ERR_STATE, "no step enqueued");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_result->flags & kResNeedsResolve) {
+        // Two or more (heading, view) pairs within delta of the maximum: the exact kernel decides.
+        int rc = enqueue_resolve(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     if (c->h_result->flags & DV_RES_OVERFLOW) {
         // More near-ties than the candidate list holds: redo this step with exact scores everywhere.
         const int was_exact = c->exact;
         const long long n_first = c->h_result->n_candidates;
         c->exact = 1;
-        int rc = enqueue_step(c, 0, c->last_want_scene, false);
+        int rc = enqueue_step(c, 0, c->last_want_scene);
         c->exact = was_exact;
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->h_result->flags |= DV_RES_OVERFLOW;
         c->h_result->n_candidates = n_first;
     }
-    if (result) memcpy(result, c->h_result, sizeof *result);
+    if (result) {
+        memcpy(result, c->h_result, sizeof *result);
+        for (int a = c->A; a < kMaxHeadings; ++a) {
+            result->angle_fam[a] = 0.0; result->angle_view[a] = -1;
+            result->exact_fam[a] = 0.0; result->exact_view[a] = -1;
+        }
+    }
     if (scene_fam) {
         if (!c->last_want_scene) return fail(c, DV_ERR_STATE, "scene familiarity was not requested for this step");
         memcpy(scene_fam, c->h_scene, (size_t)c->cfg.F * sizeof(double));
@@ -516,7 +553,7 @@ extern "C" int dv_step(dv_ctx* c, const uint8_t* patches, int A, uint32_t flags,
     int rc = dv_upload_patches(c, patches, A);
     if (rc) return rc;
     if (!result) return fail(c, DV_ERR_INVALID, "result is NULL");
-    rc = enqueue_step(c, flags, scene_fam != nullptr, false);
+    rc = enqueue_step(c, flags, scene_fam != nullptr);
     if (rc) return rc;
     return wait_step(c, result, scene_fam);
 }
@@ -525,12 +562,10 @@ extern "C" int dv_resolve(dv_ctx* c, dv_step_result* result) {
     if (!c || !result) return DV_ERR_INVALID;
     if (!c->have_lib || !c->step_pending) return fail(c, DV_ERR_STATE, "no step to resolve");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->h_result->flags & (DV_RES_EXACT_ALL | DV_RES_RESOLVED)) {   // already exact
-        memcpy(result, c->h_result, sizeof *result);
-        return DV_OK;
+    if (!(c->h_result->flags & (DV_RES_EXACT_ALL | DV_RES_RESOLVED))) {
+        int rc = enqueue_resolve(c);
+        if (rc) return rc;
     }
-    int rc = enqueue_step(c, DV_STEP_FORCE_RESOLVE, false, true);
-    if (rc) return rc;
     return wait_step(c, result, nullptr);
 }
 
@@ -538,7 +573,6 @@ extern "C" int dv_score(dv_ctx* c, const uint8_t* patch, double* fambuf) {
     int rc = dv_upload_patches(c, patch, 1);
     if (rc) return rc;
     if (!fambuf) return fail(c, DV_ERR_INVALID, "fambuf is NULL");
-    HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(StepState), c->stream));
     rc = launch_scoring(c);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(fambuf, c->d_fam, (size_t)c->cfg.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -47,6 +47,19 @@ struct LibCfg {
     double wv;          // 1 - cw            (util.pyx:69)
 };
 
+struct StepState {                       // zeroed by the scoring epilogue (k_combine / k_exact_all) of every step
+    unsigned long long amax[kMaxHeadings];      // ordered key of max_f fam[a][f]
+    unsigned long long aview[kMaxHeadings];     // ~f of the first view attaining it (0 = none)
+    unsigned long long ncand;                   // candidates found (may exceed kCandCap)
+    unsigned done;                              // blocks of k_tail that have finished
+    unsigned pad;
+};
+
+__device__ __forceinline__ void reset_step_state(StepState* st, int tid) {
+    if (tid < kMaxHeadings) st->aview[tid] = 0;
+    if (tid == 0) { st->ncand = 0; st->done = 0; }
+}
+
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ unsigned long long ordered_key(double d) {
     unsigned long long b = (unsigned long long)__double_as_longlong(d);
@@ -252,18 +265,18 @@ __global__ void k_prep(const unsigned char* __restrict__ raw, unsigned* __restri
 }
 
 // ------------------------------------------------------------------ the scoring kernel
-// Work item = (view group g, pixel chunk c): 64 views x the chunk's pixels x all planes.
-//   grid  = (ceil(G / NW), nchunk), block = 64*NW threads
-//   wave w of block b scores view group b*NW + w; all waves of a block work on the SAME pixel
-//   chunk, and blockIdx.x varies fastest, so waves that run at the same time on a CU read the
-//   same patch dwords in the same order -> the scalar cache serves most s_loads.
-// Why items and not one workgroup per view group: HBM delivers ~1/256 of the chip's bandwidth
-// to each CU (~25 GB/s, ~10 B/clk), so every CU must get an equal share of the bytes; 782 big
-// workgroups on 256 CUs leave the 4-workgroup CUs as a +31 % long pole (measured), thousands of
-// small items balance to a few percent.  Measured on MI355X (exp/sad_v2.hip, 64x64, 50k views,
-// 16 headings, 3 planes): pure read of the same bytes 98-101 us, this structure 126 us with
-// non-temporal loads (143 us with default-policy loads).
-// The kernel's only output is its raw integer sums: part[c][s][a][f] (u32), plain coalesced stores.
+// Work item = (pixel chunk c, view group g): 64 views x the chunk's pixels x all planes, scored by
+// ONE wave (lane <-> view).  Items are numbered chunk-major (item = c*G + g) and a fixed grid of
+// single-wave workgroups walks them with a grid stride, so
+//   * every CU gets the same number of items to within one (HBM delivers ~1/256 of the chip's
+//     bandwidth to each CU, ~25 GB/s: a CU holding 7 workgroups where others hold 6 finishes 1/6
+//     later and sets the kernel time -- measured with per-wave stamps in exp/sad_trace.hip);
+//   * the grid never exceeds what is resident at once (no second, almost empty round);
+//   * waves that run at the same time work on the same pixel chunk, so they read the same patch
+//     dwords and the scalar cache serves most s_loads (42 % hits + 42 % hit-on-miss measured).
+// The kernel's only output is its raw integer sums: part[c][s][a][f] (u32), plain coalesced
+// stores; k_combine adds the chunks up.  Loads are non-temporal: each byte is used once per step
+// (default-policy loads measured 13 % slower on the same structure).
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
     const v4u_t t = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(p));   // read once per step
@@ -271,86 +284,97 @@ __device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
 }
 
 // One-hot layout.  NHS saturation planes + optional value plane; APAD headings per pass.
-template <int NHS, int HASV, int APAD>
+template <int NHS, int HASV, int APAD, int PF>      // PF: register ring depth, chunk q+PF is in flight while q is scored
 __global__ void __launch_bounds__(256)
-k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c) {
+k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
+            int nchunk) {
     constexpr int NPL = NHS + HASV;
     constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
-    constexpr int PF = 1;                      // register ring: chunk q+PF is in flight while q is scored
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long g = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (g >= c.Fpad / 64) return;
+    const int nw = blockDim.x >> 6;
     const int Q = c.Q;
-    const int nchunk = gridDim.y;
-    const int q0 = (int)(((long long)blockIdx.y * Q) / nchunk), q1 = (int)(((long long)(blockIdx.y + 1) * Q) / nchunk);
-    const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
+    const long long G = c.Fpad / 64;
+    const long long n_items = G * nchunk;
+    const long long stride = (long long)gridDim.x * nw;
 
-    unsigned acc_hs[NHS > 0 ? APAD : 1];
-    unsigned acc_v[HASV ? APAD : 1];
-#pragma unroll
-    for (int a = 0; a < (NHS > 0 ? APAD : 1); ++a) acc_hs[a] = 0;
-#pragma unroll
-    for (int a = 0; a < (HASV ? APAD : 1); ++a) acc_v[a] = 0;
+    for (long long item = (long long)blockIdx.x * nw + wave; item < n_items; item += stride) {
+        const int ch = (int)(item / G);
+        const long long g = item - (long long)ch * G;
+        const int q0 = (int)(((long long)ch * Q) / nchunk), q1 = (int)(((long long)(ch + 1) * Q) / nchunk);
+        const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
 
-    if (q1 > q0) {
-        uint4 ring[PF + 1][NPL];
+        unsigned acc_hs[NHS > 0 ? APAD : 1];
+        unsigned acc_v[HASV ? APAD : 1];
 #pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            const int qq = (q0 + s < q1) ? q0 + s : q1 - 1;
+        for (int a = 0; a < (NHS > 0 ? APAD : 1); ++a) acc_hs[a] = 0;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = load_tile_nt(&base[(long long)(pl * Q + qq) * 64]);
-        }
-        for (int q = q0; q < q1; q += PF + 1) {
+        for (int a = 0; a < (HASV ? APAD : 1); ++a) acc_v[a] = 0;
+
+        if (q1 > q0) {
+            uint4 ring[PF + 1][NPL];
 #pragma unroll
-            for (int s = 0; s <= PF; ++s) {
-                const int qc = q + s;
-                const int qn = (qc + PF < q1) ? qc + PF : q1 - 1;
+            for (int s = 0; s < PF; ++s) {
+                const int qq = (q0 + s < q1) ? q0 + s : q1 - 1;
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    ring[(s + PF) % (PF + 1)][pl] = load_tile_nt(&base[(long long)(pl * Q + qn) * 64]);
-                if (qc < q1) {
+                for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = load_tile_nt(&base[(long long)(pl * Q + qq) * 64]);
+            }
+            for (int q = q0; q < q1; q += PF + 1) {
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) {
-                        const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * APAD;   // wave-uniform -> s_load
-                        const unsigned lw[4] = {ring[s][pl].x, ring[s][pl].y, ring[s][pl].z, ring[s][pl].w};
+                for (int s = 0; s <= PF; ++s) {
+                    const int qc = q + s;
+                    const int qn = (qc + PF < q1) ? qc + PF : q1 - 1;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                    for (int pl = 0; pl < NPL; ++pl)
+                        ring[(s + PF) % (PF + 1)][pl] = load_tile_nt(&base[(long long)(pl * Q + qn) * 64]);
+                    if (qc < q1) {
 #pragma unroll
-                            for (int a = 0; a < APAD; ++a) {
-                                if (pl < NHS) acc_hs[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_hs[a]);
-                                else acc_v[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_v[a]);
+                        for (int pl = 0; pl < NPL; ++pl) {
+                            const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * APAD;   // wave-uniform -> s_load
+                            const unsigned lw[4] = {ring[s][pl].x, ring[s][pl].y, ring[s][pl].z, ring[s][pl].w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                for (int a = 0; a < APAD; ++a) {
+                                    if (pl < NHS) acc_hs[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_hs[a]);
+                                    else acc_v[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_v[a]);
+                                }
                             }
                         }
                     }
                 }
             }
         }
-    }
-    unsigned* dst = part + ((long long)blockIdx.y * NSUM * APAD) * c.Fpad + g * 64 + lane;
-    if (NHS > 0) {
+        unsigned* dst = part + ((long long)ch * NSUM * APAD) * c.Fpad + g * 64 + lane;
+        if (NHS > 0) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
-    }
-    if (HASV) {
+            for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
+        }
+        if (HASV) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) dst[(long long)((NHS > 0 ? APAD : 0) + a) * c.Fpad] = acc_v[a];
+            for (int a = 0; a < APAD; ++a) dst[(long long)((NHS > 0 ? APAD : 0) + a) * c.Fpad] = acc_v[a];
+        }
     }
 }
 
 // Generic-hue layout (planes H,S[,V]): per-byte hue compare done with bit tricks.
 template <int HAS_HS, int HASV, int APAD>
 __global__ void __launch_bounds__(256)
-k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c) {
+k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
+              int nchunk) {
     constexpr int NPL = (HAS_HS ? 2 : 0) + HASV;
     constexpr int NSUM = HAS_HS + HASV;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long g = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (g >= c.Fpad / 64) return;
+    const int nw = blockDim.x >> 6;
     const int Q = c.Q;
-    const int nchunk = gridDim.y;
-    const int q0 = (int)(((long long)blockIdx.y * Q) / nchunk), q1 = (int)(((long long)(blockIdx.y + 1) * Q) / nchunk);
+    const long long G = c.Fpad / 64;
+    const long long n_items = G * nchunk;
+    const long long stride = (long long)gridDim.x * nw;
+  for (long long item = (long long)blockIdx.x * nw + wave; item < n_items; item += stride) {
+    const int ch = (int)(item / G);
+    const long long g = item - (long long)ch * G;
+    const int q0 = (int)(((long long)ch * Q) / nchunk), q1 = (int)(((long long)(ch + 1) * Q) / nchunk);
     const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
 
     unsigned acc_hs[HAS_HS ? APAD : 1];
@@ -396,7 +420,7 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
             }
         }
     }
-    unsigned* dst = part + ((long long)blockIdx.y * NSUM * APAD) * c.Fpad + g * 64 + lane;
+    unsigned* dst = part + ((long long)ch * NSUM * APAD) * c.Fpad + g * 64 + lane;
     if (HAS_HS) {
 #pragma unroll
         for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
@@ -405,6 +429,7 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
 #pragma unroll
         for (int a = 0; a < APAD; ++a) dst[(long long)((HAS_HS ? APAD : 0) + a) * c.Fpad] = acc_v[a];
     }
+  }
 }
 
 // Sums the per-chunk integer sums and converts them to the familiarity double:
@@ -413,11 +438,13 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
 // thousands of atomics on one 128-byte line serialise at the memory side, ~10 ns each).
 __global__ void __launch_bounds__(256)
 k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, double* __restrict__ fam,
-          unsigned long long* __restrict__ blockmax, LibCfg c, int nchunk, int APAD, int has_hs_sum, int has_v_sum) {
+          unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD,
+          int has_hs_sum, int has_v_sum) {
     __shared__ unsigned long long wmax[4];
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int a = blockIdx.y;
     const int nsum = has_hs_sum + has_v_sum;
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x);
     unsigned long long key = 0;
     if (f < c.F) {
         long long shs = hsconst[a];
@@ -447,30 +474,6 @@ k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, do
     }
 }
 
-// amax[a] = max over the n partial maxima of heading a.  grid = A blocks.
-__global__ void __launch_bounds__(256)
-k_amax(const unsigned long long* __restrict__ partial, int n, unsigned long long* __restrict__ amax) {
-    __shared__ unsigned long long wmax[4];
-    const int a = blockIdx.x;
-    unsigned long long key = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const unsigned long long k = partial[(long long)a * n + i];
-        key = k > key ? k : key;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o);
-        key = other > key ? other : key;
-    }
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long m = wmax[0];
-        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
-        amax[a] = m;
-    }
-}
-
 // ------------------------------------------------------------------ exact (sequential fp64) scoring
 // fam[a][f] = the reference's value bit for bit: per-pixel terms in the reference's operation
 // order, accumulated sequentially in row-major pixel order (navsim/util.pyx:44-73).
@@ -478,8 +481,10 @@ k_amax(const unsigned long long* __restrict__ partial, int n, unsigned long long
 // Leaves each wave's maximum in groupmax[a][g].
 __global__ void __launch_bounds__(256)
 k_exact_all(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw_patches,
-            double* __restrict__ fam, unsigned long long* __restrict__ groupmax, LibCfg c, int A) {
+            double* __restrict__ fam, unsigned long long* __restrict__ groupmax, StepState* __restrict__ st, LibCfg c,
+            int A) {
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.y * 64 + threadIdx.x);
     const int a = blockIdx.y * 4 + threadIdx.y;
     if (a >= A) return;
     const long long g = blockIdx.x;
@@ -518,35 +523,139 @@ k_exact_all(const uint4* __restrict__ tiles, const unsigned char* __restrict__ r
 }
 
 // ------------------------------------------------------------------ reductions after scoring
-struct StepState {                       // zeroed by one hipMemsetAsync before every step
-    unsigned long long amax[kMaxHeadings];      // ordered key of max_f fam[a][f]
-    unsigned long long aview[kMaxHeadings];     // ~f of the first view attaining it (0 = none)
-    unsigned long long ncand;                   // candidates found (may exceed kCandCap)
-    unsigned long long pad;
+struct StepResultDev {                   // mirrors dv_step_result (include/dejavu.h)
+    int best_heading;
+    unsigned flags;
+    long long best_view;
+    double best_fam;
+    double approx_max;
+    double delta;
+    long long n_candidates;
+    int n_headings;
+    int reserved;
+    double angle_fam[kMaxHeadings];
+    long long angle_view[kMaxHeadings];
+    double exact_fam[kMaxHeadings];
+    long long exact_view[kMaxHeadings];
 };
+constexpr unsigned kResNeedsResolve = 8u;   // internal: candidates must be re-scored exactly before deciding
 
-// One thread per view: scene_fam[f] = min_a fam[a][f] (NavBySceneFamiliarity.py:301-303),
-// first view attaining each heading's maximum, and the candidate list: every (a,f) whose
-// integer-sum score is within `delta` of the global maximum.
-__global__ void k_finish(const double* __restrict__ fam, StepState* __restrict__ st,
-                         unsigned long long* __restrict__ cand, double* __restrict__ scene,
-                         LibCfg c, int A, double delta, int want_scene) {
-    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= c.F) return;
-    unsigned long long gkey = 0;
-    for (int a = 0; a < A; ++a) gkey = st->amax[a] > gkey ? st->amax[a] : gkey;
-    const double thr = key_to_double(gkey) - delta;
-    double smin = __longlong_as_double(0x7ff0000000000000ll);
+// np.argmax over headings with the reference's first-maximum rule (NavBySceneFamiliarity.py:315),
+// on exact values wherever the integer scores cannot decide.  One thread.
+__device__ void decide_core(const unsigned long long* amax, const unsigned long long* aview, unsigned long long n_all,
+                            bool resolved, const unsigned long long* ekey, const unsigned long long* eview,
+                            StepResultDev* out, const LibCfg& c, int A, double delta, int exact_all) {
+    unsigned flags = 0;
+    if (resolved) flags |= 1u;
+    if (exact_all) flags |= 2u;
+    if (n_all > (unsigned long long)kCandCap) flags |= 4u;
+    unsigned long long gkey = 0, bkey = 0;
+    int best = 0;
     for (int a = 0; a < A; ++a) {
-        const double v = fam[(long long)a * c.Fpad + f];
-        smin = v < smin ? v : smin;
-        if (ordered_key(v) == st->amax[a]) atomicMax(&st->aview[a], ~(unsigned long long)f);
-        if (delta >= 0.0 && v >= thr) {
-            const unsigned long long pos = atomicAdd(&st->ncand, 1ull);
-            if (pos < (unsigned long long)kCandCap) cand[pos] = ((unsigned long long)a << 40) | (unsigned long long)f;
+        const unsigned long long k = amax[a];
+        gkey = k > gkey ? k : gkey;
+        double v = key_to_double(k);
+        long long view = (long long)(~aview[a]) + c.first;
+        double ex = __longlong_as_double(0xfff0000000000000ll);
+        long long exv = -1;
+        unsigned long long dk = k;                      // key used for the decision
+        if (resolved) {
+            if (ekey[a]) {
+                ex = key_to_double(ekey[a]);
+                exv = (long long)(~eview[a]) + c.first;
+                v = ex;
+                view = exv;
+                dk = ekey[a];
+            } else {
+                dk = 0;                                  // no candidate: cannot be the maximum
+            }
+        }
+        out->angle_fam[a] = v;
+        out->angle_view[a] = view;
+        out->exact_fam[a] = ex;
+        out->exact_view[a] = exv;
+        if (dk > bkey) { bkey = dk; best = a; }          // strict '>' keeps the first maximum
+    }
+    out->best_heading = best;
+    out->best_view = out->angle_view[best];
+    out->best_fam = out->angle_fam[best];
+    out->approx_max = key_to_double(gkey);
+    out->delta = delta;
+    out->n_candidates = (long long)n_all;
+    out->n_headings = A;
+    out->reserved = 0;
+    out->flags = flags;
+}
+
+// Everything after scoring, in one launch.  grid = ceil(F/256) blocks of 256 threads.
+//  1. every block reduces the partial maxima pmax[a][0..n_partial) to amax[a] (LDS; redundant but
+//     tiny, and it avoids both a grid-wide sync and same-line global atomics);
+//  2. one thread per view: scene_fam[f] = min_a fam[a][f] (NavBySceneFamiliarity.py:301-303), the
+//     first view attaining each heading's maximum, and the candidate list: every (a,f) whose
+//     integer-sum score is within `delta` of the global maximum;
+//  3. the block that finishes last decides (argmax over headings) unless more than one candidate
+//     needs exact re-scoring, in which case it flags the result and the host runs k_resolve + k_decide.
+__global__ void __launch_bounds__(256)
+k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
+       StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
+       StepResultDev* __restrict__ out, LibCfg c, int A, double delta, int want_scene, int exact_all, int force) {
+    __shared__ unsigned long long s_amax[kMaxHeadings];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = wave; a < A; a += 4) {
+        unsigned long long key = 0;
+        for (int i = lane; i < n_partial; i += 64) {
+            const unsigned long long k = pmax[(long long)a * n_partial + i];
+            key = k > key ? k : key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other > key ? other : key;
+        }
+        if (lane == 0) s_amax[a] = key;
+    }
+    __syncthreads();
+
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < c.F) {
+        unsigned long long gkey = 0;
+        for (int a = 0; a < A; ++a) gkey = s_amax[a] > gkey ? s_amax[a] : gkey;
+        const double thr = key_to_double(gkey) - delta;
+        double smin = __longlong_as_double(0x7ff0000000000000ll);
+        for (int a = 0; a < A; ++a) {
+            const double v = fam[(long long)a * c.Fpad + f];
+            smin = v < smin ? v : smin;
+            if (ordered_key(v) == s_amax[a]) atomicMax(&st->aview[a], ~(unsigned long long)f);
+            if (!exact_all && v >= thr) {
+                const unsigned long long pos = atomicAdd(&st->ncand, 1ull);
+                if (pos < (unsigned long long)kCandCap) cand[pos] = ((unsigned long long)a << 40) | (unsigned long long)f;
+            }
+        }
+        if (want_scene) scene[f] = smin;
+    }
+
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < A) st->amax[threadIdx.x] = s_amax[threadIdx.x];        // for k_decide on the resolve path
+    if (threadIdx.x == 0) {
+        const unsigned long long n_all = __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool overflow = n_all > (unsigned long long)kCandCap;
+        const bool needs = !exact_all && !overflow && (n_all >= 2 || (force && n_all >= 1));
+        if (needs) {
+            out->flags = kResNeedsResolve;
+            out->n_candidates = (long long)n_all;
+            out->n_headings = A;
+        } else {
+            unsigned long long av[kMaxHeadings];
+            for (int a = 0; a < A; ++a) av[a] = __hip_atomic_load(&st->aview[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            decide_core(s_amax, av, n_all, false, nullptr, nullptr, out, c, A, delta, exact_all);
         }
     }
-    if (want_scene) scene[f] = smin;
 }
 
 // One single-wave block per candidate (a,f): the reference's exact value.  Lanes compute the per-pixel
@@ -555,12 +664,11 @@ __global__ void k_finish(const double* __restrict__ fam, StepState* __restrict__
 __global__ void __launch_bounds__(64)
 k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw_patches,
           const StepState* __restrict__ st, const unsigned long long* __restrict__ cand,
-          double* __restrict__ cand_exact, LibCfg c, int force) {
+          double* __restrict__ cand_exact, LibCfg c) {
     __shared__ double terms[1024];
     const unsigned long long n_all = st->ncand;
-    const int n = (int)(n_all < (unsigned long long)kCandCap ? n_all : (unsigned long long)kCandCap);
     if (n_all > (unsigned long long)kCandCap) return;       // overflow: host redoes the step in exact mode
-    if (n < 2 && !force) return;
+    const int n = (int)n_all;
     const int lane = threadIdx.x;
     for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
         const unsigned long long cf = cand[ci];
@@ -600,92 +708,25 @@ k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw
     }
 }
 
-struct StepResultDev {                   // mirrors dv_step_result (include/dejavu.h)
-    int best_heading;
-    unsigned flags;
-    long long best_view;
-    double best_fam;
-    double approx_max;
-    double delta;
-    long long n_candidates;
-    int n_headings;
-    int reserved;
-    double angle_fam[kMaxHeadings];
-    long long angle_view[kMaxHeadings];
-    double exact_fam[kMaxHeadings];
-    long long exact_view[kMaxHeadings];
-};
-
-// Single wave: np.argmax over headings with the reference's first-maximum rule
-// (NavBySceneFamiliarity.py:315), on exact values wherever the integer scores cannot decide.
+// Resolve path only: single wave; folds the exact candidate values into per-heading maxima, then decides.
 __global__ void k_decide(const StepState* __restrict__ st, const unsigned long long* __restrict__ cand,
                          const double* __restrict__ cand_exact, StepResultDev* __restrict__ out,
-                         LibCfg c, int A, double delta, int exact_all, int force) {
+                         LibCfg c, int A, double delta) {
     __shared__ unsigned long long ekey[kMaxHeadings];
     __shared__ unsigned long long eview[kMaxHeadings];
     const int lane = threadIdx.x;
     if (lane < kMaxHeadings) { ekey[lane] = 0; eview[lane] = 0; }
     __syncthreads();
     const unsigned long long n_all = st->ncand;
-    const bool overflow = n_all > (unsigned long long)kCandCap;
-    const int n = overflow ? 0 : (int)n_all;
-    const bool resolved = !exact_all && !overflow && (n >= 2 || (force && n >= 1));
-    if (resolved) {
-        for (int i = lane; i < n; i += blockDim.x) atomicMax(&ekey[cand[i] >> 40], ordered_key(cand_exact[i]));
-        __syncthreads();
-        for (int i = lane; i < n; i += blockDim.x) {
-            const int a = (int)(cand[i] >> 40);
-            if (ordered_key(cand_exact[i]) == ekey[a]) atomicMax(&eview[a], ~(cand[i] & 0xffffffffffull));
-        }
-        __syncthreads();
+    const int n = n_all > (unsigned long long)kCandCap ? 0 : (int)n_all;
+    for (int i = lane; i < n; i += blockDim.x) atomicMax(&ekey[cand[i] >> 40], ordered_key(cand_exact[i]));
+    __syncthreads();
+    for (int i = lane; i < n; i += blockDim.x) {
+        const int a = (int)(cand[i] >> 40);
+        if (ordered_key(cand_exact[i]) == ekey[a]) atomicMax(&eview[a], ~(cand[i] & 0xffffffffffull));
     }
-    if (lane == 0) {
-        unsigned flags = 0;
-        if (resolved) flags |= 1u;
-        if (exact_all) flags |= 2u;
-        if (overflow) flags |= 4u;
-        unsigned long long gkey = 0;
-        int best = 0;
-        unsigned long long bkey = 0;
-        for (int a = 0; a < A; ++a) {
-            const unsigned long long k = st->amax[a];
-            gkey = k > gkey ? k : gkey;
-            double v = key_to_double(k);
-            long long view = (long long)(~st->aview[a]) + c.first;
-            double ex = __longlong_as_double(0xfff0000000000000ll);
-            long long exv = -1;
-            unsigned long long dk = k;                      // key used for the decision
-            if (resolved) {
-                if (ekey[a]) {
-                    ex = key_to_double(ekey[a]);
-                    exv = (long long)(~eview[a]) + c.first;
-                    v = ex;
-                    view = exv;
-                    dk = ekey[a];
-                } else {
-                    dk = 0;                                  // no candidate: cannot be the maximum
-                }
-            }
-            out->angle_fam[a] = v;
-            out->angle_view[a] = view;
-            out->exact_fam[a] = ex;
-            out->exact_view[a] = exv;
-            if (dk > bkey) { bkey = dk; best = a; }          // strict '>' keeps the first maximum
-        }
-        for (int a = A; a < kMaxHeadings; ++a) {
-            out->angle_fam[a] = 0.0; out->angle_view[a] = -1;
-            out->exact_fam[a] = 0.0; out->exact_view[a] = -1;
-        }
-        out->best_heading = best;
-        out->flags = flags;
-        out->best_view = out->angle_view[best];
-        out->best_fam = out->angle_fam[best];
-        out->approx_max = key_to_double(gkey);
-        out->delta = delta;
-        out->n_candidates = (long long)n_all;
-        out->n_headings = A;
-        out->reserved = 0;
-    }
+    __syncthreads();
+    if (lane == 0) decide_core(st->amax, st->aview, n_all, n > 0, ekey, eview, out, c, A, delta, 0);
 }
 
 // Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.
