@@ -623,38 +623,67 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
         for (int a = 0; a < A; ++a) gkey = s_amax[a] > gkey ? s_amax[a] : gkey;
         const double thr = key_to_double(gkey) - delta;
         double smin = __longlong_as_double(0x7ff0000000000000ll);
-        for (int a = 0; a < A; ++a) {
-            const double v = fam[(long long)a * c.Fpad + f];
-            smin = v < smin ? v : smin;
-            if (ordered_key(v) == s_amax[a]) atomicMax(&st->aview[a], ~(unsigned long long)f);
-            if (!exact_all && v >= thr) {
-                const unsigned long long pos = atomicAdd(&st->ncand, 1ull);
-                if (pos < (unsigned long long)kCandCap) cand[pos] = ((unsigned long long)a << 40) | (unsigned long long)f;
+        for (int a0 = 0; a0 < A; a0 += 16) {
+            double v[16];                                   // all loads of a tile issued before the first use
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = fam[(long long)(a0 + k < A ? a0 + k : A - 1) * c.Fpad + f];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int a = a0 + k;
+                if (a < A) {
+                    smin = v[k] < smin ? v[k] : smin;
+                    if (ordered_key(v[k]) == s_amax[a]) atomicMax(&st->aview[a], ~(unsigned long long)f);
+                    if (!exact_all && v[k] >= thr) {
+                        const unsigned long long pos = atomicAdd(&st->ncand, 1ull);
+                        if (pos < (unsigned long long)kCandCap) cand[pos] = ((unsigned long long)a << 40) | (unsigned long long)f;
+                    }
+                }
             }
         }
         if (want_scene) scene[f] = smin;
     }
 
-    __threadfence();
+    // Arrival ticket: every wave drains its own stores/atomics, one lane publishes (release, agent scope).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x < A) st->amax[threadIdx.x] = s_amax[threadIdx.x];        // for k_decide on the resolve path
+
+    // Last block: decide, build the record in LDS, then copy it out with wide coalesced stores
+    // (the record lives in mapped host memory: a few PCIe writes instead of one per field).
+    __shared__ StepResultDev s_res;
+    __shared__ unsigned long long s_aview[kMaxHeadings];
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x < A) {
+        st->amax[threadIdx.x] = s_amax[threadIdx.x];                            // for k_decide on the resolve path
+        s_aview[threadIdx.x] = __hip_atomic_load(&st->aview[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long n_all = __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool overflow = n_all > (unsigned long long)kCandCap;
         const bool needs = !exact_all && !overflow && (n_all >= 2 || (force && n_all >= 1));
         if (needs) {
-            out->flags = kResNeedsResolve;
-            out->n_candidates = (long long)n_all;
-            out->n_headings = A;
+            s_res.flags = kResNeedsResolve;
+            s_res.n_candidates = (long long)n_all;
+            s_res.n_headings = A;
         } else {
-            unsigned long long av[kMaxHeadings];
-            for (int a = 0; a < A; ++a) av[a] = __hip_atomic_load(&st->aview[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            decide_core(s_amax, av, n_all, false, nullptr, nullptr, out, c, A, delta, exact_all);
+            decide_core(s_amax, s_aview, n_all, false, nullptr, nullptr, &s_res, c, A, delta, exact_all);
         }
+    }
+    __syncthreads();
+    // header (7 x 8 bytes) + the first A entries of each of the four per-heading arrays
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
+    if (threadIdx.x < 7) dst[threadIdx.x] = src[threadIdx.x];
+    for (int i = threadIdx.x; i < 4 * A; i += blockDim.x) {
+        const int o = 7 + (i / A) * kMaxHeadings + (i % A);
+        dst[o] = src[o];
     }
 }
 

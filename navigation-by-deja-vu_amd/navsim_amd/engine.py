@@ -120,11 +120,15 @@ class FamiliarityEngine(object):
     @staticmethod
     def _result_dict(r, scene):
         A = r.n_headings
-        return dict(best_idex=int(r.best_heading), best_view=int(r.best_view), step_familiarity=float(r.best_fam),
-                    angle_familiarity=np.array(r.angle_fam[:A]), angle_view=np.array(r.angle_view[:A]),
-                    exact_familiarity=np.array(r.exact_fam[:A]), exact_view=np.array(r.exact_view[:A]),
-                    approx_max=float(r.approx_max), delta=float(r.delta), n_candidates=int(r.n_candidates),
-                    flags=int(r.flags), scene_familiarity=scene)
+        # one copy of the record's four per-heading arrays ([4][64] 8-byte values after the 56-byte header)
+        raw = np.frombuffer(r, dtype=np.uint8, count=4 * 8 * N.DV_MAX_HEADINGS, offset=56).copy()
+        f64 = raw.view(np.float64).reshape(4, N.DV_MAX_HEADINGS)
+        i64 = raw.view(np.int64).reshape(4, N.DV_MAX_HEADINGS)
+        return dict(best_idex=r.best_heading, best_view=r.best_view, step_familiarity=r.best_fam,
+                    angle_familiarity=f64[0, :A], angle_view=i64[1, :A],
+                    exact_familiarity=f64[2, :A], exact_view=i64[3, :A],
+                    approx_max=r.approx_max, delta=r.delta, n_candidates=r.n_candidates,
+                    flags=r.flags, scene_familiarity=scene)
 
     def step(self, patches, want_scene=True, force_resolve=False):
         """Heading loop of step_forward (:283-316) on patches uint8[A,h,w,3]."""
