@@ -58,7 +58,15 @@ def main():
                     help="0 < cw < 1 keeps all three reference bytes per pixel (H,S,V) algorithmically live")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--cpu-views", type=int, default=12288, help="views in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank "
+                    "(exercises the RCCL exchange path on a single GPU)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
+                    "rehearse the exchange on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
+
+    # Libraries (RCCL's version banner, HIP warnings) write to fd 1; keep stdout for the ONE JSON line.
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,28 +80,43 @@ def main():
     import navsim_amd
     from navsim_amd import sharded
 
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        gather = sharded.torch_gather(device=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+            gather = sharded.torch_gather(device=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=args.backend)
+            gather = sharded.torch_gather(device=None)
     else:
         gather = None
 
     F, h, w, A, cw = args.views, args.sensor, args.sensor, args.headings, args.chem_weight
-    eng = navsim_amd.FamiliarityEngine(device=local_rank)
+    eng = navsim_amd.FamiliarityEngine(device=device_index)
     eng.generate_library(args.seed, F, h, w, cw, first_view=rank * F)     # this rank's shard, made in HBM
     eng.generate_patches(args.seed, A)                                     # same patches on every rank
     info = eng.library_info()
 
+    exchange = None
+    if use_dist and args.backend == "nccl":
+        exchange = sharded.DeviceExchange(eng, rank, world, torch.device("cuda", device_index))
+
     def one_step():
-        if world > 1:
+        if exchange is not None:
+            return exchange.step()
+        if use_dist:
             return sharded.step_resident(eng, gather, rank)
         eng.step_enqueue(want_scene=False)
         return eng.step_wait(want_scene=False)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         eng.synchronize()
@@ -110,8 +133,8 @@ def main():
     kern_ms_total, kern_n = eng.profile_read()
     eng.profile_kernel(False)
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -138,7 +161,8 @@ def main():
                             "(BASELINE.json configs[1])" % (w, h, F, A, cw),
                 "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
                 "bytes_per_pixel": info["n_planes"], "parallelism": "library sharded x%d" % world,
-                "exchange": "none" if world == 1 else "1 all-gather of per-heading records per step (RCCL)",
+                "exchange": "none" if not use_dist else "1 all-gather of per-heading records per step (%s)" % (
+                    "RCCL, device-resident" if args.backend == "nccl" else args.backend),
             },
             "nav_steps_per_s": args.steps / dt,
             "best_heading": int(res["best_idex"]),
@@ -152,9 +176,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(h, w, A, cw, args.seed, min(args.cpu_views, F))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -84,6 +84,7 @@ typedef struct dv_lib_info {
     int32_t has_value_plane;    /* 0 when chem_weight == 1 */
     int64_t tile_bytes;         /* bytes the scoring kernel streams per pass */
     double chem_weight;
+    double delta;               /* half-width of the candidate window around the best integer-sum score */
     uint8_t hues[DV_MAX_HUE_PLANES];
 } dv_lib_info;
 
@@ -136,6 +137,15 @@ int dv_generate_patches(dv_ctx *ctx, uint64_t seed, int n_headings);
 int dv_step_enqueue(dv_ctx *ctx, uint32_t flags);
 /* Wait for the last enqueued step and copy its result (and optionally scene_fam[F]). */
 int dv_step_wait(dv_ctx *ctx, dv_step_result *result, double *scene_fam);
+/*
+ * Device address of the packed record of the last enqueued step, for a device-side exchange between ranks
+ * (stream-ordered after dv_step_enqueue on the context's stream; no host synchronisation):
+ *   double[3 + 4A] = approx_max, n_candidates, state (0 integer scores, 1 candidates exact, 2 all exact),
+ *                    angle_fam[A], angle_view[A], exact_fam[A], exact_view[A]
+ */
+int dv_step_record(dv_ctx *ctx, void **device_ptr, int *n_doubles);
+/* Enqueue the exact resolver on the last step's candidates (updates the record); no host synchronisation. */
+int dv_resolve_enqueue(dv_ctx *ctx);
 int dv_synchronize(dv_ctx *ctx);
 
 /* ---- measurement ------------------------------------------------------- */

@@ -56,6 +56,7 @@ struct dv_ctx {
     double* d_cand_exact = nullptr;           // [kCandCap]
     StepResultDev* h_result = nullptr;        // pinned, mapped: the kernels write the result record into it
     StepResultDev* d_result = nullptr;        // device-side address of h_result
+    double* d_record = nullptr;               // [3 + 4*64] packed record of the last step, for device-side exchange
     double* h_scene = nullptr;                // pinned staging for scene_fam
     int A = 0, APAD = 0;                      // resident patches
     bool step_pending = false;
@@ -90,7 +91,7 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst); F(c->d_fam); F(c->d_scene);
-    F(c->d_part); F(c->d_pmax);
+    F(c->d_part); F(c->d_pmax); F(c->d_record);
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
     if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; c->d_result = nullptr; }
     if (c->h_scene) { (void)hipHostFree(c->h_scene); c->h_scene = nullptr; }
@@ -213,6 +214,7 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_state, sizeof(StepState)));
     HIP_TRY(c, hipMalloc(&c->d_cand, kCandCap * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand_exact, kCandCap * sizeof(double)));
+    HIP_TRY(c, hipMalloc(&c->d_record, (3 + 4 * kMaxHeadings) * sizeof(double)));
     HIP_TRY(c, hipHostMalloc(&c->h_result, sizeof(StepResultDev), hipHostMallocMapped));
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_result, c->h_result, 0));
     memset(c->h_result, 0, sizeof(StepResultDev));
@@ -317,6 +319,7 @@ extern "C" int dv_get_library_info(const dv_ctx* c, dv_lib_info* o) {
     o->has_value_plane = c->cfg.hasv;
     o->tile_bytes = (int64_t)c->tile_bytes;
     o->chem_weight = c->cfg.cw;
+    o->delta = c->delta;
     for (int k = 0; k < kMaxHues; ++k) o->hues[k] = c->cfg.hues[k];
     return DV_OK;
 }
@@ -479,7 +482,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     int rc = launch_scoring(c);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_pmax, c->n_partial,
-                       c->d_state, c->d_cand, c->d_scene, c->d_result, c->cfg, c->A, c->delta,
+                       c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg, c->A, c->delta,
                        want_scene ? 1 : 0, c->exact, force);
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
@@ -494,8 +497,8 @@ static int enqueue_resolve(dv_ctx* c) {
     hipLaunchKernelGGL(k_resolve, dim3(256), dim3(64), 0, c->stream, c->d_tiles, c->d_raw_patches, c->d_state, c->d_cand,
                        c->d_cand_exact, c->cfg);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result, c->cfg,
-                       c->A, c->delta);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result,
+                       c->d_record, c->cfg, c->A, c->delta);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
@@ -567,6 +570,21 @@ extern "C" int dv_resolve(dv_ctx* c, dv_step_result* result) {
         if (rc) return rc;
     }
     return wait_step(c, result, nullptr);
+}
+
+extern "C" int dv_step_record(dv_ctx* c, void** device_ptr, int* n_doubles) {
+    if (!c || !device_ptr || !n_doubles) return DV_ERR_INVALID;
+    if (!c->have_lib || c->A < 1) return fail(c, DV_ERR_STATE, "no library or no resident patches");
+    *device_ptr = c->d_record;
+    *n_doubles = 3 + 4 * c->A;
+    return DV_OK;
+}
+
+extern "C" int dv_resolve_enqueue(dv_ctx* c) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib || !c->step_pending) return fail(c, DV_ERR_STATE, "no step to resolve");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_resolve(c);
 }
 
 extern "C" int dv_score(dv_ctx* c, const uint8_t* patch, double* fambuf) {

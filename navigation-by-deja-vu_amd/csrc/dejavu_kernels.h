@@ -587,6 +587,23 @@ __device__ void decide_core(const unsigned long long* amax, const unsigned long 
     out->flags = flags;
 }
 
+// Packed per-rank record for the sharded exchange (navsim_amd/sharded.py:pack_record):
+//   [approx_max, n_candidates, state, angle_fam[A], angle_view[A], exact_fam[A], exact_view[A]]   (doubles)
+// state: 0 integer-sum scores only, 1 candidates re-scored exactly, 2 every score exact.
+__device__ __forceinline__ void emit_record(const StepResultDev* r, double* __restrict__ rec, int A, int tid, int nthreads) {
+    if (tid == 0) {
+        rec[0] = r->approx_max;
+        rec[1] = (double)r->n_candidates;
+        rec[2] = (r->flags & 2u) ? 2.0 : ((r->flags & 1u) ? 1.0 : 0.0);
+    }
+    for (int i = tid; i < A; i += nthreads) {
+        rec[3 + i] = r->angle_fam[i];
+        rec[3 + A + i] = (double)r->angle_view[i];
+        rec[3 + 2 * A + i] = r->exact_fam[i];
+        rec[3 + 3 * A + i] = (double)r->exact_view[i];
+    }
+}
+
 // Everything after scoring, in one launch.  grid = ceil(F/256) blocks of 256 threads.
 //  1. every block reduces the partial maxima pmax[a][0..n_partial) to amax[a] (LDS; redundant but
 //     tiny, and it avoids both a grid-wide sync and same-line global atomics);
@@ -598,7 +615,8 @@ __device__ void decide_core(const unsigned long long* amax, const unsigned long 
 __global__ void __launch_bounds__(256)
 k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
        StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
-       StepResultDev* __restrict__ out, LibCfg c, int A, double delta, int want_scene, int exact_all, int force) {
+       StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene,
+       int exact_all, int force) {
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -668,15 +686,13 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
         const unsigned long long n_all = __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool overflow = n_all > (unsigned long long)kCandCap;
         const bool needs = !exact_all && !overflow && (n_all >= 2 || (force && n_all >= 1));
-        if (needs) {
-            s_res.flags = kResNeedsResolve;
-            s_res.n_candidates = (long long)n_all;
-            s_res.n_headings = A;
-        } else {
-            decide_core(s_amax, s_aview, n_all, false, nullptr, nullptr, &s_res, c, A, delta, exact_all);
-        }
+        // the integer-score decision is always filled in (the sharded exchange wants the per-heading maxima
+        // even when local near-ties still have to be re-scored); NEEDS_RESOLVE tells the host it is provisional
+        decide_core(s_amax, s_aview, n_all, false, nullptr, nullptr, &s_res, c, A, delta, exact_all);
+        if (needs) s_res.flags |= kResNeedsResolve;
     }
     __syncthreads();
+    emit_record(&s_res, rec, A, threadIdx.x, blockDim.x);
     // header (7 x 8 bytes) + the first A entries of each of the four per-heading arrays
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
@@ -740,9 +756,10 @@ k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw
 // Resolve path only: single wave; folds the exact candidate values into per-heading maxima, then decides.
 __global__ void k_decide(const StepState* __restrict__ st, const unsigned long long* __restrict__ cand,
                          const double* __restrict__ cand_exact, StepResultDev* __restrict__ out,
-                         LibCfg c, int A, double delta) {
+                         double* __restrict__ rec, LibCfg c, int A, double delta) {
     __shared__ unsigned long long ekey[kMaxHeadings];
     __shared__ unsigned long long eview[kMaxHeadings];
+    __shared__ StepResultDev s_res;
     const int lane = threadIdx.x;
     if (lane < kMaxHeadings) { ekey[lane] = 0; eview[lane] = 0; }
     __syncthreads();
@@ -755,7 +772,16 @@ __global__ void k_decide(const StepState* __restrict__ st, const unsigned long l
         if (ordered_key(cand_exact[i]) == ekey[a]) atomicMax(&eview[a], ~(cand[i] & 0xffffffffffull));
     }
     __syncthreads();
-    if (lane == 0) decide_core(st->amax, st->aview, n_all, n > 0, ekey, eview, out, c, A, delta, 0);
+    if (lane == 0) decide_core(st->amax, st->aview, n_all, n > 0, ekey, eview, &s_res, c, A, delta, 0);
+    __syncthreads();
+    emit_record(&s_res, rec, A, lane, blockDim.x);
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
+    if (lane < 7) dst[lane] = src[lane];
+    for (int i = lane; i < 4 * A; i += blockDim.x) {
+        const int o = 7 + (i / A) * kMaxHeadings + (i % A);
+        dst[o] = src[o];
+    }
 }
 
 // Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.

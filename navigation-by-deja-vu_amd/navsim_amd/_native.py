@@ -56,6 +56,7 @@ class LibInfo(ctypes.Structure):
         ("has_value_plane", ctypes.c_int32),
         ("tile_bytes", ctypes.c_int64),
         ("chem_weight", ctypes.c_double),
+        ("delta", ctypes.c_double),
         ("hues", ctypes.c_uint8 * DV_MAX_HUE_PLANES),
     ]
 
@@ -86,6 +87,8 @@ PROTOTYPES = {
     "dv_generate_patches": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int]),
     "dv_step_enqueue": (ctypes.c_int, [_ctx_p, ctypes.c_uint32]),
     "dv_step_wait": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult), _f64p]),
+    "dv_step_record": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
+    "dv_resolve_enqueue": (ctypes.c_int, [_ctx_p]),
     "dv_synchronize": (ctypes.c_int, [_ctx_p]),
     "dv_timer_start": (ctypes.c_int, [_ctx_p]),
     "dv_timer_stop": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float)]),

@@ -84,7 +84,7 @@ class FamiliarityEngine(object):
         return dict(n_views=info.n_views, first_view=info.first_view, h=info.h, w=info.w,
                     n_planes=info.n_planes, n_hue_planes=info.n_hue_planes, generic_hue=bool(info.generic_hue),
                     has_value_plane=bool(info.has_value_plane), tile_bytes=info.tile_bytes,
-                    chem_weight=info.chem_weight, hues=[int(x) for x in info.hues][:info.n_hue_planes])
+                    chem_weight=info.chem_weight, delta=info.delta, hues=[int(x) for x in info.hues][:info.n_hue_planes])
 
     def read_planes(self, v0, n):
         info = self.library_info()
@@ -167,6 +167,16 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_step_wait(self._ctx, ctypes.byref(r), N.f64ptr(scene) if want_scene else None),
                     "dv_step_wait")
         return self._result_dict(r, scene)
+
+    def step_record(self):
+        """(device pointer, n_doubles) of the packed record of the last enqueued step (sharded exchange)."""
+        ptr = ctypes.c_void_p()
+        n = ctypes.c_int(0)
+        self._check(self._lib.dv_step_record(self._ctx, ctypes.byref(ptr), ctypes.byref(n)), "dv_step_record")
+        return int(ptr.value), int(n.value)
+
+    def resolve_enqueue(self):
+        self._check(self._lib.dv_resolve_enqueue(self._ctx), "dv_resolve_enqueue")
 
     # -- measurement ----------------------------------------------------------------------------
     def timer_start(self):

@@ -141,11 +141,62 @@ def torch_gather(device=None):
         t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
         if device is not None:
             t = t.to(device)
-        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()
+        out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.reshape(-1))
+        return out.cpu().numpy().reshape((world,) + tuple(t.shape))
 
     return gather
+
+
+class _DeviceArray(object):
+    """Minimal __cuda_array_interface__ carrier so that torch can wrap a raw device pointer without copying."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+
+class DeviceExchange(object):
+    """Per-step exchange that never leaves the GPU until the gathered records are complete.
+
+    The engine's kernels run on torch's current stream and leave this rank's packed record in device memory
+    (dv_step_record); `all_gather_into_tensor` (RCCL) is stream-ordered behind them, one pinned-memory copy brings
+    all ranks' records to the host, and there is ONE host synchronisation per step.  Cross-rank near-ties take a
+    second round (dv_resolve_enqueue + all-gather), exactly like ShardedFamiliarity.step.
+    """
+
+    def __init__(self, engine, rank, world_size, device):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.engine, self.rank, self.world = engine, rank, world_size
+        self.device = torch.device(device)
+        self.stream = torch.cuda.current_stream(self.device)
+        engine.set_stream(self.stream.cuda_stream)
+        self.delta = engine.library_info()["delta"]
+        ptr, n = engine.step_record()
+        self.n = n
+        self.A = (n - 3) // 4
+        self.record = torch.as_tensor(_DeviceArray(ptr, n), device=self.device)
+        self.gathered = torch.empty(world_size * n, dtype=torch.float64, device=self.device)
+        self.host = torch.empty(world_size * n, dtype=torch.float64).pin_memory()
+        self.exchanges = 0
+
+    def _gather(self):
+        self._dist.all_gather_into_tensor(self.gathered, self.record)
+        self.host.copy_(self.gathered, non_blocking=True)
+        self.stream.synchronize()
+        self.exchanges += 1
+        return self.host.numpy().reshape(self.world, self.n)
+
+    def step(self):
+        self.engine.step_enqueue(want_scene=False)
+        records = self._gather()
+        again, ranks = needs_resolve(records, self.delta)
+        if again:
+            if self.rank in ranks and records[self.rank, 2] == 0.0:
+                self.engine.resolve_enqueue()
+            records = self._gather()
+        return merge_records(records, self.delta, self.A)
 
 
 def step_resident(engine, gather, rank):

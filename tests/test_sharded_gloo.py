@@ -1,0 +1,135 @@
+"""Library sharding across ranks (navsim_amd/sharded.py) with world_size 2 and 3 over gloo, on CPU.
+
+Each rank scores its own block of views through a test double of the engine (tests/fake_engine.py,
+oracle-backed); the exchange, the cross-rank tie protocol and the merge are the product code.  The
+merged decision must equal the reference's unsharded one (oracle.step) bit for bit.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from navsim_amd import sharded, synth
+from oracle import oracle
+from tests.fake_engine import OracleBackedEngine
+
+
+def cases():
+    out = []
+    lib = synth.synth_views(21, 300, 8, 8)
+    pat = synth.synth_patches(21, 6, 8, 8)
+    out.append(("plain", lib, pat, 0.0))
+    out.append(("plain_cw", lib, pat, 0.5))
+    # exact duplicates of the best view on BOTH sides of the shard boundary, seen by two headings
+    lib2 = lib.copy()
+    lib2[10] = lib2[290] = lib2[150]
+    pat2 = pat.copy()
+    pat2[1] = lib2[150]
+    pat2[4] = lib2[150]
+    out.append(("dups_across_ranks", lib2, pat2, 0.0))
+    # near-ties: equal integer SAD, different pixel order -> ulp-different doubles decide
+    small = synth.synth_views(5, 4000, 4, 4)
+    out.append(("ties_4x4", small, synth.synth_patches(5, 16, 4, 4), 0.0))
+    out.append(("ties_4x4_cw", small, synth.synth_patches(5, 16, 4, 4), 0.3))
+    # everything identical: every pair is a candidate on every rank
+    same = np.repeat(lib[:1], 50, axis=0)
+    out.append(("all_same", same, np.repeat(lib[:1], 5, axis=0), 0.25))
+    return out
+
+
+def worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gather = sharded.torch_gather(device=None)
+    results = []
+    for name, lib, pat, cw in cases():
+        sh = sharded.ShardedFamiliarity(OracleBackedEngine(), gather, rank, world)
+        sh.set_library(lib, cw)
+        lo, hi = sh.bounds
+        assert (lo, hi) == sharded.shard_bounds(len(lib), world, rank)
+        r = sh.step(pat)
+        results.append((name, r["best_idex"], r["best_view"], r["step_familiarity"],
+                        r["angle_familiarity"].tolist(), sh.exchanges))
+    q.put((rank, results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_matches_unsharded_reference(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = {name: oracle.step(lib, pat, cw) for name, lib, pat, cw in cases()}
+    exchanged = {}
+    for rank in range(world):
+        for name, best, view, fam, angle, exchanges in got[rank]:
+            want = expected[name]
+            assert best == want["best_idex"], (name, rank)
+            assert view == want["best_view"], (name, rank)
+            np.testing.assert_allclose(fam, want["step_familiarity"], rtol=1e-12)
+            np.testing.assert_allclose(angle, want["angle_familiarity"], rtol=1e-12)
+            exchanged[name] = exchanges
+    # one exchange when the integer scores decide, a second one only for cross-rank ties
+    assert exchanged["plain"] == 1 and exchanged["plain_cw"] == 1
+    assert exchanged["dups_across_ranks"] >= 1
+
+
+def test_shard_bounds_cover_the_library():
+    for n, w in ((10, 3), (50000, 8), (7, 8), (64, 2)):
+        spans = [sharded.shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_rules_on_hand_made_records():
+    A = 3
+    def rec(approx_max, ncand, state, ang, view, ex=None, exv=None):
+        r = np.empty(3 + 4 * A)
+        r[0:3] = approx_max, ncand, state
+        r[3:3 + A] = ang
+        r[3 + A:3 + 2 * A] = view
+        r[3 + 2 * A:3 + 3 * A] = ex if ex is not None else [-np.inf] * A
+        r[3 + 3 * A:3 + 4 * A] = exv if exv is not None else [-1] * A
+        return r
+    delta = 1e-9
+    # single candidate overall: integer scores decide
+    recs = np.stack([rec(10.0, 1, 0, [10.0, 7.0, 8.0], [5, 6, 7]), rec(9.0, 1, 0, [9.0, 8.5, 6.0], [105, 106, 107])])
+    again, ranks = sharded.needs_resolve(recs, delta)
+    assert not again and ranks == [0]
+    m = sharded.merge_records(recs, delta, A)
+    assert m["best_idex"] == 0 and m["best_view"] == 5 and list(m["angle_familiarity"]) == [10.0, 8.5, 8.0]
+    # both ranks hold the maximum: must resolve; after resolving, exact values decide, first heading wins ties
+    recs = np.stack([rec(10.0, 1, 0, [7.0, 10.0, 8.0], [5, 6, 7]), rec(10.0, 1, 0, [10.0, 8.5, 6.0], [105, 106, 107])])
+    again, ranks = sharded.needs_resolve(recs, delta)
+    assert again and ranks == [0, 1]
+    recs = np.stack([rec(10.0, 1, 1, [7.0, 10.0, 8.0], [5, 6, 7], [-np.inf, 10.0, -np.inf], [-1, 6, -1]),
+                     rec(10.0, 1, 1, [10.0, 8.5, 6.0], [105, 106, 107], [10.0, -np.inf, -np.inf], [105, -1, -1])])
+    assert not sharded.needs_resolve(recs, delta)[0]
+    m = sharded.merge_records(recs, delta, A)
+    assert m["best_idex"] == 0 and m["best_view"] == 105 and m["resolved"]
+    with pytest.raises(RuntimeError):
+        sharded.merge_records(np.stack([rec(10.0, 2, 0, [10.0, 1, 1], [1, 2, 3]), rec(10.0, 1, 0, [10.0, 1, 1], [4, 5, 6])]),
+                              delta, A)

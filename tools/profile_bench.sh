@@ -1,0 +1,17 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_bench.sh r01
+# Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2-3: PMC counters, each in its own run
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Results land in gpurun_out/<tag>/ and a summary JSON
+# is printed by tools/summarize_profile.py; copy both into profiles/.
+set -e
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 200 --warmup 20 --cpu-views 0 > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 > /dev/null 2> $OUT/pmc_sq.err
+cd $ROOT && python3 tools/summarize_profile.py $OUT > $OUT/summary.json && cat $OUT/summary.json
