@@ -29,6 +29,25 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
+def committed_traffic(workload_key):
+    """HBM bytes per launch of the scoring kernel from the committed PMC passes (profiles/*_summary.json).
+
+    bench.py cannot run rocprofv3 on itself; tools/profile_bench.sh collects FETCH_SIZE and WRITE_SIZE in their own
+    passes of this same command and tools/summarize_profile.py applies the gfx950 correction (FETCH_SIZE x 2).  The
+    number is reported only when the profiled workload is the one being benchmarked.
+    """
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if d["bench_under_trace"]["config"]["workload"] == workload_key:
+                best = (float(d["k_sad_tiles"]["hbm_traffic_bytes_per_launch"]), os.path.basename(f))
+        except Exception:   # noqa: BLE001
+            continue
+    return best
+
+
 def cpu_baseline(h, w, A, cw, seed, budget_views):
     """The oracle (C restatement of util.pyx:31-73, 1 thread) on a bounded sample of the same workload."""
     from navsim_amd import synth
@@ -143,6 +162,9 @@ def main():
         kern_ms = kern_ms_total / max(kern_n, 1)
         algo_bytes = float(F) * h * w * info["n_planes"]      # library bytes one launch must read
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        workload = ("%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g "
+                    "(BASELINE.json configs[1])" % (w, h, F, A, cw))
+        traffic = committed_traffic(workload)
         out = {
             "metric": "view-comparisons/sec (sensor x library x headings)",
             "value": comparisons / dt,
@@ -157,8 +179,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g "
-                            "(BASELINE.json configs[1])" % (w, h, F, A, cw),
+                "workload": workload,
                 "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
                 "bytes_per_pixel": info["n_planes"], "parallelism": "library sharded x%d" % world,
                 "exchange": "none" if not use_dist else "1 all-gather of per-heading records per step (%s)" % (
@@ -168,7 +189,9 @@ def main():
             "best_heading": int(res["best_idex"]),
             "roofline": {
                 "bound": "hbm", "kernel": "k_sad_tiles", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch, " + traffic[1]) if traffic else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kern_ms, "launches_timed": kern_n,
             },
         }
