@@ -31,7 +31,8 @@ enum {
     DV_ERR_INVALID = -1,   /* bad argument (NULL, shape, chem_weight outside [0,1], A too large) */
     DV_ERR_HIP = -2,       /* a HIP runtime call failed; see dv_last_error */
     DV_ERR_STATE = -3,     /* no library set / no step to read back */
-    DV_ERR_OOM = -4        /* device or host allocation failed */
+    DV_ERR_OOM = -4,       /* device or host allocation failed */
+    DV_ERR_INDEX = -5      /* sensor footprint past the end of the landscape (the reference raises IndexError) */
 };
 
 #define DV_MAX_HEADINGS 64      /* headings scored per library pass */
@@ -114,6 +115,25 @@ int dv_clear_library(dv_ctx *ctx);
 int dv_get_library_info(const dv_ctx *ctx, dv_lib_info *out);
 /* Copy the stored planes of local views [v0, v0+n) back as uint8[n, n_planes, h*w] (layout check). */
 int dv_read_planes(dv_ctx *ctx, int64_t v0, int64_t n, uint8_t *out);
+
+/* ---- sensor model (NavBySceneFamiliarity.py:151-192, util.pyx:91-168) -- */
+/* landscape: uint8[rows, cols, 3] HSV, C-contiguous; copied to the GPU. */
+int dv_set_landscape(dv_ctx *ctx, const uint8_t *landscape, int rows, int cols, int channels);
+/*
+ * sensor_dimensions = [sensor_w, sensor_h], sensor_pixel_dimensions = [pixel_w, pixel_h] (:90-96);
+ * lut: uint8[3][256], the per-channel level quantisation of :176-186 tabulated by the caller;
+ * mask_middle_n: columns zeroed either side of the middle (:189-190).
+ */
+int dv_configure_sensor(dv_ctx *ctx, int sensor_w, int sensor_h, int pixel_w, int pixel_h,
+                        const uint8_t *lut, int mask_middle_n);
+/* get_sensor_mat at n poses; out: uint8[n, sensor_h, sensor_w, 3].  DV_ERR_INDEX like the reference's IndexError. */
+int dv_sense(dv_ctx *ctx, const double *x, const double *y, const double *angle, int n, uint8_t *out);
+/* The A heading patches of one position straight into the resident patches (then dv_step_enqueue). */
+int dv_sense_patches(dv_ctx *ctx, double x, double y, const double *angles, int n_headings);
+/* train_from_path (:118-140) on the device: sense n poses and ingest them as the library; out_views
+ * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */
+int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,
+                              double chem_weight, int64_t first_view, uint8_t *out_views);
 
 /* ---- scoring ----------------------------------------------------------- */
 /* func(scene, fambuf) of util.pyx:14-20: fambuf[f] for one patch uint8[h,w,3] against every local view. */

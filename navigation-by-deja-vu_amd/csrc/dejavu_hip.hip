@@ -63,6 +63,18 @@ struct dv_ctx {
     bool last_want_scene = false;
     double delta = 0.0;
 
+    // sensor model (landscape resident in HBM)
+    unsigned char* d_land = nullptr;
+    SensorCfg sensor{};
+    bool have_sensor = false;
+    unsigned char* d_lut = nullptr;           // [3][256] level-quantisation tables
+    Pose* d_poses = nullptr;
+    size_t poses_cap = 0;
+    unsigned char* d_sense = nullptr;         // [n][sh][sw][3] scratch for dv_sense
+    size_t sense_cap = 0;
+    int* d_err = nullptr;
+    std::vector<Pose> h_poses;
+
     // measurement
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int profile = 0;
@@ -139,6 +151,11 @@ extern "C" void dv_destroy(dv_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_library(c);
+    if (c->d_land) (void)hipFree(c->d_land);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_poses) (void)hipFree(c->d_poses);
+    if (c->d_sense) (void)hipFree(c->d_sense);
+    if (c->d_err) (void)hipFree(c->d_err);
     for (auto e : c->pev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -234,6 +251,38 @@ static int check_lib_args(dv_ctx* c, int64_t F, int h, int w, double cw) {
     return DV_OK;
 }
 
+// Library ingest from a raw uint8[F][h*w][3] buffer already on the device: hue scan, layout choice, re-tile.
+static int ingest_raw(dv_ctx* c, const unsigned char* d_raw, int64_t F, int h, int w, double cw, int64_t first) {
+    unsigned bitmap[8] = {0};
+    if (cw > 0.0) {
+        unsigned* d_bitmap = nullptr;
+        hipError_t e = hipMalloc(&d_bitmap, sizeof bitmap);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bitmap, 0, sizeof bitmap, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_hue_scan, dim3(1024), dim3(256), 0, c->stream, d_raw, (long long)F * h * w, d_bitmap);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(bitmap, d_bitmap, sizeof bitmap, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (d_bitmap) (void)hipFree(d_bitmap);
+        if (e != hipSuccess) return fail(c, DV_ERR_HIP, "hue scan: %s", hipGetErrorString(e));
+    }
+    unsigned char hues[256];
+    int n_hues = 0;
+    for (int v = 0; v < 256; ++v)
+        if (bitmap[v >> 5] & (1u << (v & 31))) hues[n_hues++] = (unsigned char)v;
+    const int generic = n_hues > kMaxHues;
+
+    int rc = alloc_library(c, F, h, w, cw, first, n_hues, hues, generic);
+    if (rc) { free_library(c); return rc; }
+    const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.npl * c->cfg.Q * 64;
+    hipLaunchKernelGGL(k_retile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_tiles, c->cfg);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "retile: %s", hipGetErrorString(e)); }
+    return DV_OK;
+}
+
 extern "C" int dv_set_library(dv_ctx* c, const uint8_t* views, int64_t F, int h, int w, int channels,
                               double cw, int64_t first) {
     int rc = check_lib_args(c, F, h, w, cw);
@@ -243,42 +292,140 @@ extern "C" int dv_set_library(dv_ctx* c, const uint8_t* views, int64_t F, int h,
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_library(c);
-
     const size_t raw_bytes = (size_t)F * h * w * 3;
     unsigned char* d_raw = nullptr;
-    unsigned* d_bitmap = nullptr;
     HIP_TRY(c, hipMalloc(&d_raw, raw_bytes));
-    auto cleanup = [&]() { (void)hipFree(d_raw); if (d_bitmap) (void)hipFree(d_bitmap); };
     hipError_t e = hipMemcpyAsync(d_raw, views, raw_bytes, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) { cleanup(); return fail(c, DV_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d_raw); return fail(c, DV_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+    rc = ingest_raw(c, d_raw, F, h, w, cw, first);
+    (void)hipFree(d_raw);
+    return rc;
+}
 
-    unsigned bitmap[8] = {0};
-    if (cw > 0.0) {
-        e = hipMalloc(&d_bitmap, sizeof bitmap);
-        if (e == hipSuccess) e = hipMemsetAsync(d_bitmap, 0, sizeof bitmap, c->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_hue_scan, dim3(1024), dim3(256), 0, c->stream, d_raw, (long long)F * h * w, d_bitmap);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(bitmap, d_bitmap, sizeof bitmap, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { cleanup(); return fail(c, DV_ERR_HIP, "hue scan: %s", hipGetErrorString(e)); }
-    }
-    unsigned char hues[256];
-    int n_hues = 0;
-    for (int v = 0; v < 256; ++v)
-        if (bitmap[v >> 5] & (1u << (v & 31))) hues[n_hues++] = (unsigned char)v;
-    const int generic = n_hues > kMaxHues;
+// ------------------------------------------------------------------ sensor model
+static int check_step_args(dv_ctx* c, int A);
+static int prep_patches(dv_ctx* c, int A);
 
-    rc = alloc_library(c, F, h, w, cw, first, n_hues, hues, generic);
-    if (rc) { cleanup(); free_library(c); return rc; }
-    const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.npl * c->cfg.Q * 64;
-    hipLaunchKernelGGL(k_retile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_tiles, c->cfg);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
-    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "retile: %s", hipGetErrorString(e)); }
+extern "C" int dv_set_landscape(dv_ctx* c, const uint8_t* landscape, int rows, int cols, int channels) {
+    if (!c || !landscape) return DV_ERR_INVALID;
+    if (rows < 1 || cols < 1 || channels != 3) return fail(c, DV_ERR_INVALID, "landscape must be uint8[rows, cols, 3]");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_land) { (void)hipFree(c->d_land); c->d_land = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->d_land, (size_t)rows * cols * 3));
+    HIP_TRY(c, hipMemcpyAsync(c->d_land, landscape, (size_t)rows * cols * 3, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sensor.rows = rows;
+    c->sensor.cols = cols;
     return DV_OK;
+}
+
+extern "C" int dv_configure_sensor(dv_ctx* c, int sw, int sh, int pw, int ph, const uint8_t* lut, int mask_n) {
+    if (!c || !lut) return DV_ERR_INVALID;
+    if (!c->d_land) return fail(c, DV_ERR_STATE, "no landscape set (call dv_set_landscape first)");
+    if (sw < 1 || sh < 1 || pw < 1 || ph < 1 || pw * ph > 4096) return fail(c, DV_ERR_INVALID, "bad sensor geometry");
+    if (mask_n < 0 || mask_n > sw / 2) return fail(c, DV_ERR_INVALID, "mask_middle_n %d outside [0, %d]", mask_n, sw / 2);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->d_lut) HIP_TRY(c, hipMalloc(&c->d_lut, 768));
+    if (!c->d_err) HIP_TRY(c, hipMalloc(&c->d_err, sizeof(int)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_lut, lut, 768, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sensor.sw = sw; c->sensor.sh = sh; c->sensor.pw = pw; c->sensor.ph = ph; c->sensor.mask_n = mask_n;
+    c->have_sensor = true;
+    return DV_OK;
+}
+
+// Enqueue k_sense for n poses into `d_out` (uint8[n][sh][sw][3]).  Rotation cos/sin come from the host's libm,
+// like the reference's cimported cos/sin (util.pyx:143-145).
+static int enqueue_sense(dv_ctx* c, const double* x, const double* y, const double* angle, long long n, unsigned char* d_out) {
+    if ((size_t)n > c->poses_cap) {
+        if (c->d_poses) (void)hipFree(c->d_poses);
+        c->d_poses = nullptr;
+        c->poses_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_poses, (size_t)n * sizeof(Pose)));
+        c->poses_cap = (size_t)n;
+    }
+    c->h_poses.resize((size_t)n);
+    for (long long i = 0; i < n; ++i) {
+        const double rot = -(0.5 * M_PI - angle[i]);
+        c->h_poses[(size_t)i] = Pose{x[i], y[i], std::cos(rot), std::sin(rot)};
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), (size_t)n * sizeof(Pose), hipMemcpyHostToDevice, c->stream));
+    const long long total = n * c->sensor.sh * c->sensor.sw;
+    hipLaunchKernelGGL(k_sense, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, c->d_poses, (int)n,
+                       c->sensor, c->d_lut, d_out, c->d_err);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+static int check_sense_error(dv_ctx* c) {
+    int err = 0;
+    HIP_TRY(c, hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (err) return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)");
+    return DV_OK;
+}
+
+static int ensure_sense_buffer(dv_ctx* c, size_t bytes) {
+    if (bytes > c->sense_cap) {
+        if (c->d_sense) (void)hipFree(c->d_sense);
+        c->d_sense = nullptr;
+        c->sense_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_sense, bytes));
+        c->sense_cap = bytes;
+    }
+    return DV_OK;
+}
+
+extern "C" int dv_sense(dv_ctx* c, const double* x, const double* y, const double* angle, int n, uint8_t* out) {
+    if (!c || !x || !y || !angle || !out || n < 1) return DV_ERR_INVALID;
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * c->sensor.sh * c->sensor.sw * 3;
+    int rc = ensure_sense_buffer(c, bytes);
+    if (rc) return rc;
+    rc = enqueue_sense(c, x, y, angle, n, c->d_sense);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_sense, bytes, hipMemcpyDeviceToHost, c->stream));
+    return check_sense_error(c);
+}
+
+extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* angles, int A) {
+    int rc = check_step_args(c, A);
+    if (rc) return rc;
+    if (!angles) return fail(c, DV_ERR_INVALID, "angles is NULL");
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    if (c->sensor.sw != c->w || c->sensor.sh != c->h)
+        return fail(c, DV_ERR_STATE, "sensor is %dx%d but the library holds %dx%d views", c->sensor.sw, c->sensor.sh, c->w, c->h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    double xs[kMaxHeadings], ys[kMaxHeadings];
+    for (int a = 0; a < A; ++a) { xs[a] = x; ys[a] = y; }
+    rc = enqueue_sense(c, xs, ys, angles, A, c->d_raw_patches);
+    if (rc) return rc;
+    rc = prep_patches(c, A);
+    if (rc) return rc;
+    return check_sense_error(c);
+}
+
+extern "C" int dv_set_library_from_poses(dv_ctx* c, const double* x, const double* y, const double* angle, int64_t n,
+                                         double cw, int64_t first, uint8_t* out_views) {
+    if (!c || !x || !y || !angle) return DV_ERR_INVALID;
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    int rc = check_lib_args(c, n, c->sensor.sh, c->sensor.sw, cw);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_library(c);
+    const size_t bytes = (size_t)n * c->sensor.sh * c->sensor.sw * 3;
+    rc = ensure_sense_buffer(c, bytes);
+    if (rc) return rc;
+    rc = enqueue_sense(c, x, y, angle, n, c->d_sense);
+    if (rc) return rc;
+    if (out_views) HIP_TRY(c, hipMemcpyAsync(out_views, c->d_sense, bytes, hipMemcpyDeviceToHost, c->stream));
+    rc = check_sense_error(c);
+    if (rc) return rc;
+    return ingest_raw(c, c->d_sense, n, c->sensor.sh, c->sensor.sw, cw, first);
 }
 
 extern "C" int dv_generate_library(dv_ctx* c, uint64_t seed, int64_t F, int h, int w, double cw, int64_t first) {

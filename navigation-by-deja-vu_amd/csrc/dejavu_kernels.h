@@ -784,6 +784,86 @@ __global__ void k_decide(const StepState* __restrict__ st, const unsigned long l
     }
 }
 
+// ------------------------------------------------------------------ sensor model (the step either side of scoring)
+// get_sensor_mat of the reference (navsim/NavBySceneFamiliarity.py:151-192) for n poses at once:
+//   fill_sensor_from  (navsim/util.pyx:137-168): rotated nearest-neighbour crop, double arithmetic in the
+//                     reference's operation order (no FMA contraction), C round() = half away from zero,
+//                     landscape indexed [y, x]; negative indices wrap, indices past the end are an error;
+//   downscale_chem    (navsim/util.pyx:91-134): per block V = round(mean V), H = hue with the largest summed
+//                     saturation (lowest hue on ties, hue 0 when every sum is 0), S = ((sum / rows) * cols) & 0xFF
+//                     -- C integer division then multiply (util.pyx:131), uint8 cast wraps;
+//   level quantisation through float32 (:176-186): folded into a 256-entry table per channel made on the host;
+//   mask of the middle columns (:189-190).
+struct SensorCfg {
+    int rows, cols;          // landscape
+    int sw, sh;              // sensor pixels (sensor_dimensions = [w, h])
+    int pw, ph;              // landscape pixels per sensor pixel (sensor_pixel_dimensions = [w, h])
+    int mask_n;              // mask_middle_n
+};
+struct Pose { double x, y, c, s; };   // position and cos/sin of -(pi/2 - angle), computed by the host's libm
+
+__device__ __forceinline__ bool sense_fetch(const unsigned char* __restrict__ land, const SensorCfg& g, const Pose& p,
+                                            int i, int j, unsigned& H, unsigned& S, unsigned& V) {
+    const double px = (double)j - 0.5 * (double)(g.sw * g.pw);
+    const double py = (double)i - 0.5 * (double)(g.sh * g.ph);
+    const double rx = px * p.c - py * p.s;
+    const double ry = px * p.s + py * p.c;
+    long long iy = (long long)round(ry + p.y);
+    long long ix = (long long)round(rx + p.x);
+    if (iy < 0) iy += g.rows;
+    if (ix < 0) ix += g.cols;
+    if (iy < 0 || ix < 0 || iy >= g.rows || ix >= g.cols) return false;
+    const unsigned char* q = land + (iy * (long long)g.cols + ix) * 3;
+    H = q[0]; S = q[1]; V = q[2];
+    return true;
+}
+
+// One thread per sensor pixel of every pose.  out: uint8[n][sh][sw][3].
+__global__ void k_sense(const unsigned char* __restrict__ land, const Pose* __restrict__ poses, int n, SensorCfg g,
+                        const unsigned char* __restrict__ lut, unsigned char* __restrict__ out, int* __restrict__ err) {
+    const long long total = (long long)n * g.sh * g.sw;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int bj = (int)(t % g.sw);
+    const int bi = (int)((t / g.sw) % g.sh);
+    const Pose p = poses[t / ((long long)g.sw * g.sh)];
+    const int nblk = g.pw * g.ph;
+    unsigned oh = 0, os = 0, ov = 0;
+    bool ok = true;
+    if (nblk == 1) {
+        unsigned H, S, V;
+        ok = sense_fetch(land, g, p, bi, bj, H, S, V);
+        if (ok) { oh = S > 0 ? H : 0u; os = S; ov = V; }      // a zero-saturation pixel loses the argmax to hue 0
+    } else {
+        long long vsum = 0, best_sum = 0;
+        unsigned best_hue = 0;
+        for (int k = 0; k < nblk && ok; ++k) {
+            unsigned Hk, Sk, Vk;
+            ok = sense_fetch(land, g, p, bi * g.ph + k / g.pw, bj * g.pw + k % g.pw, Hk, Sk, Vk);
+            if (!ok) break;
+            vsum += Vk;
+            long long sum = 0;                                  // summed saturation of pixel k's hue over the block
+            for (int m = 0; m < nblk; ++m) {
+                unsigned Hm, Sm, Vm;
+                if (!sense_fetch(land, g, p, bi * g.ph + m / g.pw, bj * g.pw + m % g.pw, Hm, Sm, Vm)) { ok = false; break; }
+                if (Hm == Hk) sum += Sm;
+            }
+            if (sum > best_sum || (sum == best_sum && sum > 0 && Hk < best_hue)) { best_sum = sum; best_hue = Hk; }
+        }
+        if (ok) {
+            oh = best_sum > 0 ? best_hue : 0u;
+            os = (unsigned)(((best_sum / g.ph) * g.pw) & 0xFF);
+            ov = (unsigned)(long long)round((double)vsum / (double)nblk);
+        }
+    }
+    if (!ok) { atomicOr(err, 1); return; }
+    oh = lut[oh]; os = lut[256 + os]; ov = lut[512 + ov];
+    const int mid = g.sw / 2;
+    if (bj >= mid - g.mask_n && bj < mid + g.mask_n) { oh = 0; os = 0; ov = 0; }
+    unsigned char* o = out + t * 3;
+    o[0] = (unsigned char)oh; o[1] = (unsigned char)os; o[2] = (unsigned char)ov;
+}
+
 // Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.
 __global__ void k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
     const long long stride = (long long)gridDim.x * blockDim.x;

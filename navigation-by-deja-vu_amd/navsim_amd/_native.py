@@ -19,7 +19,7 @@ DV_RES_RESOLVED = 1
 DV_RES_EXACT_ALL = 2
 DV_RES_OVERFLOW = 4
 
-ERROR_NAMES = {-1: "DV_ERR_INVALID", -2: "DV_ERR_HIP", -3: "DV_ERR_STATE", -4: "DV_ERR_OOM"}
+ERROR_NAMES = {-1: "DV_ERR_INVALID", -2: "DV_ERR_HIP", -3: "DV_ERR_STATE", -4: "DV_ERR_OOM", -5: "DV_ERR_INDEX"}
 
 
 class EngineError(RuntimeError):
@@ -80,6 +80,13 @@ PROTOTYPES = {
     "dv_clear_library": (ctypes.c_int, [_ctx_p]),
     "dv_get_library_info": (ctypes.c_int, [_ctx_p, ctypes.POINTER(LibInfo)]),
     "dv_read_planes": (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, _u8p]),
+    "dv_set_landscape": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dv_configure_sensor": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u8p,
+                                           ctypes.c_int]),
+    "dv_sense": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int, _u8p]),
+    "dv_sense_patches": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, _f64p, ctypes.c_int]),
+    "dv_set_library_from_poses": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int64, ctypes.c_double,
+                                                 ctypes.c_int64, _u8p]),
     "dv_score": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
     "dv_step": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
     "dv_resolve": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult)]),

@@ -5,9 +5,9 @@ Keeps the reference agent's constructor arguments, attributes, methods and stop 
 unchanged; the heading loop of `step_forward` (:283-316) becomes ONE call into the HIP engine.
 Plotting/animation (:332-661) is out of scope.
 
-The sensor model (`get_sensor_mat`, :151-192, with util.pyx:91-168 behind it) is restated here in
-NumPy on the host; it produces the kernel's input and is pinned byte-for-byte by
-tests/golden/t5_sensor.npz.  Moving it onto the GPU is the next row of the scope table.
+The sensor model (`get_sensor_mat`, :151-192, with util.pyx:91-168 behind it) runs on the GPU next to the
+scoring kernel when the HIP model is used (landscape resident in HBM, `k_sense`), and is also restated here in
+NumPy for other plug-ins; both are pinned byte-for-byte by tests/golden/t5_sensor.npz.
 """
 import math
 
@@ -137,7 +137,8 @@ class NavBySceneFamiliarity(object):
                  saccade_degrees=180.,
                  sensor_px_per_mm=None,
                  familiarity_model=None,
-                 track_scene_familiarity=True):
+                 track_scene_familiarity=True,
+                 use_gpu_sensor=True):
         self.landscape = landscape
         self.position = (0., 0.)
         self.angle = 0.
@@ -177,6 +178,37 @@ class NavBySceneFamiliarity(object):
         self.familiarity_model = familiarity_model if familiarity_model is not None else sads_familiarity()
         self.reset_error()
 
+        # With the HIP model the landscape and the sensor model live on the GPU as well: patches are sensed where
+        # they are scored.  Any other plug-in keeps the host sensor model below (same bytes, pinned by the fixtures).
+        self._engine = None
+        make_engine = getattr(self.familiarity_model, "make_engine", None)
+        if make_engine is not None and use_gpu_sensor and self.landscape.dtype == np.uint8:
+            self._engine = make_engine()
+            self._engine.set_landscape(self.landscape)
+            self._engine.configure_sensor(self.sensor_dimensions, self.sensor_pixel_dimensions,
+                                          self._level_tables(), self.mask_middle_n)
+
+    def _level_tables(self):
+        """uint8[3][256]: the float32 level quantisation of get_sensor_mat (:176-186) applied to every byte value."""
+        lut = np.empty((3, 256), dtype=np.uint8)
+        for ch in range(3):
+            levels = self.n_sensor_levels[ch]
+            buf = np.arange(256, dtype=np.uint8).astype(np.float32)
+            buf /= 255
+            buf *= (levels - 1)
+            np.rint(buf, out=buf)
+            buf /= (levels - 1)
+            buf *= 255
+            lut[ch] = buf          # truncating float32 -> uint8 cast
+        return lut
+
+    def _check_bounds(self, position):
+        r = self._sensor_r
+        ldims = self.landscape.shape
+        if (position[0] <= r) or (position[1] <= r) or \
+           (position[0] >= ldims[1] - r) or (position[1] >= ldims[0] - r):
+            raise OutOfLandscapeBoundsException()
+
     # ---- training (:118-148) -------------------------------------------------------------------
     def train_from_path(self, points):
         if self.training_path is not None:
@@ -189,19 +221,33 @@ class NavBySceneFamiliarity(object):
         self.training_path_length = np.sum(np.linalg.norm(steps, axis=1))
         headings = np.arctan2(steps[:, 1], steps[:, 0])
         # view i looks towards point i+1; the last point reuses the last heading (:129-132)
-        for i in range(n):
-            self.familiar_scenes[i] = self.get_sensor_mat(points[i], headings[min(i, n - 2)])
+        view_headings = headings[np.minimum(np.arange(n), n - 2)]
+        if self._engine is not None:
+            for pt in points:
+                self._check_bounds(pt)
+            # sensed and ingested on the device; familiar_scenes comes back for the API
+            self.familiar_scenes[...] = self._engine.set_library_from_poses(
+                points[:, 0], points[:, 1], view_headings, self.familiarity_model.chem_weight)
+        else:
+            for i in range(n):
+                self.familiar_scenes[i] = self.get_sensor_mat(points[i], view_headings[i])
 
         self.scene_familiarity = np.zeros(n, dtype=np.float64)
         self.training_path = points
         self.reset_error()
-        # library hand-off: the model uploads the views to the GPU here (:140)
-        self._familiarity_func = self.familiarity_model(self.familiar_scenes)
+        # library hand-off (:140): already resident when the views were sensed on the GPU
+        if self._engine is not None:
+            self._familiarity_func = self.familiarity_model.from_engine(self._engine, self.familiar_scenes)
+        else:
+            self._familiarity_func = self.familiarity_model(self.familiar_scenes)
 
     def clear_training(self):
         func = getattr(self, "_familiarity_func", None)
         if func is not None and hasattr(func, "engine"):
-            func.engine.close()
+            if func.engine is getattr(self, "_engine", None):
+                func.engine.clear_library()          # keep the landscape and the sensor configuration
+            else:
+                func.engine.close()
         self.training_path = None
         self.familiar_scenes = None
         self._familiarity_func = None
@@ -210,11 +256,9 @@ class NavBySceneFamiliarity(object):
 
     # ---- sensor (:151-192) ---------------------------------------------------------------------
     def get_sensor_mat(self, position, angle):
-        r = self._sensor_r
-        ldims = self.landscape.shape
-        if (position[0] <= r) or (position[1] <= r) or \
-           (position[0] >= ldims[1] - r) or (position[1] >= ldims[0] - r):
-            raise OutOfLandscapeBoundsException()
+        self._check_bounds(position)
+        if self._engine is not None:
+            return self._engine.sense([position[0]], [position[1]], [angle])[0]
 
         fill_sensor_from(self._landscape_glimpse_buf, position[0], position[1], angle, self.landscape)
         out = downscale_chem(self._landscape_glimpse_buf,
@@ -300,10 +344,17 @@ class NavBySceneFamiliarity(object):
         engine = getattr(func, "engine", None)
         if engine is not None:
             # one fused device step for all headings: kernel + min-merge + max + argmax (:289-315)
-            patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)
-            for a_idex, angle_offset in enumerate(self.angle_offsets):
-                patches[a_idex] = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
-            res = engine.step(patches, want_scene=self.track_scene_familiarity)
+            if engine is self._engine:
+                # patches are sensed on the GPU, straight into the scoring kernel's operand layout
+                self._check_bounds(position)
+                engine.sense_patches(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi))
+                engine.step_enqueue(want_scene=self.track_scene_familiarity)
+                res = engine.step_wait(want_scene=self.track_scene_familiarity)
+            else:
+                patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)
+                for a_idex, angle_offset in enumerate(self.angle_offsets):
+                    patches[a_idex] = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
+                res = engine.step(patches, want_scene=self.track_scene_familiarity)
             self.angle_familiarity[:] = res["angle_familiarity"]
             if self.track_scene_familiarity:
                 self.scene_familiarity[:] = res["scene_familiarity"]

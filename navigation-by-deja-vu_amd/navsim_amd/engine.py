@@ -92,6 +92,64 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_read_planes(self._ctx, int(v0), int(n), N.u8ptr(out)), "dv_read_planes")
         return out
 
+    # -- sensor model on the GPU ---------------------------------------------------------------
+    def set_landscape(self, landscape):
+        """landscape: uint8[rows, cols, 3] HSV (any strides; copied).  Kept resident in HBM."""
+        landscape = N.as_u8(landscape, "landscape")
+        if landscape.ndim != 3 or landscape.shape[2] != 3:
+            raise ValueError("landscape must be uint8[rows, cols, 3], got shape %r" % (landscape.shape,))
+        self._check(self._lib.dv_set_landscape(self._ctx, N.u8ptr(landscape), landscape.shape[0], landscape.shape[1], 3),
+                    "dv_set_landscape")
+
+    def configure_sensor(self, sensor_dimensions, sensor_pixel_dimensions, lut, mask_middle_n):
+        lut = np.ascontiguousarray(lut, dtype=np.uint8)
+        assert lut.shape == (3, 256)
+        self._check(self._lib.dv_configure_sensor(self._ctx, int(sensor_dimensions[0]), int(sensor_dimensions[1]),
+                                                  int(sensor_pixel_dimensions[0]), int(sensor_pixel_dimensions[1]),
+                                                  N.u8ptr(lut), int(mask_middle_n)), "dv_configure_sensor")
+        self.sensor_shape = (int(sensor_dimensions[1]), int(sensor_dimensions[0]))
+
+    @staticmethod
+    def _pose_arrays(x, y, angle):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        angle = np.ascontiguousarray(angle, dtype=np.float64).reshape(-1)
+        assert x.shape == y.shape == angle.shape
+        return x, y, angle
+
+    def _check_sense(self, rc, what):
+        if rc == -5:
+            msg = self._lib.dv_last_error(self._ctx)
+            raise IndexError(msg.decode() if msg else "index out of bounds")     # what the reference raises
+        self._check(rc, what)
+
+    def sense(self, x, y, angle):
+        """get_sensor_mat at n poses -> uint8[n, h, w, 3] (NavBySceneFamiliarity.py:151-192)."""
+        x, y, angle = self._pose_arrays(x, y, angle)
+        h, w = self.sensor_shape
+        out = np.empty((len(x), h, w, 3), dtype=np.uint8)
+        self._check_sense(self._lib.dv_sense(self._ctx, N.f64ptr(x), N.f64ptr(y), N.f64ptr(angle), len(x), N.u8ptr(out)),
+                          "dv_sense")
+        return out
+
+    def sense_patches(self, x, y, angles):
+        """The heading patches of one position, sensed straight into the resident patches."""
+        angles = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+        self._check_sense(self._lib.dv_sense_patches(self._ctx, float(x), float(y), N.f64ptr(angles), len(angles)),
+                          "dv_sense_patches")
+
+    def set_library_from_poses(self, x, y, angle, chem_weight=0.0, first_view=0, want_views=True):
+        """train_from_path on the device: sense the poses and ingest them as the library; returns familiar_scenes."""
+        x, y, angle = self._pose_arrays(x, y, angle)
+        h, w = self.sensor_shape
+        views = np.empty((len(x), h, w, 3), dtype=np.uint8) if want_views else None
+        self._check_sense(self._lib.dv_set_library_from_poses(self._ctx, N.f64ptr(x), N.f64ptr(y), N.f64ptr(angle), len(x),
+                                                              float(chem_weight), int(first_view),
+                                                              N.u8ptr(views) if want_views else None),
+                          "dv_set_library_from_poses")
+        self.n_views, self.shape = len(x), (h, w)
+        return views
+
     # -- scoring --------------------------------------------------------------------------------
     def _patch_shape_ok(self, p, lead):
         h, w = self.shape if self.shape else (None, None)

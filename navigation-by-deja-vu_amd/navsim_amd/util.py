@@ -17,11 +17,8 @@ def sads_familiarity(chem_weight=0.0, device=0, exact=False):
     `exact=True` makes every fambuf value the reference's double bit for bit (slower fp64 kernel);
     the default integer-sum scores are within 1e-12 relative of it.
     """
-    def sads_familiarity_internal(scenes):
-        assert 0 <= chem_weight <= 1
+    def bind(engine, scenes):
         maxfam = scenes[0].shape[0] * scenes[0].shape[1]
-        engine = FamiliarityEngine(device=device, exact=exact)
-        engine.set_library(scenes, chem_weight)
 
         def func(scene, fambuf):
             engine.score(scene, fambuf)
@@ -30,6 +27,22 @@ def sads_familiarity(chem_weight=0.0, device=0, exact=False):
         func.engine = engine
         func.chem_weight = chem_weight
         return func
+
+    def sads_familiarity_internal(scenes):
+        assert 0 <= chem_weight <= 1
+        engine = FamiliarityEngine(device=device, exact=exact)
+        engine.set_library(scenes, chem_weight)
+        return bind(engine, scenes)
+
+    # Hooks for navsim_amd.NavBySceneFamiliarity: it creates the engine early (landscape and sensor model live on
+    # the GPU too), builds the library on the device and then binds `func` to that engine.
+    def make_engine():
+        assert 0 <= chem_weight <= 1
+        return FamiliarityEngine(device=device, exact=exact)
+
+    sads_familiarity_internal.make_engine = make_engine
+    sads_familiarity_internal.from_engine = bind
+    sads_familiarity_internal.chem_weight = chem_weight
     return sads_familiarity_internal
 
 

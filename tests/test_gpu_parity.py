@@ -250,10 +250,80 @@ def test_errors(eng):
 
 
 def test_trajectories_match_reference_on_gpu(manifest, golden):
-    """1000-step trajectories through the product agent with the HIP engine (fused step)."""
+    """1000-step trajectories through the product agent: sensor model, scoring and decision all on the GPU."""
     z = golden("t4_trajectory.npz")
     for case in manifest["t4_trajectory"]:
         check_trajectory(case, z, navsim_amd.sads_familiarity(case["chem_weight"]), fam_rtol=RTOL)
+
+
+def test_trajectory_with_host_sensor_and_uploaded_patches(manifest, golden):
+    """Same agent with the sensor model on the host (patches uploaded each step through dv_step)."""
+    z = golden("t4_trajectory.npz")
+    case = manifest["t4_trajectory"][2]
+    check_trajectory(case, z, navsim_amd.sads_familiarity(case["chem_weight"]), fam_rtol=RTOL, use_gpu_sensor=False)
+
+
+def test_gpu_sensor_model_matches_reference(manifest, golden):
+    """k_sense against the reference's get_sensor_mat outputs (tests/golden/t5_sensor.npz)."""
+    z = golden("t5_sensor.npz")
+    meta = manifest["t5_sensor"]["meta"]
+    land = synth.synth_landscape(meta["landscape"]["seed"], meta["landscape"]["size"], meta["landscape"]["grain"])
+    lands = {"land": land, "land2": z["land2"]}
+    for case in manifest["t5_sensor"]["cases"]:
+        levels = case["n_sensor_levels"]
+        levels = tuple(levels) if isinstance(levels, list) else levels
+        nsf = navsim_amd.NavBySceneFamiliarity(
+            lands[case["landscape"]], case["sensor_dimensions"], 1.0, n_test_angles=4,
+            sensor_pixel_dimensions=case["sensor_pixel_dimensions"], n_sensor_levels=levels,
+            mask_middle_n=case["mask_middle_n"], familiarity_model=navsim_amd.sads_familiarity())
+        assert nsf._engine is not None
+        for k, (x, y, a) in enumerate(case["poses"]):
+            assert np.array_equal(nsf.get_sensor_mat((x, y), a), z[case["name"] + "_mats"][k]), (case["name"], k)
+        nsf._engine.close()
+
+
+@pytest.mark.parametrize("sdim,spd,levels,mask", [((32, 32), [1, 1], 5, 0), ((16, 8), [2, 4], 4, 1),
+                                                  ((10, 6), [3, 5], (7, 256, 3), 2), ((64, 64), [1, 1], 5, 0)])
+def test_gpu_sensor_equals_host_sensor_on_random_poses(golden, sdim, spd, levels, mask):
+    """Many random poses: the GPU sensor model and the (fixture-pinned) host sensor model agree byte for byte."""
+    land2 = golden("t5_sensor.npz")["land2"]
+    land = np.tile(land2, (2, 2, 1))                       # 600 x 600
+    gpu = navsim_amd.NavBySceneFamiliarity(land, sdim, 1.0, n_test_angles=4, sensor_pixel_dimensions=spd,
+                                           n_sensor_levels=levels, mask_middle_n=mask,
+                                           familiarity_model=navsim_amd.sads_familiarity())
+    host = navsim_amd.NavBySceneFamiliarity(land, sdim, 1.0, n_test_angles=4, sensor_pixel_dimensions=spd,
+                                            n_sensor_levels=levels, mask_middle_n=mask, use_gpu_sensor=False,
+                                            familiarity_model=oracle.sads_familiarity())
+    rng = np.random.default_rng(7)
+    n = 60
+    xs, ys = rng.uniform(120, 480, n), rng.uniform(120, 480, n)
+    xs[:8] = np.round(xs[:8]) + 0.5                        # exact .5 coordinates: C round() half away from zero
+    ys[:8] = np.round(ys[:8]) - 0.5
+    angs = rng.uniform(0, 2 * np.pi, n)
+    angs[:4] = [0.0, np.pi / 2, np.pi, 3 * np.pi / 2]
+    got = gpu._engine.sense(xs, ys, angs)
+    for i in range(n):
+        assert np.array_equal(got[i], host.get_sensor_mat((xs[i], ys[i]), angs[i])), i
+    gpu._engine.close()
+
+
+def test_gpu_sensor_index_errors_like_the_reference():
+    land = synth.synth_landscape(3, 120, 4)
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (40, 40), 1.0, n_test_angles=4,
+                                           familiarity_model=navsim_amd.sads_familiarity())
+    host = navsim_amd.NavBySceneFamiliarity(land, (40, 40), 1.0, n_test_angles=4, use_gpu_sensor=False,
+                                            familiarity_model=oracle.sads_familiarity())
+    # corners of a rotated sensor reach r*sqrt(2): negative indices wrap, indices past the end raise IndexError
+    near_origin = (20.5, 20.5)
+    assert np.array_equal(nsf.get_sensor_mat(near_origin, 0.8), host.get_sensor_mat(near_origin, 0.8))
+    far_corner = (99.4, 99.4)
+    with pytest.raises(IndexError):
+        host.get_sensor_mat(far_corner, 0.8)
+    with pytest.raises(IndexError):
+        nsf.get_sensor_mat(far_corner, 0.8)
+    with pytest.raises(navsim_amd.OutOfLandscapeBoundsException):
+        nsf.get_sensor_mat((10.0, 60.0), 0.0)
+    nsf._engine.close()
 
 
 def test_full_size_properties():

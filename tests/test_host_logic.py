@@ -56,7 +56,7 @@ def test_sensor_model_matches_reference(manifest, golden):
     assert np.array_equal(agent_mod.downscale_chem(z["dc_quirk_in"], 8, 2), z["dc_quirk_out"])
 
 
-def _run_trajectory(case, land, model):
+def _run_trajectory(case, land, model, **agent_kwargs):
     path = synth.sin_training_path(0.5, 0.2 * case["landscape"]["size"], 0.6 * case["landscape"]["size"],
                                    arclen=1.0)[:case["n_views"]]
     assert sha(path) == case["path_sha"]
@@ -64,7 +64,7 @@ def _run_trajectory(case, land, model):
         land, case["sensor_dimensions"], case["step_size"], n_test_angles=case["n_test_angles"],
         sensor_pixel_dimensions=case["sensor_pixel_dimensions"], n_sensor_levels=case["n_sensor_levels"],
         mask_middle_n=case["mask_middle_n"], saccade_degrees=case["saccade_degrees"],
-        max_distance_to_training_path=450, familiarity_model=model)
+        max_distance_to_training_path=450, familiarity_model=model, **agent_kwargs)
     nsf.train_from_path(path)
     d = path[2] - path[1]
     nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi)) + np.deg2rad(case["start_angle_offset_deg"])
@@ -83,10 +83,10 @@ def _run_trajectory(case, land, model):
     return nsf, np.array(best), np.array(pos), np.array(ang), np.array(fam), status
 
 
-def check_trajectory(case, z, model, fam_rtol):
+def check_trajectory(case, z, model, fam_rtol, **agent_kwargs):
     land = synth.synth_landscape(case["landscape"]["seed"], case["landscape"]["size"], case["landscape"]["grain"])
     assert sha(land) == case["landscape"]["sha"]
-    nsf, best, pos, ang, fam, status = _run_trajectory(case, land, model)
+    nsf, best, pos, ang, fam, status = _run_trajectory(case, land, model, **agent_kwargs)
     name = case["name"]
     assert sha(nsf.familiar_scenes) == bytes(z[name + "_scenes_sha"]).hex()      # training views byte-identical
     n = case["steps_recorded"]
