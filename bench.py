@@ -65,6 +65,31 @@ def cpu_baseline(h, w, A, cw, seed, budget_views):
                        "linear in views (util.pyx:44)" % (budget_views, A, w, h, cw, dt))
 
 
+def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
+    """Full navsim-style agent on the same shape: sense (GPU) + score + decide + move, per step."""
+    import navsim_amd
+    from navsim_amd import synth
+    L = 2000                                                    # scripts/run_experiment.py:40 mentions 2000x2000 landscapes
+    land = synth.synth_landscape(seed, L, 4)
+    path = synth.sin_training_path(0.5, 0.2 * L, 0.6 * L, arclen=0.6 * L * 1.4 / n_views)[:n_views]
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (w, h), 0.5, n_test_angles=A, n_sensor_levels=5,
+                                           familiarity_model=navsim_amd.sads_familiarity(cw),
+                                           track_scene_familiarity=False)
+    nsf.train_from_path(path)
+    d = path[2] - path[1]
+    nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi))
+    nsf.position = path[1] + np.array([1.0, -1.0])
+    for _ in range(10):
+        nsf.step_forward(fake=True)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        nsf.step_forward(fake=True)
+    dt = time.perf_counter() - t0
+    n_lib = len(path)
+    nsf.clear_training()
+    return n_steps / dt, n_lib
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +102,7 @@ def main():
                     help="0 < cw < 1 keeps all three reference bytes per pixel (H,S,V) algorithmically live")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--cpu-views", type=int, default=12288, help="views in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--agent-steps", type=int, default=300, help="steps of the full agent loop timed at N=1 (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank "
                     "(exercises the RCCL exchange path on a single GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
@@ -195,6 +221,12 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kern_ms, "launches_timed": kern_n,
             },
         }
+        if world == 1 and args.agent_steps > 0 and not args.force_dist:
+            eng.clear_library()                                  # make room: the agent builds its own library
+            sps, n_lib = agent_steps_per_s(h, w, A, cw, F, args.seed, args.agent_steps)
+            out["agent"] = {"nav_steps_per_s": sps, "view_comparisons_per_s": sps * n_lib * A, "library_views": n_lib,
+                            "what": "navsim_amd.NavBySceneFamiliarity.step_forward(fake=True): sensor model on the GPU "
+                                    "(2000x2000 landscape resident), scoring, decision, position update; Python caller"}
         if world == 1 and args.cpu_views > 0:
             out["cpu_baseline"] = cpu_baseline(h, w, A, cw, args.seed, min(args.cpu_views, F))
         else:

@@ -361,3 +361,32 @@ def test_full_size_properties():
                         halves[0]["angle_view"], halves[1]["angle_view"])
         assert np.array_equal(pick, full_view)
     eng.close()
+
+
+def test_large_library_properties():
+    """BASELINE config 2 (128x128 sensor, 500k views, 32 headings; 24.6 GB of tiles) through size-independent properties."""
+    F, h, w, A, seed, cw = 500000, 128, 128, 32, 777, 0.25
+    eng = navsim_amd.FamiliarityEngine(device=0)
+    eng.generate_library(seed, F, h, w, cw)
+    info = eng.library_info()
+    assert info["tile_bytes"] >= F * h * w * 3
+    patches = synth.synth_patches(seed, A, h, w)
+    targets = {5: 499999, 17: 250001, 30: 3}                  # heading -> planted view (first, middle, last groups)
+    for a, f in targets.items():
+        patches[a] = synth.near_match_patch(synth.synth_views(seed, 1, h, w, first_view=f)[0], 100 + a,
+                                            fraction=0.01 * (1 + a % 3))
+    r = eng.step(patches, want_scene=True)
+    for a, f in targets.items():
+        assert r["angle_view"][a] == f, (a, r["angle_view"][a])
+    assert r["best_idex"] == 30 and r["best_view"] == 3       # 1 % perturbed beats 2 % and 3 %
+    # sampled views against the oracle
+    for f0 in (0, 250000, F - 4):
+        sub = synth.synth_views(seed, 4, h, w, first_view=f0)
+        want = oracle.step(sub, patches, cw)
+        np.testing.assert_allclose(r["scene_familiarity"][f0:f0 + 4], want["scene_familiarity"], rtol=RTOL)
+    # exact value of the winner is reproduced by the resolver when forced
+    r2 = eng.step(patches, want_scene=False, force_resolve=True)
+    win = synth.synth_views(seed, 1, h, w, first_view=3)
+    assert r2["flags"] & 1 and r2["best_idex"] == 30
+    assert r2["step_familiarity"] == oracle.sads_hsv(win, patches[30], cw)[0]
+    eng.close()
