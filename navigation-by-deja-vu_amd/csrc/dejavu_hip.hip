@@ -48,7 +48,6 @@ struct dv_ctx {
     int target_items = 7000;                  // items the scoring grid aims for: ~27 per CU (DEJAVU_TARGET_ITEMS)
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
     int waves_per_block = 1;                  // DEJAVU_WPB
-    int prefetch = 1;                         // register ring depth of the scoring kernel, 1 or 2 (DEJAVU_PF)
     double* d_fam = nullptr;                  // [64][Fpad]
     double* d_scene = nullptr;                // [Fpad]
     StepState* d_state = nullptr;
@@ -141,7 +140,6 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
-    env_int("DEJAVU_PF", c->prefetch, 1, 2);
     *out = c;
     return DV_OK;
 }
@@ -492,7 +490,7 @@ extern "C" int dv_read_planes(dv_ctx* c, int64_t v0, int64_t n, uint8_t* out) {
 // ------------------------------------------------------------------ patches
 static int prep_patches(dv_ctx* c, int A) {
     c->A = A;
-    c->APAD = A <= 16 ? 16 : (A <= 32 ? 32 : 64);
+    c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
     const long long total = (long long)c->cfg.npl * c->cfg.Q * 4 * c->APAD;
     const unsigned nb = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(k_prep, dim3(nb + A), dim3(256), 0, c->stream, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, A,
@@ -529,13 +527,23 @@ extern "C" int dv_generate_patches(dv_ctx* c, uint64_t seed, int A) {
 }
 
 // ------------------------------------------------------------------ scoring launches
+// Resident waves per CU of a scoring kernel: its VGPR allocation (granule 8, 512 per SIMD lane) and at most 7 per
+// SIMD -- the kernels are built with <= 96 SGPRs (amdgpu_num_sgpr), which the hardware admits 7 times per SIMD.
+static int resident_waves_per_cu(const void* kernel) {
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, kernel) != hipSuccess || attr.numRegs <= 0) return 8;
+    const int alloc = (attr.numRegs + 7) / 8 * 8;
+    int per_simd = 512 / alloc;
+    if (per_simd > 7) per_simd = 7;
+    if (per_simd < 1) per_simd = 1;
+    return 4 * per_simd;
+}
+
 // Grid of the scoring kernels: single-wave workgroups (waves_per_block > 1 only for experiments), never more
-// than are resident at once.  Resident waves per CU by accumulator count: the 16-heading kernels need ~52
-// VGPRs but ~95 SGPRs (patch operands are prefetched into SGPRs), which admits 6-7 waves per SIMD.
-static dim3 scoring_grid(const dv_ctx* c, dim3& block) {
+// than are resident at once, walking the items with a grid stride.
+static dim3 scoring_grid(const dv_ctx* c, int kernel_wpc, dim3& block) {
     const int wpb = c->waves_per_block;
-    int wpc = c->waves_per_cu;
-    if (wpc == 0) wpc = c->APAD == 16 ? 28 : (c->APAD == 32 ? 20 : 12);
+    const int wpc = c->waves_per_cu ? c->waves_per_cu : kernel_wpc;
     const long long n_items = (c->cfg.Fpad / 64) * (long long)c->nchunk;
     long long waves = 256ll * wpc;
     if (waves > n_items) waves = n_items;
@@ -543,28 +551,41 @@ static dim3 scoring_grid(const dv_ctx* c, dim3& block) {
     return dim3((unsigned)((waves + wpb - 1) / wpb));
 }
 
+template <int NHS, int HASV, int AP, int ATOT>
+static void launch_tiles(dv_ctx* c) {
+    static const int wpc = resident_waves_per_cu((const void*)k_sad_tiles<NHS, HASV, AP, ATOT>);
+    dim3 block;
+    const dim3 grid = scoring_grid(c, wpc, block);
+    // more than 32 headings: two passes of the 32-wide kernel (its 5 waves per SIMD beat one 64-wide pass at 2)
+    for (int a_off = 0; a_off < ATOT; a_off += AP)
+        hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part,
+                           c->cfg, c->nchunk, a_off);
+}
+
 template <int NHS, int HASV>
 static void launch_tiles_apad(dv_ctx* c) {
+    if (c->APAD == 8) launch_tiles<NHS, HASV, 8, 8>(c);
+    else if (c->APAD == 16) launch_tiles<NHS, HASV, 16, 16>(c);
+    else if (c->APAD == 32) launch_tiles<NHS, HASV, 32, 32>(c);
+    else launch_tiles<NHS, HASV, 32, 64>(c);
+}
+
+template <int HAS_HS, int HASV, int AP, int ATOT>
+static void launch_generic(dv_ctx* c) {
+    static const int wpc = resident_waves_per_cu((const void*)k_sad_generic<HAS_HS, HASV, AP, ATOT>);
     dim3 block;
-    const dim3 grid = scoring_grid(c, block);
-#define DV_LAUNCH(AP, PFD) \
-    hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, PFD>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg, c->nchunk)
-    if (c->APAD == 16) { if (c->prefetch == 2) DV_LAUNCH(16, 2); else DV_LAUNCH(16, 1); }
-    else if (c->APAD == 32) { if (c->prefetch == 2) DV_LAUNCH(32, 2); else DV_LAUNCH(32, 1); }
-    else DV_LAUNCH(64, 1);
-#undef DV_LAUNCH
+    const dim3 grid = scoring_grid(c, wpc, block);
+    for (int a_off = 0; a_off < ATOT; a_off += AP)
+        hipLaunchKernelGGL((k_sad_generic<HAS_HS, HASV, AP, ATOT>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part,
+                           c->cfg, c->nchunk, a_off);
 }
 
 template <int HAS_HS, int HASV>
 static void launch_generic_apad(dv_ctx* c) {
-    dim3 block;
-    const dim3 grid = scoring_grid(c, block);
-#define DV_LAUNCH(AP) \
-    hipLaunchKernelGGL((k_sad_generic<HAS_HS, HASV, AP>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg, c->nchunk)
-    if (c->APAD == 16) DV_LAUNCH(16);
-    else if (c->APAD == 32) DV_LAUNCH(32);
-    else DV_LAUNCH(64);
-#undef DV_LAUNCH
+    if (c->APAD == 8) launch_generic<HAS_HS, HASV, 8, 8>(c);
+    else if (c->APAD == 16) launch_generic<HAS_HS, HASV, 16, 16>(c);
+    else if (c->APAD == 32) launch_generic<HAS_HS, HASV, 32, 32>(c);
+    else launch_generic<HAS_HS, HASV, 32, 64>(c);
 }
 
 // Scoring: integer-sum kernel + combine (or the exact fp64 kernel), then amax[a] without atomics.

@@ -284,12 +284,19 @@ __device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
 }
 
 // One-hot layout.  NHS saturation planes + optional value plane; APAD headings per pass.
-template <int NHS, int HASV, int APAD, int PF>      // PF: register ring depth, chunk q+PF is in flight while q is scored
-__global__ void __launch_bounds__(256)
+// Scores headings [a_off, a_off+APAD) of the ATOT resident ones (ATOT == APAD except for the two 32-wide passes
+// that cover up to 64 headings).
+template <int NHS, int HASV, int APAD, int ATOT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
 k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
-            int nchunk) {
+            int nchunk, int a_off_arg) {
+    constexpr int apad_total = ATOT;
+    const int a_off = (ATOT == APAD) ? 0 : a_off_arg;
     constexpr int NPL = NHS + HASV;
     constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
+    // Register ring depth: chunk q+PF is in flight while q is scored.  Few planes / few headings leave VGPRs for a
+    // deeper ring (more bytes in flight per wave); 3 planes x 16 headings is best at PF = 1 (measured).
+    constexpr int PF = (APAD <= 16) ? (NPL == 1 ? 3 : (NPL == 2 ? 2 : 1)) : 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
@@ -330,14 +337,14 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
                     if (qc < q1) {
 #pragma unroll
                         for (int pl = 0; pl < NPL; ++pl) {
-                            const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * APAD;   // wave-uniform -> s_load
+                            const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * apad_total + a_off;   // wave-uniform -> s_load
                             const unsigned lw[4] = {ring[s][pl].x, ring[s][pl].y, ring[s][pl].z, ring[s][pl].w};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                                 for (int a = 0; a < APAD; ++a) {
-                                    if (pl < NHS) acc_hs[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_hs[a]);
-                                    else acc_v[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc_v[a]);
+                                    if (pl < NHS) acc_hs[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * apad_total + a], acc_hs[a]);
+                                    else acc_v[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * apad_total + a], acc_v[a]);
                                 }
                             }
                         }
@@ -345,23 +352,25 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
                 }
             }
         }
-        unsigned* dst = part + ((long long)ch * NSUM * APAD) * c.Fpad + g * 64 + lane;
+        unsigned* dst = part + ((long long)ch * NSUM * apad_total + a_off) * c.Fpad + g * 64 + lane;
         if (NHS > 0) {
 #pragma unroll
             for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
         }
         if (HASV) {
 #pragma unroll
-            for (int a = 0; a < APAD; ++a) dst[(long long)((NHS > 0 ? APAD : 0) + a) * c.Fpad] = acc_v[a];
+            for (int a = 0; a < APAD; ++a) dst[(long long)((NHS > 0 ? apad_total : 0) + a) * c.Fpad] = acc_v[a];
         }
     }
 }
 
 // Generic-hue layout (planes H,S[,V]): per-byte hue compare done with bit tricks.
-template <int HAS_HS, int HASV, int APAD>
-__global__ void __launch_bounds__(256)
+template <int HAS_HS, int HASV, int APAD, int ATOT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
 k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
-              int nchunk) {
+              int nchunk, int a_off_arg) {
+    constexpr int apad_total = ATOT;
+    const int a_off = (ATOT == APAD) ? 0 : a_off_arg;
     constexpr int NPL = (HAS_HS ? 2 : 0) + HASV;
     constexpr int NSUM = HAS_HS + HASV;
     const int lane = threadIdx.x & 63;
@@ -389,18 +398,18 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) L[pl] = load_tile_nt(&base[(long long)(pl * Q + q) * 64]);
         if constexpr (HAS_HS != 0) {
-            const unsigned* ph = prep + ((long long)(0 * Q + q) * 4) * APAD;
-            const unsigned* ps = prep + ((long long)(1 * Q + q) * 4) * APAD;
+            const unsigned* ph = prep + ((long long)(0 * Q + q) * 4) * apad_total + a_off;
+            const unsigned* ps = prep + ((long long)(1 * Q + q) * 4) * apad_total + a_off;
             const unsigned lh[4] = {L[0].x, L[0].y, L[0].z, L[0].w};
             const unsigned ls[4] = {L[1].x, L[1].y, L[1].z, L[1].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int a = 0; a < APAD; ++a) {
-                    const unsigned x = lh[j] ^ ph[j * APAD + a];
+                    const unsigned x = lh[j] ^ ph[j * apad_total + a];
                     unsigned t = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;  // 0x80 where hue differs
                     const unsigned ne = (t - (t >> 7)) | t;                                  // 0xFF where hue differs
-                    const unsigned sp = ps[j * APAD + a];
+                    const unsigned sp = ps[j * apad_total + a];
                     unsigned s = acc_hs[a];
                     s = __builtin_amdgcn_sad_u8(sp & ~ne, ls[j] & ~ne, s);   // same hue: |S_s - S_f|
                     s = __builtin_amdgcn_sad_u8(sp & ne, 0u, s);             // different hue: S_s + S_f
@@ -411,23 +420,23 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
         }
         if constexpr (HASV != 0) {
             constexpr int VP = HAS_HS ? 2 : 0;
-            const unsigned* pv = prep + ((long long)(VP * Q + q) * 4) * APAD;
+            const unsigned* pv = prep + ((long long)(VP * Q + q) * 4) * apad_total + a_off;
             const unsigned lv[4] = {L[VP].x, L[VP].y, L[VP].z, L[VP].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int a = 0; a < APAD; ++a) acc_v[a] = __builtin_amdgcn_sad_u8(lv[j], pv[j * APAD + a], acc_v[a]);
+                for (int a = 0; a < APAD; ++a) acc_v[a] = __builtin_amdgcn_sad_u8(lv[j], pv[j * apad_total + a], acc_v[a]);
             }
         }
     }
-    unsigned* dst = part + ((long long)ch * NSUM * APAD) * c.Fpad + g * 64 + lane;
+    unsigned* dst = part + ((long long)ch * NSUM * apad_total + a_off) * c.Fpad + g * 64 + lane;
     if (HAS_HS) {
 #pragma unroll
         for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
     }
     if (HASV) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) dst[(long long)((HAS_HS ? APAD : 0) + a) * c.Fpad] = acc_v[a];
+        for (int a = 0; a < APAD; ++a) dst[(long long)((HAS_HS ? apad_total : 0) + a) * c.Fpad] = acc_v[a];
     }
   }
 }
