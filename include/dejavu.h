@@ -145,6 +145,12 @@ int dv_score(dv_ctx *ctx, const uint8_t *patch, double *fambuf);
  */
 int dv_step(dv_ctx *ctx, const uint8_t *patches, int n_headings, uint32_t flags,
             dv_step_result *result, double *scene_fam);
+/*
+ * Ensemble form: n_agents agents, each with its own n_headings patches (uint8[n_agents, A, h, w, 3]), against
+ * the same library; results[n_agents].  Agents are scored DV_MAX_HEADINGS / A at a time in one library pass.
+ */
+int dv_step_batch(dv_ctx *ctx, const uint8_t *patches, int n_agents, int n_headings, uint32_t flags,
+                  dv_step_result *results);
 /* Re-run the exact resolver on the candidates of the last step (sharded runs, cross-rank ties). */
 int dv_resolve(dv_ctx *ctx, dv_step_result *result);
 

@@ -57,7 +57,8 @@ struct dv_ctx {
     StepResultDev* d_result = nullptr;        // device-side address of h_result
     double* d_record = nullptr;               // [3 + 4*64] packed record of the last step, for device-side exchange
     double* h_scene = nullptr;                // pinned staging for scene_fam
-    int A = 0, APAD = 0;                      // resident patches
+    int A = 0, APAD = 0;                      // resident patches (all agents of the pass)
+    int n_agents = 1, A_agent = 0;            // agents in the resident pass and headings per agent
     bool step_pending = false;
     bool last_want_scene = false;
     double delta = 0.0;
@@ -226,16 +227,17 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_pmax, (size_t)kMaxHeadings * (g.Fpad / 64) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_fam, (size_t)kMaxHeadings * g.Fpad * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_scene, (size_t)g.Fpad * sizeof(double)));
-    HIP_TRY(c, hipMalloc(&c->d_state, sizeof(StepState)));
-    HIP_TRY(c, hipMalloc(&c->d_cand, kCandCap * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMalloc(&c->d_cand_exact, kCandCap * sizeof(double)));
-    HIP_TRY(c, hipMalloc(&c->d_record, (3 + 4 * kMaxHeadings) * sizeof(double)));
-    HIP_TRY(c, hipHostMalloc(&c->h_result, sizeof(StepResultDev), hipHostMallocMapped));
+    // per-agent state of a batched pass: up to kMaxHeadings agents (one heading each)
+    HIP_TRY(c, hipMalloc(&c->d_state, kMaxHeadings * sizeof(StepState)));
+    HIP_TRY(c, hipMalloc(&c->d_cand, (size_t)kMaxHeadings * kCandCap * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc(&c->d_cand_exact, (size_t)kMaxHeadings * kCandCap * sizeof(double)));
+    HIP_TRY(c, hipMalloc(&c->d_record, (size_t)kMaxHeadings * (3 + 4 * kMaxHeadings) * sizeof(double)));
+    HIP_TRY(c, hipHostMalloc(&c->h_result, kMaxHeadings * sizeof(StepResultDev), hipHostMallocMapped));
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_result, c->h_result, 0));
-    memset(c->h_result, 0, sizeof(StepResultDev));
+    memset(c->h_result, 0, kMaxHeadings * sizeof(StepResultDev));
     HIP_TRY(c, hipHostMalloc(&c->h_scene, (size_t)g.Fpad * sizeof(double)));
     HIP_TRY(c, hipMemsetAsync(c->d_hsconst, 0, kMaxHeadings * sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(StepState), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_state, 0, kMaxHeadings * sizeof(StepState), c->stream));
     c->have_lib = true;
     return DV_OK;
 }
@@ -490,6 +492,8 @@ extern "C" int dv_read_planes(dv_ctx* c, int64_t v0, int64_t n, uint8_t* out) {
 // ------------------------------------------------------------------ patches
 static int prep_patches(dv_ctx* c, int A) {
     c->A = A;
+    c->n_agents = 1;
+    c->A_agent = A;
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
     const long long total = (long long)c->cfg.npl * c->cfg.Q * 4 * c->APAD;
     const unsigned nb = (unsigned)((total + 255) / 256);
@@ -608,7 +612,7 @@ static int launch_scoring(dv_ctx* c) {
     int n_partial = 0;
     if (c->exact) {
         hipLaunchKernelGGL(k_exact_all, dim3((unsigned)(g.Fpad / 64), (unsigned)((c->A + 3) / 4)), dim3(64, 4), 0, c->stream,
-                           c->d_tiles, c->d_raw_patches, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->A);
+                           c->d_tiles, c->d_raw_patches, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->A, c->n_agents);
         HIP_TRY(c, hipGetLastError());
         n_partial = (int)(g.Fpad / 64);
     } else {
@@ -635,7 +639,7 @@ static int launch_scoring(dv_ctx* c) {
         if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
         n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
         hipLaunchKernelGGL(k_combine, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
-                           c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum);
+                           c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum, c->n_agents);
         HIP_TRY(c, hipGetLastError());
     }
     if (c->exact && c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
@@ -649,9 +653,9 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     const int force = (flags & DV_STEP_FORCE_RESOLVE) ? 1 : 0;
     int rc = launch_scoring(c);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_pmax, c->n_partial,
-                       c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg, c->A, c->delta,
-                       want_scene ? 1 : 0, c->exact, force);
+    hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
+                       c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
+                       c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force);
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
         HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -660,13 +664,15 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     return DV_OK;
 }
 
-// Rare path: re-score the listed candidates with the exact kernel and decide on those values.
-static int enqueue_resolve(dv_ctx* c) {
-    hipLaunchKernelGGL(k_resolve, dim3(256), dim3(64), 0, c->stream, c->d_tiles, c->d_raw_patches, c->d_state, c->d_cand,
-                       c->d_cand_exact, c->cfg);
+// Rare path: re-score one agent's listed candidates with the exact kernel and decide on those values.
+static int enqueue_resolve(dv_ctx* c, int agent = 0) {
+    const size_t co = (size_t)agent * kCandCap;
+    hipLaunchKernelGGL(k_resolve, dim3(256), dim3(64), 0, c->stream, c->d_tiles,
+                       c->d_raw_patches + (size_t)agent * c->A_agent * c->cfg.P * 3, c->d_state + agent, c->d_cand + co,
+                       c->d_cand_exact + co, c->cfg);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result,
-                       c->d_record, c->cfg, c->A, c->delta);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state + agent, c->d_cand + co, c->d_cand_exact + co,
+                       c->d_result + agent, c->d_record + (size_t)agent * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
@@ -678,34 +684,52 @@ extern "C" int dv_step_enqueue(dv_ctx* c, uint32_t flags) {
     return enqueue_step(c, flags, (flags & DV_STEP_WANT_SCENE) != 0);
 }
 
-static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam) {
+// Waits for the enqueued pass; runs the exact resolver for agents whose near-ties need it; redoes the pass with exact
+// scores if a candidate list overflowed.  Results are left in c->h_result[0 .. n_agents).
+static int finish_pass(dv_ctx* c) {
     if (!c->step_pending) return fail(c, DV_ERR_STATE, "no step enqueued");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_result->flags & kResNeedsResolve) {
-        // Two or more (heading, view) pairs within delta of the maximum: the exact kernel decides.
-        int rc = enqueue_resolve(c);
-        if (rc) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bool any = false;
+    for (int ag = 0; ag < c->n_agents; ++ag) {
+        if (c->h_result[ag].flags & kResNeedsResolve) {
+            // two or more (heading, view) pairs within delta of the maximum: the exact kernel decides
+            int rc = enqueue_resolve(c, ag);
+            if (rc) return rc;
+            any = true;
+        }
     }
-    if (c->h_result->flags & DV_RES_OVERFLOW) {
-        // More near-ties than the candidate list holds: redo this step with exact scores everywhere.
+    if (any) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bool overflow = false;
+    for (int ag = 0; ag < c->n_agents; ++ag) overflow |= (c->h_result[ag].flags & DV_RES_OVERFLOW) != 0;
+    if (overflow) {
+        // More near-ties than a candidate list holds: redo this pass with exact scores everywhere.
         const int was_exact = c->exact;
-        const long long n_first = c->h_result->n_candidates;
+        std::vector<long long> n_first(c->n_agents);
+        std::vector<unsigned> had(c->n_agents);
+        for (int ag = 0; ag < c->n_agents; ++ag) { n_first[ag] = c->h_result[ag].n_candidates; had[ag] = c->h_result[ag].flags; }
         c->exact = 1;
         int rc = enqueue_step(c, 0, c->last_want_scene);
         c->exact = was_exact;
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->h_result->flags |= DV_RES_OVERFLOW;
-        c->h_result->n_candidates = n_first;
+        for (int ag = 0; ag < c->n_agents; ++ag)
+            if (had[ag] & DV_RES_OVERFLOW) { c->h_result[ag].flags |= DV_RES_OVERFLOW; c->h_result[ag].n_candidates = n_first[ag]; }
     }
-    if (result) {
-        memcpy(result, c->h_result, sizeof *result);
-        for (int a = c->A; a < kMaxHeadings; ++a) {
-            result->angle_fam[a] = 0.0; result->angle_view[a] = -1;
-            result->exact_fam[a] = 0.0; result->exact_view[a] = -1;
-        }
+    return DV_OK;
+}
+
+static void copy_result(const dv_ctx* c, int agent, dv_step_result* result) {
+    memcpy(result, &c->h_result[agent], sizeof *result);
+    for (int a = c->A_agent; a < kMaxHeadings; ++a) {
+        result->angle_fam[a] = 0.0; result->angle_view[a] = -1;
+        result->exact_fam[a] = 0.0; result->exact_view[a] = -1;
     }
+}
+
+static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam) {
+    int rc = finish_pass(c);
+    if (rc) return rc;
+    if (result) copy_result(c, 0, result);
     if (scene_fam) {
         if (!c->last_want_scene) return fail(c, DV_ERR_STATE, "scene familiarity was not requested for this step");
         memcpy(scene_fam, c->h_scene, (size_t)c->cfg.F * sizeof(double));
@@ -727,6 +751,33 @@ extern "C" int dv_step(dv_ctx* c, const uint8_t* patches, int A, uint32_t flags,
     rc = enqueue_step(c, flags, scene_fam != nullptr);
     if (rc) return rc;
     return wait_step(c, result, scene_fam);
+}
+
+// Batched agents (ensemble runs): N agents x A headings each against the same library.  Agents are grouped into
+// passes of at most DV_MAX_HEADINGS headings; one pass = one scoring launch set, one k_tail with an agent per
+// blockIdx.y.  Each agent's decision obeys the same rules as dv_step.
+extern "C" int dv_step_batch(dv_ctx* c, const uint8_t* patches, int n_agents, int A, uint32_t flags, dv_step_result* results) {
+    int rc = check_step_args(c, A);
+    if (rc) return rc;
+    if (!patches || !results || n_agents < 1) return fail(c, DV_ERR_INVALID, "dv_step_batch: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int per_pass = kMaxHeadings / A;
+    const size_t agent_bytes = (size_t)A * c->cfg.P * 3;
+    for (int first = 0; first < n_agents; first += per_pass) {
+        const int n = (n_agents - first < per_pass) ? n_agents - first : per_pass;
+        HIP_TRY(c, hipMemcpyAsync(c->d_raw_patches, patches + (size_t)first * agent_bytes, (size_t)n * agent_bytes,
+                                  hipMemcpyHostToDevice, c->stream));
+        rc = prep_patches(c, n * A);
+        if (rc) return rc;
+        c->n_agents = n;
+        c->A_agent = A;
+        rc = enqueue_step(c, flags, false);
+        if (rc) return rc;
+        rc = finish_pass(c);
+        if (rc) return rc;
+        for (int ag = 0; ag < n; ++ag) copy_result(c, ag, &results[first + ag]);
+    }
+    return DV_OK;
 }
 
 extern "C" int dv_resolve(dv_ctx* c, dv_step_result* result) {

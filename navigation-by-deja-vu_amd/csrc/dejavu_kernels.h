@@ -55,9 +55,11 @@ struct StepState {                       // zeroed by the scoring epilogue (k_co
     unsigned pad;
 };
 
-__device__ __forceinline__ void reset_step_state(StepState* st, int tid) {
-    if (tid < kMaxHeadings) st->aview[tid] = 0;
-    if (tid == 0) { st->ncand = 0; st->done = 0; }
+__device__ __forceinline__ void reset_step_state(StepState* st, int tid, int n_agents) {
+    for (int ag = 0; ag < n_agents; ++ag) {
+        if (tid < kMaxHeadings) st[ag].aview[tid] = 0;
+        if (tid == 0) { st[ag].ncand = 0; st[ag].done = 0; }
+    }
 }
 
 // ------------------------------------------------------------------ helpers
@@ -448,12 +450,12 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
 __global__ void __launch_bounds__(256)
 k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, double* __restrict__ fam,
           unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD,
-          int has_hs_sum, int has_v_sum) {
+          int has_hs_sum, int has_v_sum, int n_agents) {
     __shared__ unsigned long long wmax[4];
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int a = blockIdx.y;
     const int nsum = has_hs_sum + has_v_sum;
-    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x);
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x, n_agents);
     unsigned long long key = 0;
     if (f < c.F) {
         long long shs = hsconst[a];
@@ -491,9 +493,9 @@ k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, do
 __global__ void __launch_bounds__(256)
 k_exact_all(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw_patches,
             double* __restrict__ fam, unsigned long long* __restrict__ groupmax, StepState* __restrict__ st, LibCfg c,
-            int A) {
+            int A, int n_agents) {
     const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.y * 64 + threadIdx.x);
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.y * 64 + threadIdx.x, n_agents);
     const int a = blockIdx.y * 4 + threadIdx.y;
     if (a >= A) return;
     const long long g = blockIdx.x;
@@ -621,6 +623,8 @@ __device__ __forceinline__ void emit_record(const StepResultDev* r, double* __re
 //     integer-sum score is within `delta` of the global maximum;
 //  3. the block that finishes last decides (argmax over headings) unless more than one candidate
 //     needs exact re-scoring, in which case it flags the result and the host runs k_resolve + k_decide.
+// blockIdx.y = agent of a batched pass: agent g owns headings [g*A, (g+1)*A) and its own state, candidate list,
+// result record and packed record.
 __global__ void __launch_bounds__(256)
 k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
        StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
@@ -628,20 +632,18 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
        int exact_all, int force) {
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int a = wave; a < A; a += 4) {
-        unsigned long long key = 0;
-        for (int i = lane; i < n_partial; i += 64) {
-            const unsigned long long k = pmax[(long long)a * n_partial + i];
-            key = k > key ? k : key;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(key, o);
-            key = other > key ? other : key;
-        }
-        if (lane == 0) s_amax[a] = key;
-    }
+    const int agent = blockIdx.y;
+    const int a0 = agent * A;
+    st += agent;
+    cand += (long long)agent * kCandCap;
+    out += agent;
+    rec += (long long)agent * (3 + 4 * kMaxHeadings);
+    fam += (long long)a0 * c.Fpad;
+    pmax += (long long)a0 * n_partial;
+    // amax[a]: all partial maxima are fetched in one round of independent loads and folded with LDS atomics
+    if (threadIdx.x < kMaxHeadings) s_amax[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * n_partial; i += blockDim.x) atomicMax(&s_amax[i / n_partial], pmax[i]);
     __syncthreads();
 
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;

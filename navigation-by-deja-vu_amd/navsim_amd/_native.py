@@ -89,6 +89,8 @@ PROTOTYPES = {
                                                  ctypes.c_int64, _u8p]),
     "dv_score": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
     "dv_step": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
+    "dv_step_batch": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                     ctypes.POINTER(StepResult)]),
     "dv_resolve": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult)]),
     "dv_upload_patches": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int]),
     "dv_generate_patches": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int]),

@@ -201,6 +201,18 @@ class FamiliarityEngine(object):
                                       N.f64ptr(scene) if want_scene else None), "dv_step")
         return self._result_dict(r, scene)
 
+    def step_batch(self, patches, force_resolve=False):
+        """Ensemble step: patches uint8[N, A, h, w, 3] -> list of N result dicts (one library pass per 64/A agents)."""
+        patches = N.as_u8(patches, "patches")
+        if patches.ndim != 5:
+            raise ValueError("patches must be uint8[N,A,h,w,3]")
+        n, A = patches.shape[0], patches.shape[1]
+        self._patch_shape_ok(patches, (n, A))
+        res = (N.StepResult * n)()
+        self._check(self._lib.dv_step_batch(self._ctx, N.u8ptr(patches), n, A,
+                                            N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, res), "dv_step_batch")
+        return [self._result_dict(res[i], None) for i in range(n)]
+
     def resolve(self):
         r = N.StepResult()
         self._check(self._lib.dv_resolve(self._ctx, ctypes.byref(r)), "dv_resolve")

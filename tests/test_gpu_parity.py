@@ -390,3 +390,30 @@ def test_large_library_properties():
     assert r2["flags"] & 1 and r2["best_idex"] == 30
     assert r2["step_familiarity"] == oracle.sads_hsv(win, patches[30], cw)[0]
     eng.close()
+
+
+@pytest.mark.parametrize("cw", [0.0, 0.4])
+def test_batched_agents_match_per_agent_reference(eng, cw):
+    """dv_step_batch: every agent of an ensemble gets the decision the reference would take for it alone."""
+    F, h, w, A, n_agents = 700, 8, 8, 6, 27          # 27 agents x 6 headings -> 3 passes (10 + 10 + 7 agents)
+    lib = synth.synth_views(31, F, h, w)
+    patches = synth.synth_views(32, n_agents * A, h, w).reshape(n_agents, A, h, w, 3)
+    patches[3, 2] = lib[600]                          # an exact match for one agent
+    patches[5, :] = patches[5, 0]                     # one agent whose headings all tie
+    patches[11, 4] = synth.near_match_patch(lib[17], 1, fraction=0.05)
+    eng.set_library(lib, cw)
+    for exact in (False, True):
+        eng.set_exact(exact)
+        got = eng.step_batch(patches)
+        assert len(got) == n_agents
+        for i in range(n_agents):
+            want = oracle.step(lib, patches[i], cw)
+            assert got[i]["best_idex"] == want["best_idex"], (i, exact, got[i]["n_candidates"], got[i]["flags"])
+            assert got[i]["best_view"] == want["best_view"], (i, exact)
+            np.testing.assert_allclose(got[i]["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+        assert got[3]["best_idex"] == 2 and got[3]["best_view"] == 600 and got[3]["step_familiarity"] == h * w
+    eng.set_exact(False)
+    # a batch of one agent is the single-agent step
+    one = eng.step_batch(patches[:1])[0]
+    ref = eng.step(patches[0], want_scene=False)
+    assert one["best_idex"] == ref["best_idex"] and np.array_equal(one["angle_familiarity"], ref["angle_familiarity"])
