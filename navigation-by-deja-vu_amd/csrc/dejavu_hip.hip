@@ -7,6 +7,8 @@
 #include "dejavu_kernels.h"
 #include "../../include/dejavu.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -60,6 +62,8 @@ struct dv_ctx {
     int A = 0, APAD = 0;                      // resident patches (all agents of the pass)
     int n_agents = 1, A_agent = 0;            // agents in the resident pass and headings per agent
     bool step_pending = false;
+    int seq = 0;                              // sequence number of the last enqueued pass (written back by k_tail)
+    int spin_wait = 1;                        // poll the mapped result record instead of blocking on the stream (DEJAVU_SPIN)
     bool last_want_scene = false;
     double delta = 0.0;
 
@@ -141,6 +145,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
+    env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
     *out = c;
     return DV_OK;
 }
@@ -655,7 +660,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
                        c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
-                       c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force);
+                       c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force, ++c->seq);
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
         HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -686,9 +691,26 @@ extern "C" int dv_step_enqueue(dv_ctx* c, uint32_t flags) {
 
 // Waits for the enqueued pass; runs the exact resolver for agents whose near-ties need it; redoes the pass with exact
 // scores if a candidate list overflowed.  Results are left in c->h_result[0 .. n_agents).
+// Host wait for k_tail: the last word of every agent's record (n_headings | seq << 32) is stored after a
+// system-scope release, so once all agents show the current sequence number their records are complete.
+static bool spin_for_results(dv_ctx* c) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int ag = 0; ag < c->n_agents; ++ag) {
+        volatile const int* word = &c->h_result[ag].reserved;
+        unsigned spins = 0;
+        while (*word != c->seq) {
+            if ((++spins & 1023u) == 0 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;   // fall back
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
+}
+
 static int finish_pass(dv_ctx* c) {
     if (!c->step_pending) return fail(c, DV_ERR_STATE, "no step enqueued");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!(c->spin_wait && !c->last_want_scene && spin_for_results(c)))
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     bool any = false;
     for (int ag = 0; ag < c->n_agents; ++ag) {
         if (c->h_result[ag].flags & kResNeedsResolve) {

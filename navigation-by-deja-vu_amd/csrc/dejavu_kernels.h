@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(256)
 k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
        StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
        StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene,
-       int exact_all, int force) {
+       int exact_all, int force, int seq) {
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ int s_last;
     const int agent = blockIdx.y;
@@ -704,13 +704,22 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     }
     __syncthreads();
     emit_record(&s_res, rec, A, threadIdx.x, blockDim.x);
-    // header (7 x 8 bytes) + the first A entries of each of the four per-heading arrays
+    // header (7 x 8 bytes) + the first A entries of each of the four per-heading arrays; the word holding
+    // n_headings/reserved goes last, behind a system-scope fence: `reserved` carries the step's sequence number,
+    // which the host may poll instead of waiting for the stream.
+    if (threadIdx.x == 0) s_res.reserved = seq;
+    __syncthreads();
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
-    if (threadIdx.x < 7) dst[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x < 6) dst[threadIdx.x] = src[threadIdx.x];
     for (int i = threadIdx.x; i < 4 * A; i += blockDim.x) {
         const int o = 7 + (i / A) * kMaxHeadings + (i % A);
         dst[o] = src[o];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&dst[6], src[6], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
