@@ -46,8 +46,9 @@ struct dv_ctx {
     unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
     unsigned long long* d_pmax = nullptr;     // [64][max(G, Fpad/256)] partial maxima
     int n_partial = 0;                        // partial maxima per heading left in d_pmax by the last scoring
-    int nchunk = 1;                           // pixel chunks per view group (work items = G * nchunk)
-    int target_items = 7000;                  // items the scoring grid aims for: ~27 per CU (DEJAVU_TARGET_ITEMS)
+    int nchunk = 1;                           // pixel chunks per view group of the last launch (work items = G * nchunk)
+    int nchunk_cap = 1;                       // chunks the partial-sum buffer has room for
+    int target_items = 0;                     // 0 = as many items as waves are resident (DEJAVU_TARGET_ITEMS overrides)
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
     int waves_per_block = 1;                  // DEJAVU_WPB
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -219,16 +220,18 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_raw_patches, (size_t)kMaxHeadings * g.P * 3));
     HIP_TRY(c, hipMalloc(&c->d_prep, (size_t)g.npl * g.Q * 4 * kMaxHeadings * sizeof(unsigned)));
     HIP_TRY(c, hipMalloc(&c->d_hsconst, kMaxHeadings * sizeof(int)));
-    // Work items = (view group, pixel chunk); enough of them to fill the chip with ~target_waves waves.
+    // Work items = (pixel chunk, view group).  The chunk count is chosen per launch (scoring_grid); the partial-sum
+    // buffer is sized for the most chunks a launch can ask for.
     {
         const long long G = g.Fpad / 64;
-        long long n = (c->target_items + G - 1) / G;
+        long long n = (256ll * 28 + G - 1) / G;
         if (n < 1) n = 1;
         if (n > g.Q) n = g.Q;
         if (n > 32) n = 32;
-        c->nchunk = (int)n;
+        c->nchunk_cap = (int)n;
+        c->nchunk = 1;
     }
-    HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nchunk * 2 * kMaxHeadings * g.Fpad * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nchunk_cap * 2 * kMaxHeadings * g.Fpad * sizeof(unsigned)));
     HIP_TRY(c, hipMalloc(&c->d_pmax, (size_t)kMaxHeadings * (g.Fpad / 64) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_fam, (size_t)kMaxHeadings * g.Fpad * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_scene, (size_t)g.Fpad * sizeof(double)));
@@ -548,14 +551,21 @@ static int resident_waves_per_cu(const void* kernel) {
     return 4 * per_simd;
 }
 
-// Grid of the scoring kernels: single-wave workgroups (waves_per_block > 1 only for experiments), never more
-// than are resident at once, walking the items with a grid stride.
-static dim3 scoring_grid(const dv_ctx* c, int kernel_wpc, dim3& block) {
+// Grid of the scoring kernels: single-wave workgroups (waves_per_block > 1 only for experiments), never more than are
+// resident at once, walking the items with a grid stride.  The pixel range is cut into as many chunks as make the item
+// count just fill the resident waves (measured optimum: 7038 items on 7168 wave slots; one item more than fits costs
+// a second round, fewer items leave SIMDs short of waves to hide latency).
+static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block) {
     const int wpb = c->waves_per_block;
     const int wpc = c->waves_per_cu ? c->waves_per_cu : kernel_wpc;
-    const long long n_items = (c->cfg.Fpad / 64) * (long long)c->nchunk;
-    long long waves = 256ll * wpc;
-    if (waves > n_items) waves = n_items;
+    const long long G = c->cfg.Fpad / 64;
+    const long long slots = 256ll * wpc;
+    long long n = c->target_items ? (c->target_items + G - 1) / G : slots / G;
+    if (n < 1) n = 1;
+    if (n > c->nchunk_cap) n = c->nchunk_cap;
+    c->nchunk = (int)n;
+    const long long n_items = G * n;
+    const long long waves = slots < n_items ? slots : n_items;
     block = dim3(64 * wpb);
     return dim3((unsigned)((waves + wpb - 1) / wpb));
 }
