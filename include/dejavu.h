@@ -128,7 +128,8 @@ int dv_configure_sensor(dv_ctx *ctx, int sensor_w, int sensor_h, int pixel_w, in
                         const uint8_t *lut, int mask_middle_n);
 /* get_sensor_mat at n poses; out: uint8[n, sensor_h, sensor_w, 3].  DV_ERR_INDEX like the reference's IndexError. */
 int dv_sense(dv_ctx *ctx, const double *x, const double *y, const double *angle, int n, uint8_t *out);
-/* The A heading patches of one position straight into the resident patches (then dv_step_enqueue). */
+/* The A heading patches of one position straight into the resident patches (then dv_step_enqueue).  No host
+ * synchronisation: a footprint past the end of the landscape is reported by the following dv_step_wait (DV_ERR_INDEX). */
 int dv_sense_patches(dv_ctx *ctx, double x, double y, const double *angles, int n_headings);
 /* train_from_path (:118-140) on the device: sense n poses and ingest them as the library; out_views
  * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */

@@ -51,6 +51,7 @@ struct dv_ctx {
     int target_items = 0;                     // 0 = as many items as waves are resident (DEJAVU_TARGET_ITEMS overrides)
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
     int waves_per_block = 1;                  // DEJAVU_WPB
+    int stagger = 0;                          // DEJAVU_STAGGER (experiment, see k_sad_tiles)
     double* d_fam = nullptr;                  // [64][Fpad]
     double* d_scene = nullptr;                // [Fpad]
     StepState* d_state = nullptr;
@@ -63,6 +64,7 @@ struct dv_ctx {
     int A = 0, APAD = 0;                      // resident patches (all agents of the pass)
     int n_agents = 1, A_agent = 0;            // agents in the resident pass and headings per agent
     bool step_pending = false;
+    bool patches_sensed = false;              // resident patches were produced by k_sense (its error flag is live)
     int seq = 0;                              // sequence number of the last enqueued pass (written back by k_tail)
     int spin_wait = 1;                        // poll the mapped result record instead of blocking on the stream (DEJAVU_SPIN)
     bool last_want_scene = false;
@@ -146,6 +148,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
+    env_int("DEJAVU_STAGGER", c->stagger, 0, 64);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
     *out = c;
     return DV_OK;
@@ -413,7 +416,8 @@ extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* ang
     if (rc) return rc;
     rc = prep_patches(c, A);
     if (rc) return rc;
-    return check_sense_error(c);
+    c->patches_sensed = true;      // no host synchronisation here: the step's result record carries the error flag
+    return DV_OK;
 }
 
 extern "C" int dv_set_library_from_poses(dv_ctx* c, const double* x, const double* y, const double* angle, int64_t n,
@@ -502,6 +506,7 @@ static int prep_patches(dv_ctx* c, int A) {
     c->A = A;
     c->n_agents = 1;
     c->A_agent = A;
+    c->patches_sensed = false;
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
     const long long total = (long long)c->cfg.npl * c->cfg.Q * 4 * c->APAD;
     const unsigned nb = (unsigned)((total + 255) / 256);
@@ -578,7 +583,7 @@ static void launch_tiles(dv_ctx* c) {
     // more than 32 headings: two passes of the 32-wide kernel (its 5 waves per SIMD beat one 64-wide pass at 2)
     for (int a_off = 0; a_off < ATOT; a_off += AP)
         hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part,
-                           c->cfg, c->nchunk, a_off);
+                           c->cfg, c->nchunk, a_off, c->stagger);
 }
 
 template <int NHS, int HASV>
@@ -670,7 +675,8 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
                        c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
-                       c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force, ++c->seq);
+                       c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force, ++c->seq,
+                       c->patches_sensed ? c->d_err : nullptr);
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
         HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -761,6 +767,8 @@ static void copy_result(const dv_ctx* c, int agent, dv_step_result* result) {
 static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam) {
     int rc = finish_pass(c);
     if (rc) return rc;
+    if (c->h_result[0].flags & kResSenseError)
+        return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)");
     if (result) copy_result(c, 0, result);
     if (scene_fam) {
         if (!c->last_want_scene) return fail(c, DV_ERR_STATE, "scene familiarity was not requested for this step");

@@ -291,9 +291,14 @@ __device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
 template <int NHS, int HASV, int APAD, int ATOT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
 k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
-            int nchunk, int a_off_arg) {
+            int nchunk, int a_off_arg, int stagger) {
     constexpr int apad_total = ATOT;
     const int a_off = (ATOT == APAD) ? 0 : a_off_arg;
+    // Optional start stagger (experiment): every other "layer" of 256 workgroups starts `stagger` x ~0.85 us late so
+    // that the waves sharing a SIMD are not all in their load phase (or all in their VALU phase) at the same time.
+    if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     constexpr int NPL = NHS + HASV;
     constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
     // Register ring depth: chunk q+PF is in flight while q is scored.  Few planes / few headings leave VGPRs for a
@@ -550,6 +555,7 @@ struct StepResultDev {                   // mirrors dv_step_result (include/deja
     long long exact_view[kMaxHeadings];
 };
 constexpr unsigned kResNeedsResolve = 8u;   // internal: candidates must be re-scored exactly before deciding
+constexpr unsigned kResSenseError = 16u;    // the resident patches were sensed past the end of the landscape
 
 // np.argmax over headings with the reference's first-maximum rule (NavBySceneFamiliarity.py:315),
 // on exact values wherever the integer scores cannot decide.  One thread.
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(256)
 k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
        StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
        StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene,
-       int exact_all, int force, int seq) {
+       int exact_all, int force, int seq, const int* __restrict__ sense_err) {
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ int s_last;
     const int agent = blockIdx.y;
@@ -701,6 +707,7 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
         // even when local near-ties still have to be re-scored); NEEDS_RESOLVE tells the host it is provisional
         decide_core(s_amax, s_aview, n_all, false, nullptr, nullptr, &s_res, c, A, delta, exact_all);
         if (needs) s_res.flags |= kResNeedsResolve;
+        if (sense_err && *sense_err) s_res.flags |= kResSenseError;     // patches came from k_sense and it ran off the landscape
     }
     __syncthreads();
     emit_record(&s_res, rec, A, threadIdx.x, blockDim.x);

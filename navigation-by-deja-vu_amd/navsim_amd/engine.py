@@ -234,8 +234,8 @@ class FamiliarityEngine(object):
     def step_wait(self, want_scene=False):
         r = N.StepResult()
         scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
-        self._check(self._lib.dv_step_wait(self._ctx, ctypes.byref(r), N.f64ptr(scene) if want_scene else None),
-                    "dv_step_wait")
+        self._check_sense(self._lib.dv_step_wait(self._ctx, ctypes.byref(r), N.f64ptr(scene) if want_scene else None),
+                          "dv_step_wait")
         return self._result_dict(r, scene)
 
     def step_record(self):

@@ -323,6 +323,14 @@ def test_gpu_sensor_index_errors_like_the_reference():
         nsf.get_sensor_mat(far_corner, 0.8)
     with pytest.raises(navsim_amd.OutOfLandscapeBoundsException):
         nsf.get_sensor_mat((10.0, 60.0), 0.0)
+    # the same condition inside a fused step: reported when the step is waited for
+    path = np.stack([np.linspace(40, 80, 30), np.full(30, 60.0)], axis=1)
+    nsf.train_from_path(path)
+    nsf.position, nsf.angle = far_corner, 0.8 - nsf.angle_offsets[0]
+    with pytest.raises(IndexError):
+        nsf.step_forward(fake=True)
+    nsf.position, nsf.angle = (60.0, 60.0), 0.0
+    nsf.step_forward(fake=True)                      # and the engine is usable afterwards
     nsf._engine.close()
 
 
