@@ -155,6 +155,19 @@ int dv_step_batch(dv_ctx *ctx, const uint8_t *patches, int n_agents, int n_headi
 /* Re-run the exact resolver on the candidates of the last step (sharded runs, cross-rank ties). */
 int dv_resolve(dv_ctx *ctx, dv_step_result *result);
 
+/* ---- ssd_f32 metric (the reference's `ssds`, navsim/util.pyx:171-184) ---- */
+/*
+ * views: float32[F,h,w] single channel.  Scores are sums of squared differences (smaller = more familiar):
+ * fp32 fma over 16 pixels folded into a double, within ~1e-6 relative of ssds() on the upcast data; the chosen
+ * heading / view are those of the exact double sums (near-ties within 3e-6 relative are re-scored exactly).
+ * At most 16 headings per step.  In the result, angle_fam[a] = min over views of the SSD of heading a,
+ * best_heading = first heading attaining the overall minimum; scene_ssd[f] = max over headings.
+ */
+int dv_set_library_f32(dv_ctx *ctx, const float *views, int64_t n_views, int h, int w, int64_t first_view);
+int dv_score_f32(dv_ctx *ctx, const float *patch, double *ssdbuf);
+int dv_step_f32(dv_ctx *ctx, const float *patches, int n_headings, uint32_t flags, dv_step_result *result,
+                double *scene_ssd);
+
 /* ---- resident / asynchronous form (benchmarks, pipelined callers) ------ */
 /* Upload patches and prepare their device layout; no host synchronisation. */
 int dv_upload_patches(dv_ctx *ctx, const uint8_t *patches, int n_headings);

@@ -33,6 +33,11 @@ struct dv_ctx {
     int exact = 0;
 
     // library
+    int metric = 0;                           // 0 = sads_hsv (uint8 HSV), 1 = ssd_f32 (float32, one channel)
+    float4* d_ftiles = nullptr;               // ssd_f32 library
+    float* d_fraw = nullptr;                  // [64][P] raw float patches
+    float* d_fprep = nullptr;                 // [Q][4][64]
+    double* d_fpart = nullptr;                // [nchunk][64][Fpad]
     bool have_lib = false;
     LibCfg cfg{};
     int h = 0, w = 0;
@@ -111,6 +116,8 @@ static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record);
+    F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
+    c->metric = 0;
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
     if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; c->d_result = nullptr; }
     if (c->h_scene) { (void)hipHostFree(c->h_scene); c->h_scene = nullptr; }
@@ -311,6 +318,90 @@ extern "C" int dv_set_library(dv_ctx* c, const uint8_t* views, int64_t F, int h,
     rc = ingest_raw(c, d_raw, F, h, w, cw, first);
     (void)hipFree(d_raw);
     return rc;
+}
+
+// ------------------------------------------------------------------ ssd_f32 metric
+static void negate_result(dv_step_result* r) {
+    r->best_fam = -r->best_fam;
+    r->approx_max = -r->approx_max;
+    for (int a = 0; a < r->n_headings; ++a) {
+        r->angle_fam[a] = -r->angle_fam[a];
+        if (r->exact_view[a] >= 0) r->exact_fam[a] = -r->exact_fam[a];
+    }
+}
+
+extern "C" int dv_set_library_f32(dv_ctx* c, const float* views, int64_t F, int h, int w, int64_t first) {
+    int rc = check_lib_args(c, F, h, w, 0.0);
+    if (rc) return rc;
+    if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = alloc_library(c, F, h, w, 0.0, first, 0, nullptr, 0);       // common per-step buffers (fam, state, records)
+    if (rc) { free_library(c); return rc; }
+    LibCfg& g = c->cfg;
+    g.Q = (g.P + 3) / 4;                                              // 4 float pixels per 16-byte chunk
+    g.npl = 1; g.nhs = 0; g.hasv = 1;
+    (void)hipFree(c->d_tiles); c->d_tiles = nullptr;
+    c->tile_bytes = (size_t)(g.Fpad / 64) * g.Q * 64 * sizeof(float4);
+    c->metric = 1;
+    {
+        const long long G = g.Fpad / 64;
+        long long n = (256ll * 28 + G - 1) / G;
+        const long long q4 = (g.Q + 3) / 4;
+        if (n > q4) n = q4;
+        if (n > 32) n = 32;
+        if (n < 1) n = 1;
+        c->nchunk_cap = (int)n;
+    }
+    HIP_TRY(c, hipMalloc(&c->d_ftiles, c->tile_bytes));
+    HIP_TRY(c, hipMalloc(&c->d_fraw, (size_t)kMaxHeadings * g.P * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_fprep, (size_t)g.Q * 4 * kMaxHeadings * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_fpart, (size_t)c->nchunk_cap * 16 * g.Fpad * sizeof(double)));
+    float* d_raw = nullptr;
+    HIP_TRY(c, hipMalloc(&d_raw, (size_t)F * g.P * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d_raw, views, (size_t)F * g.P * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const long long total = (g.Fpad / 64) * (long long)g.Q * 64;
+        hipLaunchKernelGGL(k_retile_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_ftiles, c->cfg);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_raw);
+    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "ssd_f32 ingest: %s", hipGetErrorString(e)); }
+    // fp32 accumulation over 16 pixels, then double: relative error of a score <= ~1.3e-6 (bound), typically 1e-7
+    c->delta = 0.0;
+    return DV_OK;
+}
+
+static int upload_patches_f32(dv_ctx* c, const float* patches, int A) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib || c->metric != 1) return fail(c, DV_ERR_STATE, "no ssd_f32 library set (call dv_set_library_f32 first)");
+    if (A < 1 || A > 16) return fail(c, DV_ERR_INVALID, "ssd_f32: n_headings %d outside [1, 16]", A);
+    if (!patches) return fail(c, DV_ERR_INVALID, "patches is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_fraw, patches, (size_t)A * c->cfg.P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    c->A = A; c->n_agents = 1; c->A_agent = A; c->patches_sensed = false;
+    c->APAD = A <= 8 ? 8 : 16;
+    const long long total = (long long)c->cfg.Q * 4 * c->APAD;
+    hipLaunchKernelGGL(k_prep_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep, c->cfg, A, c->APAD);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene);
+static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam);
+
+extern "C" int dv_step_f32(dv_ctx* c, const float* patches, int A, uint32_t flags, dv_step_result* result, double* scene_ssd) {
+    int rc = upload_patches_f32(c, patches, A);
+    if (rc) return rc;
+    if (!result) return fail(c, DV_ERR_INVALID, "result is NULL");
+    rc = enqueue_step(c, flags, scene_ssd != nullptr);
+    if (rc) return rc;
+    rc = wait_step(c, result, scene_ssd);
+    if (rc) return rc;
+    negate_result(result);
+    if (scene_ssd) for (int64_t f = 0; f < c->cfg.F; ++f) scene_ssd[f] = -scene_ssd[f];
+    return DV_OK;
 }
 
 // ------------------------------------------------------------------ sensor model
@@ -519,6 +610,7 @@ static int prep_patches(dv_ctx* c, int A) {
 static int check_step_args(dv_ctx* c, int A) {
     if (!c) return DV_ERR_INVALID;
     if (!c->have_lib) return fail(c, DV_ERR_STATE, "no library set (call dv_set_library first)");
+    if (c->metric != 0) return fail(c, DV_ERR_STATE, "the resident library is ssd_f32; use the _f32 entry points");
     if (A < 1 || A > kMaxHeadings) return fail(c, DV_ERR_INVALID, "n_headings %d outside [1, %d]", A, kMaxHeadings);
     return DV_OK;
 }
@@ -630,6 +722,36 @@ static int launch_scoring(dv_ctx* c) {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
     }
     int n_partial = 0;
+    if (c->metric == 1) {
+        if (c->exact) {
+            hipLaunchKernelGGL(k_exact_all_f32, dim3((unsigned)(g.Fpad / 64), (unsigned)((c->A + 3) / 4)), dim3(64, 4), 0, c->stream,
+                               c->d_ftiles, c->d_fraw, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->A, c->n_agents);
+            HIP_TRY(c, hipGetLastError());
+            n_partial = (int)(g.Fpad / 64);
+        } else {
+            dim3 block;
+            if (c->APAD == 8) {
+                static const int wpc = resident_waves_per_cu((const void*)k_ssd_tiles<8>);
+                const dim3 grid = scoring_grid(c, wpc, block);
+                hipLaunchKernelGGL(k_ssd_tiles<8>, grid, block, 0, c->stream, c->d_ftiles, c->d_fprep, c->d_fpart, c->cfg, c->nchunk);
+            } else if (c->APAD == 16) {
+                static const int wpc = resident_waves_per_cu((const void*)k_ssd_tiles<16>);
+                const dim3 grid = scoring_grid(c, wpc, block);
+                hipLaunchKernelGGL(k_ssd_tiles<16>, grid, block, 0, c->stream, c->d_ftiles, c->d_fprep, c->d_fpart, c->cfg, c->nchunk);
+            } else {
+                return fail(c, DV_ERR_INVALID, "ssd_f32 scores at most 16 headings per step (got %d)", c->A);
+            }
+            HIP_TRY(c, hipGetLastError());
+            if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+            n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
+            hipLaunchKernelGGL(k_combine_f32, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_fpart,
+                               c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, c->n_agents);
+            HIP_TRY(c, hipGetLastError());
+        }
+        if (c->exact && c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+        c->n_partial = n_partial;
+        return DV_OK;
+    }
     if (c->exact) {
         hipLaunchKernelGGL(k_exact_all, dim3((unsigned)(g.Fpad / 64), (unsigned)((c->A + 3) / 4)), dim3(64, 4), 0, c->stream,
                            c->d_tiles, c->d_raw_patches, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->A, c->n_agents);
@@ -676,7 +798,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
                        c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
                        c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force, ++c->seq,
-                       c->patches_sensed ? c->d_err : nullptr);
+                       c->patches_sensed ? c->d_err : nullptr, c->metric == 1 ? 3e-6 : 0.0);
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
         HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -688,6 +810,11 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
 // Rare path: re-score one agent's listed candidates with the exact kernel and decide on those values.
 static int enqueue_resolve(dv_ctx* c, int agent = 0) {
     const size_t co = (size_t)agent * kCandCap;
+    if (c->metric == 1)
+        hipLaunchKernelGGL(k_resolve_f32, dim3(256), dim3(64), 0, c->stream, c->d_ftiles,
+                           c->d_fraw + (size_t)agent * c->A_agent * c->cfg.P, c->d_state + agent, c->d_cand + co,
+                           c->d_cand_exact + co, c->cfg);
+    else
     hipLaunchKernelGGL(k_resolve, dim3(256), dim3(64), 0, c->stream, c->d_tiles,
                        c->d_raw_patches + (size_t)agent * c->A_agent * c->cfg.P * 3, c->d_state + agent, c->d_cand + co,
                        c->d_cand_exact + co, c->cfg);
@@ -844,6 +971,21 @@ extern "C" int dv_resolve_enqueue(dv_ctx* c) {
     if (!c->have_lib || !c->step_pending) return fail(c, DV_ERR_STATE, "no step to resolve");
     HIP_TRY(c, hipSetDevice(c->device));
     return enqueue_resolve(c);
+}
+
+static int launch_scoring(dv_ctx* c);
+
+extern "C" int dv_score_f32(dv_ctx* c, const float* patch, double* ssdbuf) {
+    int rc = upload_patches_f32(c, patch, 1);
+    if (rc) return rc;
+    if (!ssdbuf) return fail(c, DV_ERR_INVALID, "ssdbuf is NULL");
+    rc = launch_scoring(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(ssdbuf, c->d_fam, (size_t)c->cfg.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int64_t f = 0; f < c->cfg.F; ++f) ssdbuf[f] = -ssdbuf[f];
+    c->step_pending = false;
+    return DV_OK;
 }
 
 extern "C" int dv_score(dv_ctx* c, const uint8_t* patch, double* fambuf) {

@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(256)
 k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
        StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
        StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene,
-       int exact_all, int force, int seq, const int* __restrict__ sense_err) {
+       int exact_all, int force, int seq, const int* __restrict__ sense_err, double delta_rel) {
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ int s_last;
     const int agent = blockIdx.y;
@@ -656,7 +656,8 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     if (f < c.F) {
         unsigned long long gkey = 0;
         for (int a = 0; a < A; ++a) gkey = s_amax[a] > gkey ? s_amax[a] : gkey;
-        const double thr = key_to_double(gkey) - delta;
+        const double gbest = key_to_double(gkey);
+        const double thr = gbest - delta - delta_rel * fabs(gbest);
         double smin = __longlong_as_double(0x7ff0000000000000ll);
         for (int a0 = 0; a0 < A; a0 += 16) {
             double v[16];                                   // all loads of a tile issued before the first use
@@ -808,6 +809,197 @@ __global__ void k_decide(const StepState* __restrict__ st, const unsigned long l
     for (int i = lane; i < 4 * A; i += blockDim.x) {
         const int o = 7 + (i / A) * kMaxHeadings + (i % A);
         dst[o] = src[o];
+    }
+}
+
+// ------------------------------------------------------------------ ssd_f32 metric
+// Sum of squared differences of single-channel float32 views: the reference's only definition of "SSD" is
+// navsim/util.pyx:171-184 (`ssds`, dead code there): sum over i,j of (a[i,j]-b[i,j])**2, double, row-major, sequential.
+// Layout: ftiles[g][q][lane] = 4 consecutive pixels (float4) of view g*64+lane, pixels zero padded to a multiple of 4
+// (a padded pixel is 0 in both operands and adds nothing); fprep[q][j][APAD] = patch pixel 4q+j of each heading.
+// Accumulation: fp32 fma over 16 pixels, then into a double (keeps the result within ~2e-7 relative of the
+// reference's all-double sum; near-ties are re-scored exactly by k_resolve_f32).  Scores are stored NEGATED
+// (fam = -ssd) so that the max-based reductions of k_combine_f32 / k_tail apply unchanged: most familiar = least SSD.
+__global__ void k_retile_f32(const float* __restrict__ raw, float4* __restrict__ ftiles, LibCfg c) {
+    const long long total = (c.Fpad / 64) * (long long)c.Q * 64;       // c.Q = ceil(P/4) for this metric
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long r = t >> 6;
+    const int q = (int)(r % c.Q);
+    const long long f = (r / c.Q) * 64 + lane;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f < c.F)
+        for (int i = 0; i < 4; ++i) { const int px = q * 4 + i; if (px < c.P) v[i] = raw[f * (long long)c.P + px]; }
+    ftiles[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void k_prep_f32(const float* __restrict__ raw, float* __restrict__ fprep, LibCfg c, int A, int APAD) {
+    const long long total = (long long)c.Q * 4 * APAD;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int a = (int)(t % APAD);
+    const int px = (int)(t / APAD);
+    fprep[t] = (a < A && px < c.P) ? raw[(long long)a * c.P + px] : 0.f;
+}
+
+template <int APAD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
+k_ssd_tiles(const float4* __restrict__ ftiles, const float* __restrict__ fprep, double* __restrict__ part, LibCfg c, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int Q = c.Q;
+    const long long G = c.Fpad / 64;
+    const long long n_items = G * nchunk;
+    const long long stride = (long long)gridDim.x * nw;
+    for (long long item = (long long)blockIdx.x * nw + wave; item < n_items; item += stride) {
+        const int ch = (int)(item / G);
+        const long long g = item - (long long)ch * G;
+        // chunk boundaries on multiples of 4 q-steps (16 pixels): the fp32 -> double fold happens every 4 steps
+        const int Q4 = (Q + 3) / 4;
+        const int q0 = (int)(((long long)ch * Q4) / nchunk) * 4;
+        int q1 = (int)(((long long)(ch + 1) * Q4) / nchunk) * 4;
+        if (q1 > Q) q1 = Q;
+        const float4* base = ftiles + g * (long long)Q * 64 + lane;
+        double acc[APAD];
+        float run[APAD];
+#pragma unroll
+        for (int a = 0; a < APAD; ++a) { acc[a] = 0.0; run[a] = 0.f; }
+        for (int qb = q0; qb < q1; qb += 4) {
+            float4 L[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int q = (qb + s < q1) ? qb + s : q1 - 1;
+                const v4u_t t = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(&base[(long long)q * 64]));
+                L[s] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (qb + s < q1) {
+                    const float* pp = fprep + ((long long)(qb + s) * 4) * APAD;          // wave-uniform -> s_load
+                    const float lw[4] = {L[s].x, L[s].y, L[s].z, L[s].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int a = 0; a < APAD; ++a) {
+                            const float d = lw[j] - pp[j * APAD + a];
+                            run[a] = __builtin_fmaf(d, d, run[a]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < APAD; ++a) { acc[a] += (double)run[a]; run[a] = 0.f; }
+        }
+        double* dst = part + ((long long)ch * APAD) * c.Fpad + g * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc[a];
+    }
+}
+
+// fam[a][f] = -(sum over chunks of the partial SSDs); per-block maxima as in k_combine.
+__global__ void __launch_bounds__(256)
+k_combine_f32(const double* __restrict__ part, double* __restrict__ fam, unsigned long long* __restrict__ blockmax,
+              StepState* __restrict__ st, LibCfg c, int nchunk, int APAD, int n_agents) {
+    __shared__ unsigned long long wmax[4];
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x, n_agents);
+    unsigned long long key = 0;
+    if (f < c.F) {
+        double ssd = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) ssd += part[((long long)ch * APAD + a) * c.Fpad + f];
+        const double val = -ssd;
+        fam[(long long)a * c.Fpad + f] = val;
+        key = ordered_key(val);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmax[0];
+        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+        blockmax[(long long)a * gridDim.x + blockIdx.x] = m;
+    }
+}
+
+// Every (heading, view) SSD exact (overflow fallback / exact mode of the f32 metric).  grid = (G, ceil(A/4)), block (64,4).
+__global__ void __launch_bounds__(256)
+k_exact_all_f32(const float4* __restrict__ ftiles, const float* __restrict__ raw_patches, double* __restrict__ fam,
+                unsigned long long* __restrict__ groupmax, StepState* __restrict__ st, LibCfg c, int A, int n_agents) {
+    const int lane = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.y * 64 + threadIdx.x, n_agents);
+    const int a = blockIdx.y * 4 + threadIdx.y;
+    if (a >= A) return;
+    const long long g = blockIdx.x;
+    const long long f = g * 64 + lane;
+    const float4* base = ftiles + g * (long long)c.Q * 64 + lane;
+    const float* pa = raw_patches + (long long)a * c.P;
+    double diff = 0.0;
+    for (int q = 0; q < c.Q; ++q) {
+        const float4 L = base[(long long)q * 64];
+        const float lw[4] = {L.x, L.y, L.z, L.w};
+        for (int i = 0; i < 4; ++i) {
+            const int px = q * 4 + i;
+            if (px >= c.P) break;
+            const double d = (double)pa[px] - (double)lw[i];
+            diff += d * d;
+        }
+    }
+    const double val = -diff;
+    unsigned long long key = 0;
+    if (f < c.F) {
+        fam[(long long)a * c.Fpad + f] = val;
+        key = ordered_key(val);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if (lane == 0) groupmax[(long long)a * gridDim.x + g] = key;
+}
+
+// Exact SSD of listed (heading, view) candidates: the reference's sequential double sum (util.pyx:180-182), negated.
+__global__ void __launch_bounds__(64)
+k_resolve_f32(const float4* __restrict__ ftiles, const float* __restrict__ raw_patches, const StepState* __restrict__ st,
+              const unsigned long long* __restrict__ cand, double* __restrict__ cand_exact, LibCfg c) {
+    __shared__ double terms[256];
+    const unsigned long long n_all = st->ncand;
+    if (n_all > (unsigned long long)kCandCap) return;
+    const int n = (int)n_all;
+    const int lane = threadIdx.x;
+    for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
+        const unsigned long long cf = cand[ci];
+        const int a = (int)(cf >> 40);
+        const long long f = (long long)(cf & 0xffffffffffull);
+        const float4* base = ftiles + (f >> 6) * (long long)c.Q * 64 + (f & 63);
+        const float* pa = raw_patches + (long long)a * c.P;
+        double diff = 0.0;
+        for (int qb = 0; qb < c.Q; qb += 64) {
+            const int q = qb + lane;
+            if (q < c.Q) {
+                const float4 L = base[(long long)q * 64];
+                const float lw[4] = {L.x, L.y, L.z, L.w};
+                for (int i = 0; i < 4; ++i) {
+                    const int px = q * 4 + i;
+                    double t = 0.0;
+                    if (px < c.P) { const double d = (double)pa[px] - (double)lw[i]; t = d * d; }
+                    terms[lane * 4 + i] = t;
+                }
+            }
+            __syncthreads();
+            int npx = c.P - qb * 4;
+            npx = npx > 256 ? 256 : npx;
+            for (int i = 0; i < npx; ++i) diff += terms[i];
+            __syncthreads();
+        }
+        if (lane == 0) cand_exact[ci] = -diff;
     }
 }
 

@@ -213,6 +213,49 @@ class FamiliarityEngine(object):
                                             N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, res), "dv_step_batch")
         return [self._result_dict(res[i], None) for i in range(n)]
 
+    # -- ssd_f32 metric --------------------------------------------------------------------------
+    @staticmethod
+    def _f32(a, what):
+        a = np.ascontiguousarray(a)
+        if a.dtype != np.float32:
+            raise ValueError("Buffer dtype mismatch for %s, expected 'float' but got '%s'" % (what, a.dtype))
+        return a
+
+    def set_library_f32(self, views, first_view=0):
+        """views: float32[F,h,w]; scores are sums of squared differences (navsim/util.pyx:171-184)."""
+        views = self._f32(views, "views")
+        if views.ndim != 3:
+            raise ValueError("views must be float32[F,h,w], got shape %r" % (views.shape,))
+        F, h, w = views.shape
+        fp = views.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        self._check(self._lib.dv_set_library_f32(self._ctx, fp, F, h, w, int(first_view)), "dv_set_library_f32")
+        self.n_views, self.shape = F, (h, w)
+
+    def score_f32(self, patch, ssdbuf=None):
+        patch = self._f32(patch, "patch")
+        if tuple(patch.shape) != self.shape:
+            raise ValueError("patch has shape %r, expected %r" % (patch.shape, self.shape))
+        if ssdbuf is None:
+            ssdbuf = np.empty(self.n_views, dtype=np.float64)
+        self._check(self._lib.dv_score_f32(self._ctx, patch.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                           N.f64ptr(ssdbuf)), "dv_score_f32")
+        return ssdbuf
+
+    def step_f32(self, patches, want_scene=False, force_resolve=False):
+        """Least-SSD heading over float32 patches [A,h,w]: dict with angle_ssd, best_idex, best_view, step_ssd."""
+        patches = self._f32(patches, "patches")
+        if patches.ndim != 3 or tuple(patches.shape[1:]) != self.shape:
+            raise ValueError("patches must be float32[A,%d,%d]" % self.shape)
+        r = N.StepResult()
+        scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
+        self._check(self._lib.dv_step_f32(self._ctx, patches.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                          patches.shape[0], N.DV_STEP_FORCE_RESOLVE if force_resolve else 0,
+                                          ctypes.byref(r), N.f64ptr(scene) if want_scene else None), "dv_step_f32")
+        d = self._result_dict(r, scene)
+        return dict(best_idex=d["best_idex"], best_view=d["best_view"], step_ssd=d["step_familiarity"],
+                    angle_ssd=d["angle_familiarity"], angle_view=d["angle_view"], n_candidates=d["n_candidates"],
+                    flags=d["flags"], scene_ssd=scene)
+
     def resolve(self):
         r = N.StepResult()
         self._check(self._lib.dv_resolve(self._ctx, ctypes.byref(r)), "dv_resolve")

@@ -425,3 +425,64 @@ def test_batched_agents_match_per_agent_reference(eng, cw):
     one = eng.step_batch(patches[:1])[0]
     ref = eng.step(patches[0], want_scene=False)
     assert one["best_idex"] == ref["best_idex"] and np.array_equal(one["angle_familiarity"], ref["angle_familiarity"])
+
+
+def _ssd_reference(lib, patches):
+    """ssds() of the reference (navsim/util.pyx:171-184, via the pinned oracle) on the upcast data."""
+    F, A = lib.shape[0], patches.shape[0]
+    out = np.empty((A, F))
+    lib64 = lib.astype(np.float64)
+    for a in range(A):
+        p64 = patches[a].astype(np.float64)
+        for f in range(F):
+            out[a, f] = oracle.ssds(p64, lib64[f])
+    return out
+
+
+@pytest.mark.parametrize("F,h,w,A", [(1, 1, 1, 1), (130, 5, 7, 3), (300, 16, 16, 16), (64, 9, 31, 8), (257, 32, 32, 10)])
+def test_ssd_f32_metric_against_reference_ssds(eng, F, h, w, A):
+    rng = np.random.default_rng(F * 7 + A)
+    lib = rng.uniform(-3, 3, (F, h, w)).astype(np.float32)
+    patches = rng.uniform(-3, 3, (A, h, w)).astype(np.float32)
+    if F > 100:
+        patches[A // 2] = lib[F // 3] + rng.normal(0, 0.01, (h, w)).astype(np.float32)    # a near match
+    want = _ssd_reference(lib, patches)
+    eng.set_library_f32(lib)
+    for exact in (False, True):
+        eng.set_exact(exact)
+        r = eng.step_f32(patches, want_scene=True)
+        best_a = int(np.argmin(want.min(axis=1)))
+        assert r["best_idex"] == best_a and r["best_view"] == int(np.argmin(want[best_a])), (exact, r["flags"])
+        np.testing.assert_allclose(r["angle_ssd"], want.min(axis=1), rtol=2e-6, atol=1e-12)      # north star: 1e-6 relative
+        np.testing.assert_allclose(r["scene_ssd"], want.max(axis=0), rtol=2e-6, atol=1e-12)
+        if exact:
+            assert np.array_equal(r["angle_ssd"], want.min(axis=1))
+        buf = eng.score_f32(patches[0])
+        np.testing.assert_allclose(buf, want[0], rtol=2e-6 if not exact else 0, atol=1e-12 if not exact else 0)
+    eng.set_exact(False)
+    with pytest.raises(ValueError):
+        eng.set_library_f32(lib.astype(np.float64))
+    with pytest.raises((ValueError, navsim_amd.EngineError)):
+        eng.step(np.zeros((2, h, w, 3), dtype=np.uint8))            # uint8 entry point on an f32 library
+
+
+def test_ssd_f32_ties_and_duplicates(eng):
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0, 1, (8, 8)).astype(np.float32)
+    lib = np.repeat(base[None], 600, axis=0)
+    lib[100] += np.float32(0.5)
+    patches = np.repeat(base[None], 9, axis=0)
+    patches[:, 0, 0] += np.float32(0.25)
+    patches[4, 3, 3] -= np.float32(0.125)
+    want = _ssd_reference(lib, patches)
+    eng.set_library_f32(lib)
+    r = eng.step_f32(patches)                       # 9 x 599 exact ties > candidate cap -> exact fallback
+    best_a = int(np.argmin(want.min(axis=1)))
+    assert r["best_idex"] == best_a and r["best_view"] == int(np.argmin(want[best_a]))
+    assert r["flags"] & 4
+    lib2 = rng.uniform(0, 1, (200, 8, 8)).astype(np.float32)
+    lib2[150] = lib2[20]                            # two identical views: the first one wins
+    eng.set_library_f32(lib2)
+    p = np.stack([lib2[20], lib2[150] + np.float32(1e-3)])
+    r = eng.step_f32(p)
+    assert r["best_idex"] == 0 and r["best_view"] == 20 and r["step_ssd"] == 0.0
