@@ -154,7 +154,7 @@ def test_c_abi_exports_every_declared_symbol():
     """The library loads and exports exactly what include/dejavu.h declares (no compute calls here)."""
     from navsim_amd import _native
     header = open(os.path.join(REPO, "include", "dejavu.h")).read()
-    declared = set(re.findall(r"\b(dv_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(dv_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
     lib = _native.load()
     for name in declared:
