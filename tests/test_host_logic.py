@@ -179,3 +179,24 @@ def test_no_cpu_fallback_in_product(monkeypatch):
         if fn.endswith(".py"):
             src += open(os.path.join(pkg, fn)).read()
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_experiment_loop_reports_the_reference_row():
+    """run_experiment / chop_path_to_len (scripts/run_experiment.py:107-124,235-258)."""
+    land = synth.synth_landscape(5, 200, 4)
+    path = np.stack([np.linspace(40, 160, 61), np.full(61, 100.0)], axis=1)      # 2 px apart
+    chopped = navsim_amd.chop_path_to_len(path, 100.0)
+    seg = np.linalg.norm(chopped[1:] - chopped[:-1], axis=1)
+    assert np.sum(seg) <= 100.0 < np.sum(seg) + 4.0 + 1e-9
+    assert abs((chopped[0, 0] - path[0, 0]) - (path[-1, 0] - chopped[-1, 0])) <= 2.0 + 1e-9     # trimmed from both ends
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (8, 8), 2.0, n_test_angles=5,
+                                           familiarity_model=oracle.sads_familiarity())
+    nsf.train_from_path(chopped)
+    nsf.position, nsf.angle = chopped[1], 0.0
+    row = navsim_amd.run_experiment(nsf)
+    assert set(row) == {"path_coverage", "rmsd_error", "completed_frames", "stop_status", "percent_forgiving", "n_captures"}
+    assert row["stop_status"] in (0, 1, -1, -2)
+    assert row["completed_frames"] <= int(3.0 * nsf.training_path_length / nsf.step_size)
+    if row["stop_status"] == 1:
+        assert isinstance(nsf.stopped_with_exception, navsim_amd.ReachedEndOfTrainingPathException)
+        assert row["path_coverage"] > 0.5
