@@ -186,8 +186,15 @@ def main():
     if rank == 0:
         comparisons = float(world) * F * A * args.steps
         kern_ms = kern_ms_total / max(kern_n, 1)
-        algo_bytes = float(F) * h * w * info["n_planes"]      # library bytes one launch must read
+        # Algorithmic bytes per launch, SURVEY.md section 8(d): F*P*s with s = 3 for sads_hsv with chem_weight > 0
+        # (H,S,V all live) and s = 1 for chem_weight = 0 (V only); one launch reads the library once for all headings.
+        s_ref = 3 if cw > 0 else 1
+        algo_bytes = float(F) * h * w * s_ref
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        # What this build actually keeps in HBM and streams per launch: when the library has two
+        # hues and no saturation above 127, one signed plane carries (H,S), i.e. 2 bytes per pixel instead of 3.
+        stored_bytes = float(F) * h * w * info["n_planes"]
+        achieved_stored = stored_bytes / (kern_ms * 1e-3) / 1e9
         workload = ("%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g "
                     "(BASELINE.json configs[1])" % (w, h, F, A, cw))
         traffic = committed_traffic(workload)
@@ -207,7 +214,7 @@ def main():
             "config": {
                 "workload": workload,
                 "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
-                "bytes_per_pixel": info["n_planes"], "parallelism": "library sharded x%d" % world,
+                "bytes_per_pixel_reference": s_ref, "bytes_per_pixel_stored": info["n_planes"], "parallelism": "library sharded x%d" % world,
                 "exchange": "none" if not use_dist else "1 all-gather of per-heading records per step (%s)" % (
                     "RCCL, device-resident" if args.backend == "nccl" else args.backend),
             },
@@ -219,6 +226,8 @@ def main():
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch, " + traffic[1]) if traffic else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kern_ms, "launches_timed": kern_n,
+                "stored_bytes_per_launch": stored_bytes, "achieved_stored": achieved_stored,
+                "frac_stored": achieved_stored / HBM_PEAK_GBPS,
             },
         }
         if world == 1 and args.agent_steps > 0 and not args.force_dist:

@@ -80,13 +80,15 @@ typedef struct dv_lib_info {
     int64_t first_view;         /* global index of local view 0 */
     int32_t h, w;
     int32_t n_planes;           /* bytes stored per pixel on the device */
-    int32_t n_hue_planes;       /* one-hot saturation planes (0 when chem_weight == 0) */
+    int32_t n_hue_planes;       /* saturation planes stored (0 when chem_weight == 0) */
     int32_t generic_hue;        /* 1: more than DV_MAX_HUE_PLANES hues, H/S kept as planes */
     int32_t has_value_plane;    /* 0 when chem_weight == 1 */
     int64_t tile_bytes;         /* bytes the scoring kernel streams per pass */
     double chem_weight;
     double delta;               /* half-width of the candidate window around the best integer-sum score */
     uint8_t hues[DV_MAX_HUE_PLANES];
+    int32_t n_hues;             /* distinct hues with S > 0 in the library (entries of hues[] that are valid) */
+    int32_t signed_saturation;  /* 1: two hues, S <= 127: one plane holds 128 + S(hue0) - S(hue1) */
 } dv_lib_info;
 
 /* ---- lifetime ---------------------------------------------------------- */

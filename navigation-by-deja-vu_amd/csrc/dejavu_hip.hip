@@ -57,6 +57,7 @@ struct dv_ctx {
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
     int waves_per_block = 1;                  // DEJAVU_WPB
     int stagger = 0;                          // DEJAVU_STAGGER (experiment, see k_sad_tiles)
+    int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
     double* d_scene = nullptr;                // [Fpad]
     StepState* d_state = nullptr;
@@ -156,6 +157,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
     env_int("DEJAVU_STAGGER", c->stagger, 0, 64);
+    env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
     *out = c;
     return DV_OK;
@@ -200,7 +202,7 @@ extern "C" int dv_synchronize(dv_ctx* c) {
 
 // ------------------------------------------------------------------ library
 static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t first,
-                         int n_hues, const unsigned char* hues, int generic) {
+                         int n_hues, const unsigned char* hues, int generic, int max_s = 255) {
     free_library(c);
     LibCfg& g = c->cfg;
     g = LibCfg{};
@@ -213,10 +215,12 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     g.whs = 0.5 * cw;
     g.wv = 1 - cw;
     g.generic = (cw > 0.0 && generic) ? 1 : 0;
-    g.nhs = cw > 0.0 ? (g.generic ? 2 : n_hues) : 0;
+    // two hues and no saturation above 127: one signed plane instead of two one-hot planes (plane_byte)
+    g.signed_s = (cw > 0.0 && !g.generic && n_hues == 2 && max_s <= 127 && c->allow_signed) ? 1 : 0;
+    g.nhs = cw > 0.0 ? (g.generic ? 2 : (g.signed_s ? 1 : n_hues)) : 0;
     g.hasv = cw < 1.0 ? 1 : 0;
     g.npl = g.nhs + g.hasv;
-    for (int k = 0; k < kMaxHues; ++k) g.hues[k] = (!g.generic && k < g.nhs) ? hues[k] : 0;
+    for (int k = 0; k < kMaxHues; ++k) g.hues[k] = (!g.generic && cw > 0.0 && k < n_hues) ? hues[k] : 0;
     c->h = h;
     c->w = w;
     // cw == 1 with an all-zero-saturation library stores nothing; keep one (zero) plane so that the
@@ -271,7 +275,7 @@ static int check_lib_args(dv_ctx* c, int64_t F, int h, int w, double cw) {
 
 // Library ingest from a raw uint8[F][h*w][3] buffer already on the device: hue scan, layout choice, re-tile.
 static int ingest_raw(dv_ctx* c, const unsigned char* d_raw, int64_t F, int h, int w, double cw, int64_t first) {
-    unsigned bitmap[8] = {0};
+    unsigned bitmap[9] = {0};
     if (cw > 0.0) {
         unsigned* d_bitmap = nullptr;
         hipError_t e = hipMalloc(&d_bitmap, sizeof bitmap);
@@ -291,7 +295,7 @@ static int ingest_raw(dv_ctx* c, const unsigned char* d_raw, int64_t F, int h, i
         if (bitmap[v >> 5] & (1u << (v & 31))) hues[n_hues++] = (unsigned char)v;
     const int generic = n_hues > kMaxHues;
 
-    int rc = alloc_library(c, F, h, w, cw, first, n_hues, hues, generic);
+    int rc = alloc_library(c, F, h, w, cw, first, n_hues, hues, generic, (int)bitmap[8]);
     if (rc) { free_library(c); return rc; }
     const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.npl * c->cfg.Q * 64;
     hipLaunchKernelGGL(k_retile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_tiles, c->cfg);
@@ -537,7 +541,7 @@ extern "C" int dv_generate_library(dv_ctx* c, uint64_t seed, int64_t F, int h, i
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const unsigned char hues[2] = {0, 127};   // synth.hsv_from_words: H = bit * 127, S > 0 in both
-    rc = alloc_library(c, F, h, w, cw, first, 2, hues, 0);
+    rc = alloc_library(c, F, h, w, cw, first, 2, hues, 0, 127);     // synth: S is 0 or 127
     if (rc) { free_library(c); return rc; }
     const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.npl * c->cfg.Q * 64;
     hipLaunchKernelGGL(k_generate_tiles, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_tiles,
@@ -566,11 +570,14 @@ extern "C" int dv_get_library_info(const dv_ctx* c, dv_lib_info* o) {
     o->n_planes = c->cfg.npl;
     o->n_hue_planes = c->cfg.generic ? 0 : c->cfg.nhs;
     o->generic_hue = c->cfg.generic;
+    o->signed_saturation = c->cfg.signed_s;
     o->has_value_plane = c->cfg.hasv;
     o->tile_bytes = (int64_t)c->tile_bytes;
     o->chem_weight = c->cfg.cw;
     o->delta = c->delta;
     for (int k = 0; k < kMaxHues; ++k) o->hues[k] = c->cfg.hues[k];
+    o->n_hues = 0;
+    if (c->cfg.cw > 0.0 && !c->cfg.generic) o->n_hues = c->cfg.signed_s ? 2 : c->cfg.nhs;
     return DV_OK;
 }
 

@@ -41,6 +41,7 @@ struct LibCfg {
     int nhs;            // one-hot saturation planes (or 2 = H,S when generic)
     int hasv;           // value plane present
     int generic;        // H and S kept as planes (more than kMaxHues hues)
+    int signed_s;       // two hues and every library S <= 127: ONE saturation plane holding 128 + (S of hue0) - (S of hue1)
     unsigned char hues[kMaxHues];
     double cw;          // chem_weight
     double whs;         // 0.5 * cw          (util.pyx:59,68)
@@ -85,10 +86,18 @@ __device__ __forceinline__ void synth_hsv(unsigned long long z, unsigned& H, uns
     S = (unsigned)((z >> 17) & 1ull) * 127u;
 }
 // Byte stored in plane `pl` for a pixel (H,S,V).
+// Signed-saturation plane: with two hues, |S_s,0 - S_f,0| + |S_s,1 - S_f,1| = |x_s - x_f| for x = S_0 - S_1 (at most one of
+// the two is nonzero per pixel), so ONE byte plane 128 + x replaces two whenever |x| <= 127.  Library pixels satisfy that
+// by construction (checked at ingest); a patch pixel with S > 127 is clamped to +-127 and the excess S - 127 goes into
+// the per-heading constant, which is exact because |+-(127 + r) - x_f| = |+-127 - x_f| + r for every |x_f| <= 127.
 __device__ __forceinline__ unsigned plane_byte(const LibCfg& c, int pl, unsigned H, unsigned S, unsigned V) {
     if (c.generic) {
         if (pl < c.nhs) return pl == 0 ? H : S;
         return V;
+    }
+    if (c.signed_s && pl == 0) {
+        const unsigned s = S > 127u ? 127u : S;
+        return H == c.hues[0] ? 128u + s : (H == c.hues[1] ? 128u - s : 128u);
     }
     if (pl < c.nhs) return (H == c.hues[pl]) ? S : 0u;
     return V;
@@ -112,6 +121,12 @@ __device__ __forceinline__ void px_ints(const LibCfg& c, const unsigned* lib, un
         if (c.generic) {
             const int lh = (int)lib[0], ls = (int)lib[1];
             hs = ((int)H == lh) ? abs((int)S - ls) : (int)S + ls;
+        } else if (c.signed_s) {
+            const int x = (int)lib[0] - 128;                  // +S of hue 0, -S of hue 1
+            const int f0 = x > 0 ? x : 0, f1 = x < 0 ? -x : 0;
+            const int s0 = H == c.hues[0] ? (int)S : 0, s1 = H == c.hues[1] ? (int)S : 0;
+            hs = abs(s0 - f0) + abs(s1 - f1);
+            if (H != c.hues[0] && H != c.hues[1]) hs += (int)S;
         } else {
             bool in_set = false;
             for (int k = 0; k < c.nhs; ++k) {
@@ -126,18 +141,22 @@ __device__ __forceinline__ void px_ints(const LibCfg& c, const unsigned* lib, un
 }
 
 // ------------------------------------------------------------------ library construction
-// Marks every hue that occurs with S > 0 in the raw library (uint8[n_px][3]).
+// Marks every hue that occurs with S > 0 in the raw library (uint8[n_px][3]); bitmap[8] = largest S.
 __global__ void k_hue_scan(const unsigned char* __restrict__ raw, long long n_px, unsigned* __restrict__ bitmap) {
-    __shared__ unsigned local[8];
-    if (threadIdx.x < 8) local[threadIdx.x] = 0;
+    __shared__ unsigned local[9];
+    if (threadIdx.x < 9) local[threadIdx.x] = 0;
     __syncthreads();
     const long long stride = (long long)gridDim.x * blockDim.x;
+    unsigned smax = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += stride) {
         const unsigned H = raw[i * 3 + 0], S = raw[i * 3 + 1];
         if (S > 0) atomicOr(&local[H >> 5], 1u << (H & 31));
+        smax = S > smax ? S : smax;
     }
+    atomicMax(&local[8], smax);
     __syncthreads();
     if (threadIdx.x < 8 && local[threadIdx.x]) atomicOr(&bitmap[threadIdx.x], local[threadIdx.x]);
+    if (threadIdx.x == 8) atomicMax(&bitmap[8], local[8]);
 }
 
 // raw uint8[F][P][3] -> tiles.  One thread per 16-byte chunk (g, plane, q, lane).
@@ -249,11 +268,13 @@ __global__ void k_prep(const unsigned char* __restrict__ raw, unsigned* __restri
         int s = 0;
         if (!c.generic && c.cw > 0.0) {
             const unsigned char* p = raw + (long long)a * c.P * 3;
+            const int nk = c.signed_s ? 2 : c.nhs;
             for (int px = threadIdx.x; px < c.P; px += blockDim.x) {
-                const unsigned H = p[px * 3];
+                const unsigned H = p[px * 3], S = p[px * 3 + 1];
                 bool in_set = false;
-                for (int k = 0; k < c.nhs; ++k) in_set |= (H == c.hues[k]);
-                if (!in_set) s += p[px * 3 + 1];
+                for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
+                if (!in_set) s += S;
+                else if (c.signed_s && S > 127u) s += S - 127u;       // excess over the clamped plane byte
             }
         }
         part[threadIdx.x] = s;

@@ -58,6 +58,8 @@ class LibInfo(ctypes.Structure):
         ("chem_weight", ctypes.c_double),
         ("delta", ctypes.c_double),
         ("hues", ctypes.c_uint8 * DV_MAX_HUE_PLANES),
+        ("n_hues", ctypes.c_int32),
+        ("signed_saturation", ctypes.c_int32),
     ]
 
 

@@ -84,7 +84,8 @@ class FamiliarityEngine(object):
         return dict(n_views=info.n_views, first_view=info.first_view, h=info.h, w=info.w,
                     n_planes=info.n_planes, n_hue_planes=info.n_hue_planes, generic_hue=bool(info.generic_hue),
                     has_value_plane=bool(info.has_value_plane), tile_bytes=info.tile_bytes,
-                    chem_weight=info.chem_weight, delta=info.delta, hues=[int(x) for x in info.hues][:info.n_hue_planes])
+                    chem_weight=info.chem_weight, delta=info.delta, hues=[int(x) for x in info.hues][:info.n_hues],
+                    signed_saturation=bool(info.signed_saturation))
 
     def read_planes(self, v0, n):
         info = self.library_info()

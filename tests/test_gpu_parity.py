@@ -32,7 +32,11 @@ def expected_planes(lib, info):
     planes = []
     if info["generic_hue"]:
         planes += [flat[..., 0], flat[..., 1]]
-    else:
+    elif info["signed_saturation"]:
+        h0, h1 = info["hues"]
+        x = np.where(flat[..., 0] == h0, flat[..., 1].astype(int), 0) - np.where(flat[..., 0] == h1, flat[..., 1].astype(int), 0)
+        planes.append((128 + x).astype(np.uint8))
+    elif info["chem_weight"] > 0:
         for hue in info["hues"]:
             planes.append(np.where(flat[..., 0] == hue, flat[..., 1], 0).astype(np.uint8))
     if info["has_value_plane"]:
@@ -46,9 +50,9 @@ def test_layout_round_trip(eng, cw):
     eng.set_library(lib, cw)
     info = eng.library_info()
     assert info["n_views"] == 130 and (info["h"], info["w"]) == (5, 7)
-    assert info["n_planes"] == (0 if cw == 0 else 2) + (0 if cw == 1 else 1)
+    assert info["n_planes"] == (0 if cw == 0 else 1) + (0 if cw == 1 else 1)       # S <= 127, two hues: one signed plane
     if cw > 0:
-        assert info["hues"] == [0, 127] and not info["generic_hue"]
+        assert info["hues"] == [0, 127] and not info["generic_hue"] and info["signed_saturation"]
     assert np.array_equal(eng.read_planes(0, 130), expected_planes(lib, info))
     assert np.array_equal(eng.read_planes(64, 3), expected_planes(lib, info)[64:67])
 
@@ -168,6 +172,9 @@ SHAPES = [
     (120, 9, 9, 8, 0.6, "threehues"),
     (64, 12, 12, 8, 0.5, "foreignhue"),
     (64, 12, 12, 8, 1.0, "zerosat"),
+    (150, 9, 13, 12, 0.35, "signed"),
+    (90, 16, 16, 16, 1.0, "signed"),
+    (70, 8, 8, 5, 0.5, "twohues_big_s"),
 ]
 
 
@@ -187,6 +194,13 @@ def make_inputs(F, h, w, A, kind, seed):
         pat[..., 0] = (pat[..., 0] % 4) * 9
     elif kind == "zerosat":          # library without any saturation
         lib[..., 1] = 0
+    elif kind == "signed":           # two hues, library S <= 127 -> one signed plane; patches exceed it and bring a third hue
+        lib[..., 0] = np.where(lib[..., 0] & 1, 200, 10)
+        lib[..., 1] >>= 1
+        pat[..., 0] = np.choose(pat[..., 0] % 3, [10, 200, 77])
+    elif kind == "twohues_big_s":    # two hues but S up to 255 -> stays two one-hot planes
+        lib[..., 0] = np.where(lib[..., 0] & 1, 200, 10)
+        pat[..., 0] = np.where(pat[..., 0] & 1, 200, 10)
     return lib, pat
 
 
@@ -199,6 +213,10 @@ def test_ragged_shapes_against_oracle(eng, F, h, w, A, cw, kind):
         assert info["generic_hue"]
     if kind == "threehues" and cw > 0:
         assert info["n_hue_planes"] == 3
+    if kind == "signed":
+        assert info["signed_saturation"] and info["n_hue_planes"] == 1
+    if kind == "twohues_big_s":
+        assert not info["signed_saturation"] and info["n_hue_planes"] == 2
     want = oracle.step(lib, pat, cw)
     for exact in (False, True):
         eng.set_exact(exact)
@@ -372,12 +390,13 @@ def test_full_size_properties():
 
 
 def test_large_library_properties():
-    """BASELINE config 2 (128x128 sensor, 500k views, 32 headings; 24.6 GB of tiles) through size-independent properties."""
+    """BASELINE config 2 (128x128 sensor, 500k views, 32 headings; 16.4 GB of tiles) through size-independent properties."""
     F, h, w, A, seed, cw = 500000, 128, 128, 32, 777, 0.25
     eng = navsim_amd.FamiliarityEngine(device=0)
     eng.generate_library(seed, F, h, w, cw)
     info = eng.library_info()
-    assert info["tile_bytes"] >= F * h * w * 3
+    assert info["n_planes"] == 2 and info["signed_saturation"]          # synth: two hues, S in {0,127}
+    assert info["tile_bytes"] >= F * h * w * info["n_planes"]
     patches = synth.synth_patches(seed, A, h, w)
     targets = {5: 499999, 17: 250001, 30: 3}                  # heading -> planted view (first, middle, last groups)
     for a, f in targets.items():
