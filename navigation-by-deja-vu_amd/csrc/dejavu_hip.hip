@@ -1,9 +1,10 @@
 // dejavu_hip.hip -- host side of libdejavu_hip.so: the C ABI of include/dejavu.h.
 //
-// One context = one GPU = one stream.  All device buffers are allocated when the library
-// is set (nothing is allocated inside a step), results come back through one pinned-host
-// record, and a step is five launches on one stream:
-//   memset(step state) -> k_sad_tiles (the HBM stream) -> k_finish -> k_resolve -> k_decide.
+// One context = one GPU = one stream.  All device buffers are allocated when the library is set (nothing is
+// allocated inside a step), results come back through one pinned, mapped host record that the host polls, and a
+// step is three launches on one stream:
+//   k_sad_tiles (the HBM stream, integer partial sums) -> k_combine (sums -> scores) -> k_tail (reductions + decision)
+// plus, only when near-ties need exact re-scoring, k_resolve -> k_decide.
 #include "dejavu_kernels.h"
 #include "../../include/dejavu.h"
 

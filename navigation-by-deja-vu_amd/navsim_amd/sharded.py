@@ -20,6 +20,9 @@ candidate in total, they re-score their candidates with the exact sequential-dou
 import numpy as np
 
 
+CANDIDATE_CAP = 4096        # kCandCap of csrc/dejavu_kernels.h
+
+
 def shard_bounds(n_views, world_size, rank):
     """Contiguous block of views owned by `rank` (np.array_split convention: first ranks get the extras)."""
     base, extra = divmod(int(n_views), int(world_size))
@@ -194,7 +197,13 @@ class DeviceExchange(object):
         again, ranks = needs_resolve(records, self.delta)
         if again:
             if self.rank in ranks and records[self.rank, 2] == 0.0:
-                self.engine.resolve_enqueue()
+                if records[self.rank, 1] > CANDIDATE_CAP:
+                    # more local near-ties than the candidate list holds: score this shard exactly instead
+                    self.engine.set_exact(True)
+                    self.engine.step_enqueue(want_scene=False)
+                    self.engine.set_exact(False)
+                else:
+                    self.engine.resolve_enqueue()
             records = self._gather()
         return merge_records(records, self.delta, self.A)
 
