@@ -57,7 +57,6 @@ struct dv_ctx {
     int target_items = 0;                     // 0 = as many items as waves are resident (DEJAVU_TARGET_ITEMS overrides)
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
     int waves_per_block = 1;                  // DEJAVU_WPB
-    int stagger = 0;                          // DEJAVU_STAGGER (experiment, see k_sad_tiles)
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
     double* d_scene = nullptr;                // [Fpad]
@@ -157,7 +156,6 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
-    env_int("DEJAVU_STAGGER", c->stagger, 0, 64);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
     *out = c;
@@ -683,7 +681,7 @@ static void launch_tiles(dv_ctx* c) {
     // more than 32 headings: two passes of the 32-wide kernel (its 5 waves per SIMD beat one 64-wide pass at 2)
     for (int a_off = 0; a_off < ATOT; a_off += AP)
         hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part,
-                           c->cfg, c->nchunk, a_off, c->stagger);
+                           c->cfg, c->nchunk, a_off);
 }
 
 template <int NHS, int HASV>

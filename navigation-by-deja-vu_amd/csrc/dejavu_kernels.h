@@ -312,14 +312,9 @@ __device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
 template <int NHS, int HASV, int APAD, int ATOT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
 k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
-            int nchunk, int a_off_arg, int stagger) {
+            int nchunk, int a_off_arg) {
     constexpr int apad_total = ATOT;
     const int a_off = (ATOT == APAD) ? 0 : a_off_arg;
-    // Optional start stagger (experiment): every other "layer" of 256 workgroups starts `stagger` x ~0.85 us late so
-    // that the waves sharing a SIMD are not all in their load phase (or all in their VALU phase) at the same time.
-    if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     constexpr int NPL = NHS + HASV;
     constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
     // Register ring depth: chunk q+PF is in flight while q is scored.  Few planes / few headings leave VGPRs for a
