@@ -133,6 +133,9 @@ int dv_sense(dv_ctx *ctx, const double *x, const double *y, const double *angle,
 /* The A heading patches of one position straight into the resident patches (then dv_step_enqueue).  No host
  * synchronisation: a footprint past the end of the landscape is reported by the following dv_step_wait (DV_ERR_INDEX). */
 int dv_sense_patches(dv_ctx *ctx, double x, double y, const double *angles, int n_headings);
+/* One agent step's device work in one call: dv_sense_patches + dv_step_enqueue + dv_step_wait. */
+int dv_sense_step(dv_ctx *ctx, double x, double y, const double *angles, int n_headings, uint32_t flags,
+                  dv_step_result *result, double *scene_fam);
 /* train_from_path (:118-140) on the device: sense n poses and ingest them as the library; out_views
  * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */
 int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,

@@ -504,14 +504,42 @@ extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* ang
     if (c->sensor.sw != c->w || c->sensor.sh != c->h)
         return fail(c, DV_ERR_STATE, "sensor is %dx%d but the library holds %dx%d views", c->sensor.sw, c->sensor.sh, c->w, c->h);
     HIP_TRY(c, hipSetDevice(c->device));
-    double xs[kMaxHeadings], ys[kMaxHeadings];
-    for (int a = 0; a < A; ++a) { xs[a] = x; ys[a] = y; }
-    rc = enqueue_sense(c, xs, ys, angles, A, c->d_raw_patches);
-    if (rc) return rc;
-    rc = prep_patches(c, A);
-    if (rc) return rc;
+    // poses (cos/sin from the host's libm), then ONE kernel that senses and lays the patches out for the scoring kernel
+    if ((size_t)A > c->poses_cap) {
+        if (c->d_poses) (void)hipFree(c->d_poses);
+        c->d_poses = nullptr;
+        c->poses_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_poses, (size_t)kMaxHeadings * sizeof(Pose)));
+        c->poses_cap = kMaxHeadings;
+    }
+    c->h_poses.resize((size_t)A);
+    for (int a = 0; a < A; ++a) {
+        const double rot = -(0.5 * M_PI - angles[a]);
+        c->h_poses[(size_t)a] = Pose{x, y, std::cos(rot), std::sin(rot)};
+    }
+    c->A = A; c->n_agents = 1; c->A_agent = A;
+    c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
+    HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_hsconst, 0, kMaxHeadings * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), (size_t)A * sizeof(Pose), hipMemcpyHostToDevice, c->stream));
+    // (prep entries of the padded headings A..APAD-1 are left as they are: their sums are never read)
+    const long long total = (long long)A * c->cfg.Q * 4;
+    hipLaunchKernelGGL(k_sense_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, c->d_poses, A,
+                       c->sensor, c->d_lut, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, c->APAD, c->d_err);
+    HIP_TRY(c, hipGetLastError());
     c->patches_sensed = true;      // no host synchronisation here: the step's result record carries the error flag
     return DV_OK;
+}
+
+// One full agent step's device work in one call: sense the heading patches at (x, y), score them, decide.
+extern "C" int dv_sense_step(dv_ctx* c, double x, double y, const double* angles, int A, uint32_t flags,
+                             dv_step_result* result, double* scene_fam) {
+    int rc = dv_sense_patches(c, x, y, angles, A);
+    if (rc) return rc;
+    if (!result) return fail(c, DV_ERR_INVALID, "result is NULL");
+    rc = enqueue_step(c, flags, scene_fam != nullptr);
+    if (rc) return rc;
+    return wait_step(c, result, scene_fam);
 }
 
 extern "C" int dv_set_library_from_poses(dv_ctx* c, const double* x, const double* y, const double* angle, int64_t n,

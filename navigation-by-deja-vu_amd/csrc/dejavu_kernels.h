@@ -1099,6 +1099,91 @@ __global__ void k_sense(const unsigned char* __restrict__ land, const Pose* __re
     o[0] = (unsigned char)oh; o[1] = (unsigned char)os; o[2] = (unsigned char)ov;
 }
 
+// Sensing fused with the per-step patch preparation (dv_sense_patches): one thread per (heading, group of 4 sensor
+// pixels) senses its 4 pixels, stores them raw (uint8[A][P][3], needed by the exact kernels) and writes the prep
+// dword of every stored plane; the per-heading constant is folded per wave and added with one integer atomic.
+// hsconst[0..A) must be zero on entry (hipMemsetAsync).
+__device__ __forceinline__ bool sense_pixel(const unsigned char* __restrict__ land, const SensorCfg& g, const Pose& p,
+                                            const unsigned char* __restrict__ lut, int bi, int bj,
+                                            unsigned& oh, unsigned& os, unsigned& ov) {
+    const int nblk = g.pw * g.ph;
+    oh = os = ov = 0;
+    if (nblk == 1) {
+        unsigned H, S, V;
+        if (!sense_fetch(land, g, p, bi, bj, H, S, V)) return false;
+        oh = S > 0 ? H : 0u; os = S; ov = V;
+    } else {
+        long long vsum = 0, best_sum = 0;
+        unsigned best_hue = 0;
+        for (int k = 0; k < nblk; ++k) {
+            unsigned Hk, Sk, Vk;
+            if (!sense_fetch(land, g, p, bi * g.ph + k / g.pw, bj * g.pw + k % g.pw, Hk, Sk, Vk)) return false;
+            vsum += Vk;
+            long long sum = 0;
+            for (int m = 0; m < nblk; ++m) {
+                unsigned Hm, Sm, Vm;
+                if (!sense_fetch(land, g, p, bi * g.ph + m / g.pw, bj * g.pw + m % g.pw, Hm, Sm, Vm)) return false;
+                if (Hm == Hk) sum += Sm;
+            }
+            if (sum > best_sum || (sum == best_sum && sum > 0 && Hk < best_hue)) { best_sum = sum; best_hue = Hk; }
+        }
+        oh = best_sum > 0 ? best_hue : 0u;
+        os = (unsigned)(((best_sum / g.ph) * g.pw) & 0xFF);
+        ov = (unsigned)(long long)round((double)vsum / (double)nblk);
+    }
+    oh = lut[oh]; os = lut[256 + os]; ov = lut[512 + ov];
+    const int mid = g.sw / 2;
+    if (bj >= mid - g.mask_n && bj < mid + g.mask_n) { oh = 0; os = 0; ov = 0; }
+    return true;
+}
+
+__global__ void __launch_bounds__(256)
+k_sense_prep(const unsigned char* __restrict__ land, const Pose* __restrict__ poses, int A, SensorCfg g,
+             const unsigned char* __restrict__ lut, unsigned char* __restrict__ raw, unsigned* __restrict__ prep,
+             int* __restrict__ hsconst, LibCfg c, int APAD, int* __restrict__ err) {
+    const int ngroups = c.Q * 4;                           // groups of 4 pixels, incl. the zero padding
+    const long long total = (long long)A * ngroups;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int konst = 0;
+    int a = 0;
+    if (t < total) {
+        a = (int)(t / ngroups);                            // heading-major: a wave never straddles two headings
+        const int grp = (int)(t % ngroups);                //   when ngroups is a multiple of 64; handled below otherwise
+        const Pose p = poses[a];
+        unsigned w[kMaxHues + 1];
+        for (int pl = 0; pl < c.npl; ++pl) w[pl] = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int px = grp * 4 + i;
+            if (px >= c.P) break;
+            unsigned H, S, V;
+            if (!sense_pixel(land, g, p, lut, px / g.sw, px % g.sw, H, S, V)) { atomicOr(err, 1); H = S = V = 0; }
+            unsigned char* o = raw + ((long long)a * c.P + px) * 3;
+            o[0] = (unsigned char)H; o[1] = (unsigned char)S; o[2] = (unsigned char)V;
+            for (int pl = 0; pl < c.npl; ++pl) w[pl] |= plane_byte(c, pl, H, S, V) << (8 * i);
+            if (!c.generic && c.cw > 0.0) {
+                const int nk = c.signed_s ? 2 : c.nhs;
+                bool in_set = false;
+                for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
+                if (!in_set) konst += (int)S;
+                else if (c.signed_s && S > 127u) konst += (int)S - 127;
+            }
+        }
+        const int q = grp >> 2, j = grp & 3;
+        for (int pl = 0; pl < c.npl; ++pl) prep[(((long long)pl * c.Q + q) * 4 + j) * APAD + a] = w[pl];
+    }
+    // per-heading constant: lanes of a wave may belong to two headings when ngroups is not a multiple of 64
+    const int a_first = __shfl(a, 0);
+    const bool uniform = __all(t >= total || a == a_first);
+    if (uniform) {
+        int sum = (t < total) ? konst : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if ((threadIdx.x & 63) == 0 && sum != 0) atomicAdd(&hsconst[a_first], sum);
+    } else if (t < total && konst != 0) {
+        atomicAdd(&hsconst[a], konst);
+    }
+}
+
 // Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.
 __global__ void k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
     const long long stride = (long long)gridDim.x * blockDim.x;

@@ -347,9 +347,8 @@ class NavBySceneFamiliarity(object):
             if engine is self._engine:
                 # patches are sensed on the GPU, straight into the scoring kernel's operand layout
                 self._check_bounds(position)
-                engine.sense_patches(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi))
-                engine.step_enqueue(want_scene=self.track_scene_familiarity)
-                res = engine.step_wait(want_scene=self.track_scene_familiarity)
+                res = engine.sense_step(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi),
+                                        want_scene=self.track_scene_familiarity)
             else:
                 patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)
                 for a_idex, angle_offset in enumerate(self.angle_offsets):

@@ -139,6 +139,16 @@ class FamiliarityEngine(object):
         self._check_sense(self._lib.dv_sense_patches(self._ctx, float(x), float(y), N.f64ptr(angles), len(angles)),
                           "dv_sense_patches")
 
+    def sense_step(self, x, y, angles, want_scene=True, force_resolve=False):
+        """Sense the heading patches at (x, y) and score them: one call for an agent step's device work."""
+        angles = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+        r = N.StepResult()
+        scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
+        self._check_sense(self._lib.dv_sense_step(self._ctx, float(x), float(y), N.f64ptr(angles), len(angles),
+                                                  N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, ctypes.byref(r),
+                                                  N.f64ptr(scene) if want_scene else None), "dv_sense_step")
+        return self._result_dict(r, scene)
+
     def set_library_from_poses(self, x, y, angle, chem_weight=0.0, first_view=0, want_views=True):
         """train_from_path on the device: sense the poses and ingest them as the library; returns familiar_scenes."""
         x, y, angle = self._pose_arrays(x, y, angle)
