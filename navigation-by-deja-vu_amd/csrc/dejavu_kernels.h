@@ -318,8 +318,8 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
     constexpr int NPL = NHS + HASV;
     constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
     // Register ring depth: chunk q+PF is in flight while q is scored.  Few planes / few headings leave VGPRs for a
-    // deeper ring (more bytes in flight per wave); 3 planes x 16 headings is best at PF = 1 (measured).
-    constexpr int PF = (APAD <= 16) ? (NPL == 1 ? 3 : (NPL == 2 ? 2 : 1)) : 1;
+    // deeper ring (more bytes in flight per wave); with 2 or 3 planes PF = 1 measured best (A/B, tools/ab_lib.sh).
+    constexpr int PF = (APAD <= 16 && NPL == 1) ? 3 : 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
