@@ -57,6 +57,7 @@ struct dv_ctx {
     int target_items = 0;                     // 0 = as many items as waves are resident (DEJAVU_TARGET_ITEMS overrides)
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
     int waves_per_block = 1;                  // DEJAVU_WPB
+    int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
     double* d_scene = nullptr;                // [Fpad]
@@ -157,6 +158,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
+    env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
     *out = c;
     return DV_OK;
@@ -199,6 +201,14 @@ extern "C" int dv_synchronize(dv_ctx* c) {
     return DV_OK;
 }
 
+// Distance between view groups in the tile array, in 16-byte units.  A group is kb = planes*Q KiB; consecutive
+// groups are streamed at the same time by different waves at the same offset, so a power-of-two distance would put
+// them on the same HBM channels.  DEJAVU_GPAD = KiB of padding per group (default -1: make the KiB count odd).
+static long long group_stride(const dv_ctx* c, long long kb) {
+    const long long pad = c->group_pad_kb >= 0 ? c->group_pad_kb : ((kb & 1) ? 0 : 1);
+    return (kb + pad) * 64;
+}
+
 // ------------------------------------------------------------------ library
 static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t first,
                          int n_hues, const unsigned char* hues, int generic, int max_s = 255) {
@@ -225,7 +235,8 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     // cw == 1 with an all-zero-saturation library stores nothing; keep one (zero) plane so that the
     // kernels have something to stream (it contributes |0 - 0| = 0).
     if (g.npl == 0) { g.hasv = 1; g.npl = 1; }
-    c->tile_bytes = (size_t)(g.Fpad / 64) * g.npl * g.Q * 64 * sizeof(uint4);
+    g.gstride = group_stride(c, (long long)g.npl * g.Q);
+    c->tile_bytes = (size_t)(g.Fpad / 64) * g.gstride * sizeof(uint4);
     const double n = (double)g.P;
     c->delta = 4.0 * (n + 8.0) * std::ldexp(1.0, -53) * n;
 
@@ -345,7 +356,8 @@ extern "C" int dv_set_library_f32(dv_ctx* c, const float* views, int64_t F, int 
     g.Q = (g.P + 3) / 4;                                              // 4 float pixels per 16-byte chunk
     g.npl = 1; g.nhs = 0; g.hasv = 1;
     (void)hipFree(c->d_tiles); c->d_tiles = nullptr;
-    c->tile_bytes = (size_t)(g.Fpad / 64) * g.Q * 64 * sizeof(float4);
+    g.gstride = group_stride(c, (long long)g.Q);
+    c->tile_bytes = (size_t)(g.Fpad / 64) * g.gstride * sizeof(float4);
     c->metric = 1;
     {
         const long long G = g.Fpad / 64;

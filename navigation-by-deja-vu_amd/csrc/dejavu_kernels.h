@@ -35,6 +35,8 @@ struct LibCfg {
     long long F;        // local views
     long long Fpad;     // padded to a multiple of 64
     long long first;    // global index of local view 0
+    long long gstride;  // 16-byte units between consecutive view groups in the tile array (>= npl*Q*64: padded so that
+                        // concurrently streamed groups do not sit a power of two apart)
     int P;              // h*w
     int Q;              // ceil(P/16)
     int npl;            // planes stored per pixel
@@ -181,7 +183,7 @@ __global__ void k_retile(const unsigned char* __restrict__ raw, uint4* __restric
             }
         }
     }
-    tiles[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    tiles[g * c.gstride + ((long long)pl * c.Q + q) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Synthetic library straight into tiles: view f, pixel p <- splitmix64((first+f)*P + p + seed*GOLDEN).
@@ -208,7 +210,7 @@ __global__ void k_generate_tiles(uint4* __restrict__ tiles, LibCfg c, unsigned l
             }
         }
     }
-    tiles[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    tiles[g * c.gstride + ((long long)pl * c.Q + q) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Raw synthetic patches uint8[A][P][3] (stream seed+1, like synth.synth_patches).
@@ -233,7 +235,7 @@ __global__ void k_read_planes(const uint4* __restrict__ tiles, unsigned char* __
     long long r = t / c.P;
     const int pl = (int)(r % c.npl);
     const long long f = v0 + r / c.npl;
-    const long long idx = (((f >> 6) * c.npl + pl) * c.Q + (px >> 4)) * 64 + (f & 63);
+    const long long idx = (f >> 6) * c.gstride + ((long long)pl * c.Q + (px >> 4)) * 64 + (f & 63);
     const unsigned char* b = reinterpret_cast<const unsigned char*>(tiles + idx);
     out[t] = b[px & 15];
 }
@@ -332,7 +334,7 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
         const int ch = (int)(item / G);
         const long long g = item - (long long)ch * G;
         const int q0 = (int)(((long long)ch * Q) / nchunk), q1 = (int)(((long long)(ch + 1) * Q) / nchunk);
-        const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
+        const uint4* base = tiles + g * c.gstride + lane;
 
         unsigned acc_hs[NHS > 0 ? APAD : 1];
         unsigned acc_v[HASV ? APAD : 1];
@@ -407,7 +409,7 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
     const int ch = (int)(item / G);
     const long long g = item - (long long)ch * G;
     const int q0 = (int)(((long long)ch * Q) / nchunk), q1 = (int)(((long long)(ch + 1) * Q) / nchunk);
-    const uint4* base = tiles + g * (long long)NPL * Q * 64 + lane;
+    const uint4* base = tiles + g * c.gstride + lane;
 
     unsigned acc_hs[HAS_HS ? APAD : 1];
     unsigned acc_v[HASV ? APAD : 1];
@@ -521,7 +523,7 @@ k_exact_all(const uint4* __restrict__ tiles, const unsigned char* __restrict__ r
     if (a >= A) return;
     const long long g = blockIdx.x;
     const long long f = g * 64 + lane;
-    const uint4* base = tiles + g * (long long)c.npl * c.Q * 64 + lane;
+    const uint4* base = tiles + g * c.gstride + lane;
     const unsigned char* pa = raw_patches + (long long)a * c.P * 3;
     double diff = 0.0;
     for (int q = 0; q < c.Q; ++q) {
@@ -763,7 +765,7 @@ k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw
         const unsigned long long cf = cand[ci];
         const int a = (int)(cf >> 40);
         const long long f = (long long)(cf & 0xffffffffffull);
-        const uint4* base = tiles + (f >> 6) * (long long)c.npl * c.Q * 64 + (f & 63);
+        const uint4* base = tiles + (f >> 6) * c.gstride + (f & 63);
         const unsigned char* pa = raw_patches + (long long)a * c.P * 3;
         double diff = 0.0;
         for (int qb = 0; qb < c.Q; qb += 64) {
@@ -847,7 +849,7 @@ __global__ void k_retile_f32(const float* __restrict__ raw, float4* __restrict__
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (f < c.F)
         for (int i = 0; i < 4; ++i) { const int px = q * 4 + i; if (px < c.P) v[i] = raw[f * (long long)c.P + px]; }
-    ftiles[t] = make_float4(v[0], v[1], v[2], v[3]);
+    ftiles[(r / c.Q) * c.gstride + (long long)q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 __global__ void k_prep_f32(const float* __restrict__ raw, float* __restrict__ fprep, LibCfg c, int A, int APAD) {
@@ -877,7 +879,7 @@ k_ssd_tiles(const float4* __restrict__ ftiles, const float* __restrict__ fprep, 
         const int q0 = (int)(((long long)ch * Q4) / nchunk) * 4;
         int q1 = (int)(((long long)(ch + 1) * Q4) / nchunk) * 4;
         if (q1 > Q) q1 = Q;
-        const float4* base = ftiles + g * (long long)Q * 64 + lane;
+        const float4* base = ftiles + g * c.gstride + lane;
         double acc[APAD];
         float run[APAD];
 #pragma unroll
@@ -954,7 +956,7 @@ k_exact_all_f32(const float4* __restrict__ ftiles, const float* __restrict__ raw
     if (a >= A) return;
     const long long g = blockIdx.x;
     const long long f = g * 64 + lane;
-    const float4* base = ftiles + g * (long long)c.Q * 64 + lane;
+    const float4* base = ftiles + g * c.gstride + lane;
     const float* pa = raw_patches + (long long)a * c.P;
     double diff = 0.0;
     for (int q = 0; q < c.Q; ++q) {
@@ -994,7 +996,7 @@ k_resolve_f32(const float4* __restrict__ ftiles, const float* __restrict__ raw_p
         const unsigned long long cf = cand[ci];
         const int a = (int)(cf >> 40);
         const long long f = (long long)(cf & 0xffffffffffull);
-        const float4* base = ftiles + (f >> 6) * (long long)c.Q * 64 + (f & 63);
+        const float4* base = ftiles + (f >> 6) * c.gstride + (f & 63);
         const float* pa = raw_patches + (long long)a * c.P;
         double diff = 0.0;
         for (int qb = 0; qb < c.Q; qb += 64) {
