@@ -792,7 +792,16 @@ k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw
             __syncthreads();
             int npx = c.P - qb * 16;
             npx = npx > 1024 ? 1024 : npx;
-            for (int i = 0; i < npx; ++i) diff += terms[i];
+            // same sequential order as the reference; the LDS reads are batched so that only the adds are serial
+            int i = 0;
+            for (; i + 16 <= npx; i += 16) {
+                double t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] = terms[i + k];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) diff += t[k];
+            }
+            for (; i < npx; ++i) diff += terms[i];
             __syncthreads();
         }
         if (lane == 0) cand_exact[ci] = (double)c.P - diff;

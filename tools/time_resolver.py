@@ -1,0 +1,20 @@
+import sys, time
+sys.path.insert(0, "/root/repo/navigation-by-deja-vu_amd"); sys.path.insert(0, "/root/repo")
+import numpy as np, navsim_amd
+from navsim_amd import synth
+from oracle import oracle
+eng = navsim_amd.FamiliarityEngine(0)
+F, h, w, A = 50000, 64, 64, 16
+eng.generate_library(5, F, h, w, 0.25)
+p = synth.synth_patches(5, A, h, w)
+eng.upload_patches(p)
+for force in (False, True):
+    for _ in range(5):
+        eng.step_enqueue(force_resolve=force); r = eng.step_wait()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        eng.step_enqueue(force_resolve=force); r = eng.step_wait()
+    print("force_resolve", force, "step %.1f us" % ((time.perf_counter() - t0) / 100 * 1e6), "flags", r["flags"], "cands", r["n_candidates"])
+sub = synth.synth_views(5, 1, h, w, first_view=r["best_view"])
+assert r["step_familiarity"] == oracle.sads_hsv(sub, p[r["best_idex"]], 0.25)[0]
+print("exact value of the winner matches the oracle")
