@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, "/root/repo/navigation-by-deja-vu_amd"); sys.path.insert(0, "/root/repo")
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "navigation-by-deja-vu_amd"))
 import numpy as np, navsim_amd
 from navsim_amd import synth
 from oracle import oracle
