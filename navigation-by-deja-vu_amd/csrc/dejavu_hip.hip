@@ -825,7 +825,7 @@ static int launch_scoring(dv_ctx* c) {
         }
         HIP_TRY(c, hipGetLastError());
         if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
-        n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
+        n_partial = (int)((g.Fpad + 1023) / 1024);
         hipLaunchKernelGGL(k_combine, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
                            c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum, c->n_agents);
         HIP_TRY(c, hipGetLastError());

@@ -468,31 +468,48 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
 
 // Sums the per-chunk integer sums and converts them to the familiarity double:
 //   fam[a][f] = P - (0.5*cw*S_hs + (1-cw)*S_v) / 255        (one rounding per operation)
-// grid = (Fpad/256, A); also leaves each block's maximum in blockmax[a][blockIdx.x] (no atomics:
+// grid = (ceil(Fpad/1024), A), four views per thread; also leaves each block's maximum in blockmax[a][blockIdx.x] (no atomics:
 // thousands of atomics on one 128-byte line serialise at the memory side, ~10 ns each).
 __global__ void __launch_bounds__(256)
 k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, double* __restrict__ fam,
           unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD,
           int has_hs_sum, int has_v_sum, int n_agents) {
     __shared__ unsigned long long wmax[4];
-    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // four consecutive views per thread: one 16-byte load per (chunk, sum) row
+    const long long f0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int a = blockIdx.y;
     const int nsum = has_hs_sum + has_v_sum;
     if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x, n_agents);
     unsigned long long key = 0;
-    if (f < c.F) {
-        long long shs = hsconst[a];
-        long long sv = 0;
+    if (f0 < c.Fpad) {
+        const long long base = hsconst[a];
+        long long shs[4] = {base, base, base, base};
+        long long sv[4] = {0, 0, 0, 0};
         for (int ch = 0; ch < nchunk; ++ch) {
-            const unsigned* p = part + ((long long)ch * nsum * APAD) * c.Fpad + f;
-            if (has_hs_sum) shs += (long long)p[(long long)a * c.Fpad];
-            if (has_v_sum) sv += (long long)p[(long long)((has_hs_sum ? APAD : 0) + a) * c.Fpad];
+            const unsigned* p = part + ((long long)ch * nsum * APAD) * c.Fpad + f0;
+            if (has_hs_sum) {
+                const uint4 q = *reinterpret_cast<const uint4*>(p + (long long)a * c.Fpad);
+                shs[0] += q.x; shs[1] += q.y; shs[2] += q.z; shs[3] += q.w;
+            }
+            if (has_v_sum) {
+                const uint4 q = *reinterpret_cast<const uint4*>(p + (long long)((has_hs_sum ? APAD : 0) + a) * c.Fpad);
+                sv[0] += q.x; sv[1] += q.y; sv[2] += q.z; sv[3] += q.w;
+            }
         }
-        double acc = c.whs * (double)shs;
-        if (has_v_sum) acc = acc + c.wv * (double)sv;
-        const double val = (double)c.P - acc / 255.;
-        fam[(long long)a * c.Fpad + f] = val;
-        key = ordered_key(val);
+        double val[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double acc = c.whs * (double)shs[i];
+            if (has_v_sum) acc = acc + c.wv * (double)sv[i];
+            val[i] = (double)c.P - acc / 255.;
+            if (f0 + i < c.F) {
+                const unsigned long long k = ordered_key(val[i]);
+                key = k > key ? k : key;
+            }
+        }
+        double2* o = reinterpret_cast<double2*>(fam + (long long)a * c.Fpad + f0);
+        o[0] = make_double2(val[0], val[1]);
+        o[1] = make_double2(val[2], val[3]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
