@@ -56,7 +56,10 @@ struct dv_ctx {
     int nchunk_cap = 1;                       // chunks the partial-sum buffer has room for
     int target_items = 0;                     // 0 = as many items as waves are resident (DEJAVU_TARGET_ITEMS overrides)
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
-    int waves_per_block = 1;                  // DEJAVU_WPB
+    int waves_per_block = 0;                  // DEJAVU_WPB: 1 or 4 waves per k_sad_tiles workgroup (0: timed once per library)
+    int force_nw = 0;                         // set while tune_workgroup_shape() times a candidate
+    int tuned_nw[4] = {0, 0, 0, 0};           // chosen workgroup shape per APAD class (8, 16, 32, 64); 0 = not timed yet
+    float tuned_us[4][2] = {};                // what the timing saw (1-wave, 4-wave), for dv_profile / debugging
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -124,6 +127,7 @@ static void free_library(dv_ctx* c) {
     if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; c->d_result = nullptr; }
     if (c->h_scene) { (void)hipHostFree(c->h_scene); c->h_scene = nullptr; }
     c->have_lib = false;
+    for (int i = 0; i < 4; ++i) c->tuned_nw[i] = 0;
     c->A = 0;
     c->step_pending = false;
 }
@@ -156,7 +160,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     };
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
-    env_int("DEJAVU_WPB", c->waves_per_block, 1, 4);
+    env_int("DEJAVU_WPB", c->waves_per_block, 0, 4);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -698,30 +702,49 @@ static int resident_waves_per_cu(const void* kernel) {
 // resident at once, walking the items with a grid stride.  The pixel range is cut into as many chunks as make the item
 // count just fill the resident waves (measured optimum: 7038 items on 7168 wave slots; one item more than fits costs
 // a second round, fewer items leave SIMDs short of waves to hide latency).
-static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block) {
-    const int wpb = c->waves_per_block;
+static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block, int wpb = 1) {
     const int wpc = c->waves_per_cu ? c->waves_per_cu : kernel_wpc;
     const long long G = c->cfg.Fpad / 64;
-    const long long slots = 256ll * wpc;
+    const long long slots = 256ll * (wpc / wpb > 0 ? wpc / wpb : 1);      // workgroups resident at once
     long long n = c->target_items ? (c->target_items + G - 1) / G : slots / G;
     if (n < 1) n = 1;
     if (n > c->nchunk_cap) n = c->nchunk_cap;
     c->nchunk = (int)n;
     const long long n_items = G * n;
-    const long long waves = slots < n_items ? slots : n_items;
     block = dim3(64 * wpb);
-    return dim3((unsigned)((waves + wpb - 1) / wpb));
+    return dim3((unsigned)(slots < n_items ? slots : n_items));
+}
+
+template <int NHS, int HASV, int AP, int ATOT, int NW>
+static void launch_tiles_nw(dv_ctx* c) {
+    static const int wpc = resident_waves_per_cu((const void*)k_sad_tiles<NHS, HASV, AP, ATOT, NW>);
+    dim3 block;
+    const dim3 grid = scoring_grid(c, wpc, block, NW);
+    constexpr int nsum = (NHS > 0 ? 1 : 0) + HASV;
+    const size_t lds = NW > 1 ? (size_t)nsum * AP * 64 * sizeof(unsigned) : 0;
+    // more than 32 headings: two passes of the 32-wide kernel (its 5 waves per SIMD beat one 64-wide pass at 2)
+    for (int a_off = 0; a_off < ATOT; a_off += AP)
+        hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT, NW>), grid, block, lds, c->stream, c->d_tiles, c->d_prep,
+                           c->d_part, c->cfg, c->nchunk, a_off);
+}
+
+// Waves per workgroup of k_sad_tiles.  Four waves sharing an item add their sums in LDS, so a quarter of the partial
+// sums cross HBM (written here, read again by k_combine), and they read the same patch dwords together; single-wave
+// workgroups cut the pixel range finer and balance the CUs better.  Which wins depends on the library size and the
+// heading count (tools/sweep_grid.sh: -18 % to +37 %), so it is timed once per library and heading class
+// (tune_workgroup_shape); the integer sums are identical either way.
+static int apad_class(int APAD) { return APAD == 8 ? 0 : (APAD == 16 ? 1 : (APAD == 32 ? 2 : 3)); }
+static int waves_per_block_now(dv_ctx* c) {
+    if (c->force_nw) return c->force_nw;
+    if (c->waves_per_block == 1 || c->waves_per_block == 4) return c->waves_per_block;
+    const int t = c->tuned_nw[apad_class(c->APAD)];
+    return t ? t : 1;
 }
 
 template <int NHS, int HASV, int AP, int ATOT>
 static void launch_tiles(dv_ctx* c) {
-    static const int wpc = resident_waves_per_cu((const void*)k_sad_tiles<NHS, HASV, AP, ATOT>);
-    dim3 block;
-    const dim3 grid = scoring_grid(c, wpc, block);
-    // more than 32 headings: two passes of the 32-wide kernel (its 5 waves per SIMD beat one 64-wide pass at 2)
-    for (int a_off = 0; a_off < ATOT; a_off += AP)
-        hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT>), grid, block, 0, c->stream, c->d_tiles, c->d_prep, c->d_part,
-                           c->cfg, c->nchunk, a_off);
+    if (waves_per_block_now(c) == 4) launch_tiles_nw<NHS, HASV, AP, ATOT, 4>(c);
+    else launch_tiles_nw<NHS, HASV, AP, ATOT, 1>(c);
 }
 
 template <int NHS, int HASV>
@@ -750,9 +773,83 @@ static void launch_generic_apad(dv_ctx* c) {
     else launch_generic<HAS_HS, HASV, 32, 64>(c);
 }
 
+// The integer path of one scoring pass: k_sad_tiles / k_sad_generic, then k_combine.  `after_tiles` (optional) is
+// recorded between the two.
+static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial) {
+    const LibCfg& g = c->cfg;
+    int has_hs_sum, has_v_sum = g.hasv;
+    if (g.generic) {
+        has_hs_sum = 1;
+        if (g.hasv) launch_generic_apad<1, 1>(c); else launch_generic_apad<1, 0>(c);
+    } else {
+        has_hs_sum = g.nhs > 0 ? 1 : 0;
+        switch (g.nhs * 2 + g.hasv) {
+            case 1: launch_tiles_apad<0, 1>(c); break;
+            case 2: launch_tiles_apad<1, 0>(c); break;
+            case 3: launch_tiles_apad<1, 1>(c); break;
+            case 4: launch_tiles_apad<2, 0>(c); break;
+            case 5: launch_tiles_apad<2, 1>(c); break;
+            case 6: launch_tiles_apad<3, 0>(c); break;
+            case 7: launch_tiles_apad<3, 1>(c); break;
+            case 8: launch_tiles_apad<4, 0>(c); break;
+            case 9: launch_tiles_apad<4, 1>(c); break;
+            default: return fail(c, DV_ERR_STATE, "unsupported plane configuration nhs=%d hasv=%d", g.nhs, g.hasv);
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (after_tiles) HIP_TRY(c, hipEventRecord(after_tiles, c->stream));
+    *n_partial = (int)((g.Fpad + 1023) / 1024);
+    hipLaunchKernelGGL(k_combine, dim3((unsigned)*n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
+                       c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum, c->n_agents);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+// Times the two workgroup shapes of k_sad_tiles (+ k_combine, whose input they size) on the resident library and
+// patches and keeps the faster one for this heading class.  Runs once, on the first scoring pass after a library is
+// set: 8 extra passes and one host wait.
+static int tune_workgroup_shape(dv_ctx* c) {
+    hipEvent_t ev[2];
+    HIP_TRY(c, hipEventCreate(&ev[0]));
+    HIP_TRY(c, hipEventCreate(&ev[1]));
+    const int cls = apad_class(c->APAD);
+    const int cand[2] = {1, 4};
+    float best = 0.f;
+    int rc = DV_OK, pick = 1, np = 0;
+    for (int i = 0; i < 2 && rc == DV_OK; ++i) {
+        c->force_nw = cand[i];
+        rc = launch_int_scoring(c, nullptr, &np);                     // warm: code objects, caches
+        if (rc == DV_OK && hipEventRecord(ev[0], c->stream) != hipSuccess) rc = DV_ERR_HIP;
+        for (int k = 0; k < 3 && rc == DV_OK; ++k) rc = launch_int_scoring(c, nullptr, &np);
+        if (rc == DV_OK && (hipEventRecord(ev[1], c->stream) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess))
+            rc = DV_ERR_HIP;
+        float ms = 0.f;
+        if (rc == DV_OK && hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) rc = DV_ERR_HIP;
+        if (rc == DV_OK) {
+            c->tuned_us[cls][i] = ms * 1e3f / 3.f;
+            if (i == 0 || ms < best) { best = ms; pick = cand[i]; }
+        }
+    }
+    c->force_nw = 0;
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc == DV_ERR_HIP) return fail(c, DV_ERR_HIP, "timing the workgroup shapes failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc) return rc;
+    c->tuned_nw[cls] = pick;
+    if (getenv("DEJAVU_VERBOSE"))
+        fprintf(stderr, "[dejavu] APAD %d: 1-wave workgroups %.1f us, 4-wave %.1f us per pass -> %d\n", c->APAD,
+                c->tuned_us[cls][0], c->tuned_us[cls][1], pick);
+    return DV_OK;
+}
+
 // Scoring: integer-sum kernel + combine (or the exact fp64 kernel), then amax[a] without atomics.
 static int launch_scoring(dv_ctx* c) {
     const LibCfg& g = c->cfg;
+    int rc = DV_OK;
+    if (c->metric == 0 && !c->exact && !g.generic && c->waves_per_block == 0 && c->tuned_nw[apad_class(c->APAD)] == 0) {
+        rc = tune_workgroup_shape(c);
+        if (rc) return rc;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
         if (c->pev_used + 2 > c->pev.size()) {
@@ -804,31 +901,8 @@ static int launch_scoring(dv_ctx* c) {
         HIP_TRY(c, hipGetLastError());
         n_partial = (int)(g.Fpad / 64);
     } else {
-        int has_hs_sum, has_v_sum = g.hasv;
-        if (g.generic) {
-            has_hs_sum = 1;
-            if (g.hasv) launch_generic_apad<1, 1>(c); else launch_generic_apad<1, 0>(c);
-        } else {
-            has_hs_sum = g.nhs > 0 ? 1 : 0;
-            switch (g.nhs * 2 + g.hasv) {
-                case 1: launch_tiles_apad<0, 1>(c); break;
-                case 2: launch_tiles_apad<1, 0>(c); break;
-                case 3: launch_tiles_apad<1, 1>(c); break;
-                case 4: launch_tiles_apad<2, 0>(c); break;
-                case 5: launch_tiles_apad<2, 1>(c); break;
-                case 6: launch_tiles_apad<3, 0>(c); break;
-                case 7: launch_tiles_apad<3, 1>(c); break;
-                case 8: launch_tiles_apad<4, 0>(c); break;
-                case 9: launch_tiles_apad<4, 1>(c); break;
-                default: return fail(c, DV_ERR_STATE, "unsupported plane configuration nhs=%d hasv=%d", g.nhs, g.hasv);
-            }
-        }
-        HIP_TRY(c, hipGetLastError());
-        if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
-        n_partial = (int)((g.Fpad + 1023) / 1024);
-        hipLaunchKernelGGL(k_combine, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
-                           c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum, c->n_agents);
-        HIP_TRY(c, hipGetLastError());
+        rc = launch_int_scoring(c, c->profile ? e1 : nullptr, &n_partial);
+        if (rc) return rc;
     }
     if (c->exact && c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->n_partial = n_partial;

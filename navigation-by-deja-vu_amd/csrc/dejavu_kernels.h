@@ -311,10 +311,11 @@ __device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
 // One-hot layout.  NHS saturation planes + optional value plane; APAD headings per pass.
 // Scores headings [a_off, a_off+APAD) of the ATOT resident ones (ATOT == APAD except for the two 32-wide passes
 // that cover up to 64 headings).
-template <int NHS, int HASV, int APAD, int ATOT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
+template <int NHS, int HASV, int APAD, int ATOT, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(96)))
 k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
             int nchunk, int a_off_arg) {
+    extern __shared__ unsigned red[];          // [NSUM*APAD][64], only when the workgroup has more than one wave
     constexpr int apad_total = ATOT;
     const int a_off = (ATOT == APAD) ? 0 : a_off_arg;
     constexpr int NPL = NHS + HASV;
@@ -323,17 +324,20 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
     // deeper ring (more bytes in flight per wave); with 2 or 3 planes PF = 1 measured best (A/B, tools/ab_lib.sh).
     constexpr int PF = (APAD <= 16 && NPL == 1) ? 3 : 1;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
+    constexpr int nw = NW;
+    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Q = c.Q;
     const long long G = c.Fpad / 64;
     const long long n_items = G * nchunk;
-    const long long stride = (long long)gridDim.x * nw;
 
-    for (long long item = (long long)blockIdx.x * nw + wave; item < n_items; item += stride) {
+    // The nw waves of a workgroup share an item and take its 16-pixel steps round-robin (step k of wave w is
+    // q0 + w + k*nw): they read neighbouring 1 KB tiles and the same patch dwords at the same time.
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / G);
         const long long g = item - (long long)ch * G;
         const int q0 = (int)(((long long)ch * Q) / nchunk), q1 = (int)(((long long)(ch + 1) * Q) / nchunk);
+        const int nk = (q1 - q0 - wave + nw - 1) / nw;          // steps of this wave (<= 0: none)
+        const int qw = q0 + wave;
         const uint4* base = tiles + g * c.gstride + lane;
 
         unsigned acc_hs[NHS > 0 ? APAD : 1];
@@ -343,23 +347,24 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
 #pragma unroll
         for (int a = 0; a < (HASV ? APAD : 1); ++a) acc_v[a] = 0;
 
-        if (q1 > q0) {
+        if (nk > 0) {
             uint4 ring[PF + 1][NPL];
 #pragma unroll
             for (int s = 0; s < PF; ++s) {
-                const int qq = (q0 + s < q1) ? q0 + s : q1 - 1;
+                const int qq = qw + (s < nk ? s : nk - 1) * nw;
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = load_tile_nt(&base[(long long)(pl * Q + qq) * 64]);
             }
-            for (int q = q0; q < q1; q += PF + 1) {
+            for (int k = 0; k < nk; k += PF + 1) {
 #pragma unroll
                 for (int s = 0; s <= PF; ++s) {
-                    const int qc = q + s;
-                    const int qn = (qc + PF < q1) ? qc + PF : q1 - 1;
+                    const int kc = k + s;
+                    const int qc = qw + kc * nw;
+                    const int qn = qw + ((kc + PF < nk) ? kc + PF : nk - 1) * nw;
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
                         ring[(s + PF) % (PF + 1)][pl] = load_tile_nt(&base[(long long)(pl * Q + qn) * 64]);
-                    if (qc < q1) {
+                    if (kc < nk) {
 #pragma unroll
                         for (int pl = 0; pl < NPL; ++pl) {
                             const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * apad_total + a_off;   // wave-uniform -> s_load
@@ -378,14 +383,45 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
             }
         }
         unsigned* dst = part + ((long long)ch * NSUM * apad_total + a_off) * c.Fpad + g * 64 + lane;
-        if (NHS > 0) {
+        if (nw == 1) {
+            if (NHS > 0) {
 #pragma unroll
-            for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
-        }
-        if (HASV) {
+                for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc_hs[a];
+            }
+            if (HASV) {
 #pragma unroll
-            for (int a = 0; a < APAD; ++a) dst[(long long)((NHS > 0 ? apad_total : 0) + a) * c.Fpad] = acc_v[a];
+                for (int a = 0; a < APAD; ++a) dst[(long long)((NHS > 0 ? apad_total : 0) + a) * c.Fpad] = acc_v[a];
+            }
+            continue;
         }
+        // the workgroup's waves add their sums up in LDS and share the stores: 1/nw of the partial-sum traffic
+        if (wave == 0) {
+            if (NHS > 0) {
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) red[a * 64 + lane] = acc_hs[a];
+            }
+            if (HASV) {
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) red[((NHS > 0 ? APAD : 0) + a) * 64 + lane] = acc_v[a];
+            }
+        }
+        __syncthreads();
+        if (wave != 0) {
+            if (NHS > 0) {
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) atomicAdd(&red[a * 64 + lane], acc_hs[a]);
+            }
+            if (HASV) {
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) atomicAdd(&red[((NHS > 0 ? APAD : 0) + a) * 64 + lane], acc_v[a]);
+            }
+        }
+        __syncthreads();
+        for (int r = wave; r < NSUM * APAD; r += nw) {
+            const int row = (NHS > 0 && r >= APAD) ? apad_total + (r - APAD) : r;
+            dst[(long long)row * c.Fpad] = red[r * 64 + lane];
+        }
+        __syncthreads();
     }
 }
 
