@@ -198,6 +198,11 @@ def main():
         workload = ("%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g "
                     "(BASELINE.json configs[1])" % (w, h, F, A, cw))
         traffic = committed_traffic(workload)
+        # SURVEY.md 8(d) asks for both peaks: the spec figure and what a pure streaming read reaches on this device
+        try:
+            read_ceiling = float(eng.stream_read_gbps(1 << 30, 10))
+        except Exception:                                        # measurement aid only
+            read_ceiling = None
         out = {
             "metric": "view-comparisons/sec (sensor x library x headings)",
             "value": comparisons / dt,
@@ -228,6 +233,8 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kern_ms, "launches_timed": kern_n,
                 "stored_bytes_per_launch": stored_bytes, "achieved_stored": achieved_stored,
                 "frac_stored": achieved_stored / HBM_PEAK_GBPS,
+                "measured_read_ceiling": read_ceiling,
+                "frac_stored_of_measured_ceiling": (achieved_stored / read_ceiling) if read_ceiling else None,
             },
         }
         if world == 1 and args.agent_steps > 0 and not args.force_dist:

@@ -56,10 +56,10 @@ struct dv_ctx {
     int nchunk_cap = 1;                       // chunks the partial-sum buffer has room for
     int target_items = 0;                     // 0 = as many items as waves are resident (DEJAVU_TARGET_ITEMS overrides)
     int waves_per_cu = 0;                     // resident waves per CU the grid is sized for; 0 = by kernel (DEJAVU_WPC)
-    int waves_per_block = 0;                  // DEJAVU_WPB: 1 or 4 waves per k_sad_tiles workgroup (0: timed once per library)
-    int force_nw = 0;                         // set while tune_workgroup_shape() times a candidate
-    int tuned_nw[4] = {0, 0, 0, 0};           // chosen workgroup shape per APAD class (8, 16, 32, 64); 0 = not timed yet
-    float tuned_us[4][2] = {};                // what the timing saw (1-wave, 4-wave), for dv_profile / debugging
+    int shape_env = 0;                        // DEJAVU_SHAPE: workgroup shape of k_sad_tiles, 1..4 (0: timed once per library)
+    int force_shape = 0;                      // set while tune_workgroup_shape() times a candidate
+    int tuned_shape[4] = {0, 0, 0, 0};        // chosen shape per heading class (8, 16, 32, 64 resident); 0 = not timed yet
+    float tuned_us[4][4] = {};                // what the timing saw per shape (DEJAVU_VERBOSE prints it)
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -127,7 +127,7 @@ static void free_library(dv_ctx* c) {
     if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; c->d_result = nullptr; }
     if (c->h_scene) { (void)hipHostFree(c->h_scene); c->h_scene = nullptr; }
     c->have_lib = false;
-    for (int i = 0; i < 4; ++i) c->tuned_nw[i] = 0;
+    for (int i = 0; i < 4; ++i) c->tuned_shape[i] = 0;
     c->A = 0;
     c->step_pending = false;
 }
@@ -160,7 +160,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     };
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
-    env_int("DEJAVU_WPB", c->waves_per_block, 0, 4);
+    env_int("DEJAVU_SHAPE", c->shape_env, 0, 4);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -698,9 +698,9 @@ static int resident_waves_per_cu(const void* kernel) {
     return 4 * per_simd;
 }
 
-// Grid of the scoring kernels: single-wave workgroups (waves_per_block > 1 only for experiments), never more than are
-// resident at once, walking the items with a grid stride.  The pixel range is cut into as many chunks as make the item
-// count just fill the resident waves (measured optimum: 7038 items on 7168 wave slots; one item more than fits costs
+// Grid of the scoring kernels: workgroups of `wpb` waves, never more than are resident at once, walking the items
+// with a grid stride.  The pixel range is cut into as many chunks as make the item count just fill the resident
+// workgroups (measured optimum for single-wave workgroups: 7038 items on 7168 wave slots; one item more than fits costs
 // a second round, fewer items leave SIMDs short of waves to hide latency).
 static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block, int wpb = 1) {
     const int wpc = c->waves_per_cu ? c->waves_per_cu : kernel_wpc;
@@ -715,44 +715,58 @@ static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block, int wpb = 1) {
     return dim3((unsigned)(slots < n_items ? slots : n_items));
 }
 
-template <int NHS, int HASV, int AP, int ATOT, int NW>
-static void launch_tiles_nw(dv_ctx* c) {
-    static const int wpc = resident_waves_per_cu((const void*)k_sad_tiles<NHS, HASV, AP, ATOT, NW>);
+// One workgroup shape of k_sad_tiles: AP headings per wave, NW waves sharing an item's pixels, HW heading ways.
+template <int NHS, int HASV, int AP, int ATOT, int NW, int HW>
+static void launch_tiles_shape(dv_ctx* c) {
+    static const int wpc = resident_waves_per_cu((const void*)k_sad_tiles<NHS, HASV, AP, ATOT, NW, HW>);
     dim3 block;
-    const dim3 grid = scoring_grid(c, wpc, block, NW);
+    const dim3 grid = scoring_grid(c, wpc, block, NW * HW);
     constexpr int nsum = (NHS > 0 ? 1 : 0) + HASV;
-    const size_t lds = NW > 1 ? (size_t)nsum * AP * 64 * sizeof(unsigned) : 0;
-    // more than 32 headings: two passes of the 32-wide kernel (its 5 waves per SIMD beat one 64-wide pass at 2)
-    for (int a_off = 0; a_off < ATOT; a_off += AP)
-        hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT, NW>), grid, block, lds, c->stream, c->d_tiles, c->d_prep,
+    const size_t lds = NW > 1 ? (size_t)HW * nsum * AP * 64 * sizeof(unsigned) : 0;
+    // more resident headings than one launch covers: further passes over the library
+    for (int a_off = 0; a_off < ATOT; a_off += AP * HW)
+        hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT, NW, HW>), grid, block, lds, c->stream, c->d_tiles, c->d_prep,
                            c->d_part, c->cfg, c->nchunk, a_off);
 }
 
-// Waves per workgroup of k_sad_tiles.  Four waves sharing an item add their sums in LDS, so a quarter of the partial
-// sums cross HBM (written here, read again by k_combine), and they read the same patch dwords together; single-wave
-// workgroups cut the pixel range finer and balance the CUs better.  Which wins depends on the library size and the
-// heading count (tools/sweep_grid.sh: -18 % to +37 %), so it is timed once per library and heading class
-// (tune_workgroup_shape); the integer sums are identical either way.
+// Workgroup shapes of k_sad_tiles per heading class (resident headings padded to 8, 16, 32 or 64):
+//   1: single-wave workgroups, the pixel range cut finest (best CU balance);
+//   2: four waves share an item and add their sums in LDS -- a quarter of the partial sums cross HBM (written here,
+//      read again by k_combine) and the waves read the same patch dwords together;
+//   3, 4: heading ways -- 2 or 4 waves score the same tiles against different slices of the headings, so the
+//      library crosses HBM once for all of them and each wave keeps the register footprint (hence the occupancy)
+//      of the narrower kernel; with 64 headings shapes 1 and 2 take two passes of the 32-wide kernel instead.
+// Which one wins depends on the library size and the heading count (tools/sweep_grid.sh), so the shapes are timed once
+// per library and heading class (tune_workgroup_shape).  The integer sums are identical in every shape.
 static int apad_class(int APAD) { return APAD == 8 ? 0 : (APAD == 16 ? 1 : (APAD == 32 ? 2 : 3)); }
-static int waves_per_block_now(dv_ctx* c) {
-    if (c->force_nw) return c->force_nw;
-    if (c->waves_per_block == 1 || c->waves_per_block == 4) return c->waves_per_block;
-    const int t = c->tuned_nw[apad_class(c->APAD)];
-    return t ? t : 1;
-}
-
-template <int NHS, int HASV, int AP, int ATOT>
-static void launch_tiles(dv_ctx* c) {
-    if (waves_per_block_now(c) == 4) launch_tiles_nw<NHS, HASV, AP, ATOT, 4>(c);
-    else launch_tiles_nw<NHS, HASV, AP, ATOT, 1>(c);
+static int n_shapes(int cls) { return cls == 0 ? 2 : (cls == 3 ? 4 : 3); }
+static int shape_now(dv_ctx* c) {
+    const int cls = apad_class(c->APAD);
+    int s = c->force_shape ? c->force_shape : (c->shape_env ? c->shape_env : c->tuned_shape[cls]);
+    if (s < 1 || s > n_shapes(cls)) s = 1;
+    return s;
 }
 
 template <int NHS, int HASV>
 static void launch_tiles_apad(dv_ctx* c) {
-    if (c->APAD == 8) launch_tiles<NHS, HASV, 8, 8>(c);
-    else if (c->APAD == 16) launch_tiles<NHS, HASV, 16, 16>(c);
-    else if (c->APAD == 32) launch_tiles<NHS, HASV, 32, 32>(c);
-    else launch_tiles<NHS, HASV, 32, 64>(c);
+    const int s = shape_now(c);
+    if (c->APAD == 8) {
+        if (s == 2) launch_tiles_shape<NHS, HASV, 8, 8, 4, 1>(c);
+        else launch_tiles_shape<NHS, HASV, 8, 8, 1, 1>(c);
+    } else if (c->APAD == 16) {
+        if (s == 2) launch_tiles_shape<NHS, HASV, 16, 16, 4, 1>(c);
+        else if (s == 3) launch_tiles_shape<NHS, HASV, 8, 16, 1, 2>(c);
+        else launch_tiles_shape<NHS, HASV, 16, 16, 1, 1>(c);
+    } else if (c->APAD == 32) {
+        if (s == 2) launch_tiles_shape<NHS, HASV, 32, 32, 4, 1>(c);
+        else if (s == 3) launch_tiles_shape<NHS, HASV, 16, 32, 1, 2>(c);
+        else launch_tiles_shape<NHS, HASV, 32, 32, 1, 1>(c);
+    } else {
+        if (s == 2) launch_tiles_shape<NHS, HASV, 32, 64, 4, 1>(c);
+        else if (s == 3) launch_tiles_shape<NHS, HASV, 32, 64, 1, 2>(c);
+        else if (s == 4) launch_tiles_shape<NHS, HASV, 16, 64, 1, 4>(c);
+        else launch_tiles_shape<NHS, HASV, 32, 64, 1, 1>(c);
+    }
 }
 
 template <int HAS_HS, int HASV, int AP, int ATOT>
@@ -805,19 +819,18 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial)
     return DV_OK;
 }
 
-// Times the two workgroup shapes of k_sad_tiles (+ k_combine, whose input they size) on the resident library and
-// patches and keeps the faster one for this heading class.  Runs once, on the first scoring pass after a library is
-// set: 8 extra passes and one host wait.
+// Times the workgroup shapes of k_sad_tiles (+ k_combine, whose input they size) on the resident library and patches
+// and keeps the fastest for this heading class.  Runs once, on the first scoring pass after a library is set: four
+// extra passes per shape and one host wait each.
 static int tune_workgroup_shape(dv_ctx* c) {
     hipEvent_t ev[2];
     HIP_TRY(c, hipEventCreate(&ev[0]));
     HIP_TRY(c, hipEventCreate(&ev[1]));
     const int cls = apad_class(c->APAD);
-    const int cand[2] = {1, 4};
     float best = 0.f;
     int rc = DV_OK, pick = 1, np = 0;
-    for (int i = 0; i < 2 && rc == DV_OK; ++i) {
-        c->force_nw = cand[i];
+    for (int sh = 1; sh <= n_shapes(cls) && rc == DV_OK; ++sh) {
+        c->force_shape = sh;
         rc = launch_int_scoring(c, nullptr, &np);                     // warm: code objects, caches
         if (rc == DV_OK && hipEventRecord(ev[0], c->stream) != hipSuccess) rc = DV_ERR_HIP;
         for (int k = 0; k < 3 && rc == DV_OK; ++k) rc = launch_int_scoring(c, nullptr, &np);
@@ -826,19 +839,21 @@ static int tune_workgroup_shape(dv_ctx* c) {
         float ms = 0.f;
         if (rc == DV_OK && hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) rc = DV_ERR_HIP;
         if (rc == DV_OK) {
-            c->tuned_us[cls][i] = ms * 1e3f / 3.f;
-            if (i == 0 || ms < best) { best = ms; pick = cand[i]; }
+            c->tuned_us[cls][sh - 1] = ms * 1e3f / 3.f;
+            if (sh == 1 || ms < best) { best = ms; pick = sh; }
         }
     }
-    c->force_nw = 0;
+    c->force_shape = 0;
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
     if (rc == DV_ERR_HIP) return fail(c, DV_ERR_HIP, "timing the workgroup shapes failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc) return rc;
-    c->tuned_nw[cls] = pick;
-    if (getenv("DEJAVU_VERBOSE"))
-        fprintf(stderr, "[dejavu] APAD %d: 1-wave workgroups %.1f us, 4-wave %.1f us per pass -> %d\n", c->APAD,
-                c->tuned_us[cls][0], c->tuned_us[cls][1], pick);
+    c->tuned_shape[cls] = pick;
+    if (getenv("DEJAVU_VERBOSE")) {
+        fprintf(stderr, "[dejavu] %d resident headings, us per scoring pass by workgroup shape:", c->APAD);
+        for (int sh = 1; sh <= n_shapes(cls); ++sh) fprintf(stderr, " %d: %.1f", sh, c->tuned_us[cls][sh - 1]);
+        fprintf(stderr, " -> shape %d\n", pick);
+    }
     return DV_OK;
 }
 
@@ -846,7 +861,7 @@ static int tune_workgroup_shape(dv_ctx* c) {
 static int launch_scoring(dv_ctx* c) {
     const LibCfg& g = c->cfg;
     int rc = DV_OK;
-    if (c->metric == 0 && !c->exact && !g.generic && c->waves_per_block == 0 && c->tuned_nw[apad_class(c->APAD)] == 0) {
+    if (c->metric == 0 && !c->exact && !g.generic && c->shape_env == 0 && c->tuned_shape[apad_class(c->APAD)] == 0) {
         rc = tune_workgroup_shape(c);
         if (rc) return rc;
     }

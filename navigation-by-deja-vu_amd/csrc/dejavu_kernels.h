@@ -308,16 +308,21 @@ __device__ __forceinline__ uint4 load_tile_nt(const uint4* p) {
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+template <bool NT>
+__device__ __forceinline__ uint4 load_tile(const uint4* p) {
+    if (NT) return load_tile_nt(p);
+    return *p;                                  // several waves of the workgroup read this tile: keep it cached
+}
+
 // One-hot layout.  NHS saturation planes + optional value plane; APAD headings per pass.
 // Scores headings [a_off, a_off+APAD) of the ATOT resident ones (ATOT == APAD except for the two 32-wide passes
 // that cover up to 64 headings).
-template <int NHS, int HASV, int APAD, int ATOT, int NW>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(96)))
+template <int NHS, int HASV, int APAD, int ATOT, int NW, int HW>
+__global__ void __launch_bounds__(64 * NW * HW) __attribute__((amdgpu_num_sgpr(96)))
 k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
             int nchunk, int a_off_arg) {
-    extern __shared__ unsigned red[];          // [NSUM*APAD][64], only when the workgroup has more than one wave
+    extern __shared__ unsigned red_all[];      // [HW][NSUM*APAD][64], only when NW > 1
     constexpr int apad_total = ATOT;
-    const int a_off = (ATOT == APAD) ? 0 : a_off_arg;
     constexpr int NPL = NHS + HASV;
     constexpr int NSUM = (NHS > 0 ? 1 : 0) + HASV;
     // Register ring depth: chunk q+PF is in flight while q is scored.  Few planes / few headings leave VGPRs for a
@@ -325,7 +330,14 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
     constexpr int PF = (APAD <= 16 && NPL == 1) ? 3 : 1;
     const int lane = threadIdx.x & 63;
     constexpr int nw = NW;
-    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Workgroup = HW "heading ways" x NW waves.  The NW waves of a way share the item's 16-pixel steps (below); the HW
+    // ways score the same tiles against different APAD-wide slices of the resident headings, so one trip of the
+    // library through HBM serves HW*APAD headings (the ways run in step and meet in L1/L2).
+    const int wid = (NW * HW == 1) ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = NW == 1 ? 0 : (HW == 1 ? wid : wid % NW);
+    const int hway = HW == 1 ? 0 : (NW == 1 ? wid : wid / NW);
+    const int a_off = ((ATOT == APAD) ? 0 : a_off_arg) + hway * APAD;
+    unsigned* red = red_all + hway * (NSUM * APAD * 64);
     const int Q = c.Q;
     const long long G = c.Fpad / 64;
     const long long n_items = G * nchunk;
@@ -353,7 +365,7 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
             for (int s = 0; s < PF; ++s) {
                 const int qq = qw + (s < nk ? s : nk - 1) * nw;
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = load_tile_nt(&base[(long long)(pl * Q + qq) * 64]);
+                for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = load_tile<HW == 1>(&base[(long long)(pl * Q + qq) * 64]);
             }
             for (int k = 0; k < nk; k += PF + 1) {
 #pragma unroll
@@ -363,7 +375,7 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
                     const int qn = qw + ((kc + PF < nk) ? kc + PF : nk - 1) * nw;
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
-                        ring[(s + PF) % (PF + 1)][pl] = load_tile_nt(&base[(long long)(pl * Q + qn) * 64]);
+                        ring[(s + PF) % (PF + 1)][pl] = load_tile<HW == 1>(&base[(long long)(pl * Q + qn) * 64]);
                     if (kc < nk) {
 #pragma unroll
                         for (int pl = 0; pl < NPL; ++pl) {
