@@ -59,7 +59,7 @@ struct dv_ctx {
     int shape_env = 0;                        // DEJAVU_SHAPE: workgroup shape of k_sad_tiles, 1..4 (0: timed once per library)
     int force_shape = 0;                      // set while tune_workgroup_shape() times a candidate
     int tuned_shape[4] = {0, 0, 0, 0};        // chosen shape per heading class (8, 16, 32, 64 resident); 0 = not timed yet
-    float tuned_us[4][4] = {};                // what the timing saw per shape (DEJAVU_VERBOSE prints it)
+    float tuned_us[4][5] = {};                // what the timing saw per shape (DEJAVU_VERBOSE prints it)
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -160,7 +160,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     };
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
-    env_int("DEJAVU_SHAPE", c->shape_env, 0, 4);
+    env_int("DEJAVU_SHAPE", c->shape_env, 0, 5);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -702,10 +702,13 @@ static int resident_waves_per_cu(const void* kernel) {
 // with a grid stride.  The pixel range is cut into as many chunks as make the item count just fill the resident
 // workgroups (measured optimum for single-wave workgroups: 7038 items on 7168 wave slots; one item more than fits costs
 // a second round, fewer items leave SIMDs short of waves to hide latency).
-static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block, int wpb = 1) {
+static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block, int wpb = 1, size_t lds_bytes = 0) {
     const int wpc = c->waves_per_cu ? c->waves_per_cu : kernel_wpc;
     const long long G = c->cfg.Fpad / 64;
-    const long long slots = 256ll * (wpc / wpb > 0 ? wpc / wpb : 1);      // workgroups resident at once
+    long long per_cu = wpc / wpb > 0 ? wpc / wpb : 1;
+    if (lds_bytes && per_cu > (long long)(163840 / lds_bytes)) per_cu = 163840 / lds_bytes;      // 160 KB of LDS per CU
+    if (per_cu < 1) per_cu = 1;
+    const long long slots = 256ll * per_cu;                                // workgroups resident at once
     long long n = c->target_items ? (c->target_items + G - 1) / G : slots / G;
     if (n < 1) n = 1;
     if (n > c->nchunk_cap) n = c->nchunk_cap;
@@ -720,13 +723,32 @@ template <int NHS, int HASV, int AP, int ATOT, int NW, int HW>
 static void launch_tiles_shape(dv_ctx* c) {
     static const int wpc = resident_waves_per_cu((const void*)k_sad_tiles<NHS, HASV, AP, ATOT, NW, HW>);
     dim3 block;
-    const dim3 grid = scoring_grid(c, wpc, block, NW * HW);
     constexpr int nsum = (NHS > 0 ? 1 : 0) + HASV;
     const size_t lds = NW > 1 ? (size_t)HW * nsum * AP * 64 * sizeof(unsigned) : 0;
+    const dim3 grid = scoring_grid(c, wpc, block, NW * HW, lds);
     // more resident headings than one launch covers: further passes over the library
     for (int a_off = 0; a_off < ATOT; a_off += AP * HW)
         hipLaunchKernelGGL((k_sad_tiles<NHS, HASV, AP, ATOT, NW, HW>), grid, block, lds, c->stream, c->d_tiles, c->d_prep,
                            c->d_part, c->cfg, c->nchunk, a_off);
+}
+
+// The packed kernel (both sums in one accumulator per heading): all resident headings in one pass.
+template <int NHS, int AP, int PF>
+static void launch_packed(dv_ctx* c) {
+    static const int wpc = resident_waves_per_cu((const void*)k_sad_packed<NHS, AP, PF>);
+    dim3 block;
+    const size_t lds = (size_t)2 * AP * 64 * sizeof(unsigned);
+    const dim3 grid = scoring_grid(c, wpc, block, 4, lds);
+    hipLaunchKernelGGL((k_sad_packed<NHS, AP, PF>), grid, block, lds, c->stream, c->d_tiles, c->d_prep, c->d_part, c->cfg,
+                       c->nchunk);
+}
+
+template <int NHS>
+static void launch_packed_apad(dv_ctx* c) {
+    if (c->APAD == 8) launch_packed<NHS, 8, 1>(c);
+    else if (c->APAD == 16) launch_packed<NHS, 16, 1>(c);
+    else if (c->APAD == 32) launch_packed<NHS, 32, 1>(c);
+    else launch_packed<NHS, 64, 1>(c);
 }
 
 // Workgroup shapes of k_sad_tiles per heading class (resident headings padded to 8, 16, 32 or 64):
@@ -739,17 +761,26 @@ static void launch_tiles_shape(dv_ctx* c) {
 // Which one wins depends on the library size and the heading count (tools/sweep_grid.sh), so the shapes are timed once
 // per library and heading class (tune_workgroup_shape).  The integer sums are identical in every shape.
 static int apad_class(int APAD) { return APAD == 8 ? 0 : (APAD == 16 ? 1 : (APAD == 32 ? 2 : 3)); }
-static int n_shapes(int cls) { return cls == 0 ? 2 : (cls == 3 ? 4 : 3); }
+//   5: k_sad_packed (libraries with both sums only), all resident headings in one pass.
+constexpr int kMaxShape = 5;
+static bool shape_valid(const dv_ctx* c, int cls, int sh) {
+    if (sh >= 1 && sh <= (cls == 0 ? 2 : (cls == 3 ? 4 : 3))) return true;
+    const bool both_sums = !c->cfg.generic && c->cfg.nhs > 0 && c->cfg.hasv;
+    return sh == 5 && both_sums;
+}
 static int shape_now(dv_ctx* c) {
     const int cls = apad_class(c->APAD);
     int s = c->force_shape ? c->force_shape : (c->shape_env ? c->shape_env : c->tuned_shape[cls]);
-    if (s < 1 || s > n_shapes(cls)) s = 1;
+    if (!shape_valid(c, cls, s)) s = 1;
     return s;
 }
 
 template <int NHS, int HASV>
 static void launch_tiles_apad(dv_ctx* c) {
     const int s = shape_now(c);
+    if constexpr (NHS > 0 && HASV == 1) {
+        if (s == 5) return launch_packed_apad<NHS>(c);
+    }
     if (c->APAD == 8) {
         if (s == 2) launch_tiles_shape<NHS, HASV, 8, 8, 4, 1>(c);
         else launch_tiles_shape<NHS, HASV, 8, 8, 1, 1>(c);
@@ -829,7 +860,8 @@ static int tune_workgroup_shape(dv_ctx* c) {
     const int cls = apad_class(c->APAD);
     float best = 0.f;
     int rc = DV_OK, pick = 1, np = 0;
-    for (int sh = 1; sh <= n_shapes(cls) && rc == DV_OK; ++sh) {
+    for (int sh = 1; sh <= kMaxShape && rc == DV_OK; ++sh) {
+        if (!shape_valid(c, cls, sh)) continue;
         c->force_shape = sh;
         rc = launch_int_scoring(c, nullptr, &np);                     // warm: code objects, caches
         if (rc == DV_OK && hipEventRecord(ev[0], c->stream) != hipSuccess) rc = DV_ERR_HIP;
@@ -851,7 +883,8 @@ static int tune_workgroup_shape(dv_ctx* c) {
     c->tuned_shape[cls] = pick;
     if (getenv("DEJAVU_VERBOSE")) {
         fprintf(stderr, "[dejavu] %d resident headings, us per scoring pass by workgroup shape:", c->APAD);
-        for (int sh = 1; sh <= n_shapes(cls); ++sh) fprintf(stderr, " %d: %.1f", sh, c->tuned_us[cls][sh - 1]);
+        for (int sh = 1; sh <= kMaxShape; ++sh)
+            if (shape_valid(c, cls, sh)) fprintf(stderr, " %d: %.1f", sh, c->tuned_us[cls][sh - 1]);
         fprintf(stderr, " -> shape %d\n", pick);
     }
     return DV_OK;

@@ -437,6 +437,92 @@ k_sad_tiles(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, 
     }
 }
 
+// Packed variant for libraries that need both sums (0 < chem_weight < 1): one 32-bit accumulator per heading
+// carries the value-plane SAD in its low half (v_sad_u8) and the saturation-plane SAD in its high half
+// (v_sad_hi_u8: D = (SAD << 16) + S2), so a wave holds APAD accumulators instead of 2*APAD -- more waves per SIMD, or
+// a deeper load ring, or 64 headings in one pass.  A half holds 16 steps of 16 pixels (256 * 255 < 2^16; with several
+// saturation planes a pixel contributes up to 510, hence 8 steps); after that many steps the wave adds both halves
+// into the workgroup's LDS accumulators, which the four waves of the workgroup (sharing the item's steps round-robin,
+// as in k_sad_tiles with NW = 4) then store as one set of partial sums.
+template <int NHS, int APAD, int PF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
+k_sad_packed(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep, unsigned* __restrict__ part, LibCfg c,
+             int nchunk) {
+    extern __shared__ unsigned red[];          // [2*APAD][64]: rows 0..APAD-1 saturation sums, then value sums
+    constexpr int NPL = NHS + 1;
+    constexpr int NW = 4;
+    constexpr int FLUSH = (NHS > 1 ? 8 : 16) / (PF + 1);     // ring turns between flushes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Q = c.Q;
+    const long long G = c.Fpad / 64;
+    const long long n_items = G * nchunk;
+
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ch = (int)(item / G);
+        const long long g = item - (long long)ch * G;
+        const int q0 = (int)(((long long)ch * Q) / nchunk), q1 = (int)(((long long)(ch + 1) * Q) / nchunk);
+        const int nk = (q1 - q0 - wave + NW - 1) / NW;
+        const int qw = q0 + wave;
+        const uint4* base = tiles + g * c.gstride + lane;
+
+        for (int r = wave; r < 2 * APAD; r += NW) red[r * 64 + lane] = 0;
+        __syncthreads();
+
+        if (nk > 0) {
+            uint4 ring[PF + 1][NPL];
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                const int qq = qw + (s < nk ? s : nk - 1) * NW;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) ring[s][pl] = load_tile_nt(&base[(long long)(pl * Q + qq) * 64]);
+            }
+            // blocks of FLUSH ring turns: the accumulators start at zero in each block and are flushed after it
+            for (int kb = 0; kb < nk; kb += FLUSH * (PF + 1)) {
+                unsigned acc[APAD];
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) acc[a] = 0;
+                const int kend = (kb + FLUSH * (PF + 1) < nk) ? kb + FLUSH * (PF + 1) : nk;
+                for (int k = kb; k < kend; k += PF + 1) {
+#pragma unroll
+                    for (int s = 0; s <= PF; ++s) {
+                        const int kc = k + s;
+                        const int qc = qw + kc * NW;
+                        const int qn = qw + ((kc + PF < nk) ? kc + PF : nk - 1) * NW;
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl)
+                            ring[(s + PF) % (PF + 1)][pl] = load_tile_nt(&base[(long long)(pl * Q + qn) * 64]);
+                        if (kc < nk) {
+#pragma unroll
+                            for (int pl = 0; pl < NPL; ++pl) {
+                                const unsigned* pp = prep + ((long long)(pl * Q + qc) * 4) * APAD;   // wave-uniform -> s_load
+                                const unsigned lw[4] = {ring[s][pl].x, ring[s][pl].y, ring[s][pl].z, ring[s][pl].w};
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                    for (int a = 0; a < APAD; ++a) {
+                                        if (pl < NHS) acc[a] = __builtin_amdgcn_sad_hi_u8(lw[j], pp[j * APAD + a], acc[a]);
+                                        else acc[a] = __builtin_amdgcn_sad_u8(lw[j], pp[j * APAD + a], acc[a]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < APAD; ++a) {
+                    atomicAdd(&red[a * 64 + lane], acc[a] >> 16);
+                    atomicAdd(&red[(APAD + a) * 64 + lane], acc[a] & 0xffffu);
+                }
+            }
+        }
+        __syncthreads();
+        unsigned* dst = part + ((long long)ch * 2 * APAD) * c.Fpad + g * 64 + lane;
+        for (int r = wave; r < 2 * APAD; r += NW) dst[(long long)r * c.Fpad] = red[r * 64 + lane];
+        __syncthreads();
+    }
+}
+
 // Generic-hue layout (planes H,S[,V]): per-byte hue compare done with bit tricks.
 template <int HAS_HS, int HASV, int APAD, int ATOT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))

@@ -189,13 +189,14 @@ class FamiliarityEngine(object):
     @staticmethod
     def _result_dict(r, scene):
         A = r.n_headings
-        # one copy of the record's four per-heading arrays ([4][64] 8-byte values after the 56-byte header)
-        raw = np.frombuffer(r, dtype=np.uint8, count=4 * 8 * N.DV_MAX_HEADINGS, offset=56).copy()
-        f64 = raw.view(np.float64).reshape(4, N.DV_MAX_HEADINGS)
-        i64 = raw.view(np.int64).reshape(4, N.DV_MAX_HEADINGS)
+        # views of the record's four per-heading arrays ([4][64] 8-byte values after the 56-byte header); every step
+        # has its own record, which the views keep alive
+        M = N.DV_MAX_HEADINGS
+        f64 = np.frombuffer(r, dtype=np.float64, count=4 * M, offset=56)
+        i64 = f64.view(np.int64)
         return dict(best_idex=r.best_heading, best_view=r.best_view, step_familiarity=r.best_fam,
-                    angle_familiarity=f64[0, :A], angle_view=i64[1, :A],
-                    exact_familiarity=f64[2, :A], exact_view=i64[3, :A],
+                    angle_familiarity=f64[:A], angle_view=i64[M:M + A],
+                    exact_familiarity=f64[2 * M:2 * M + A], exact_view=i64[3 * M:3 * M + A],
                     approx_max=r.approx_max, delta=r.delta, n_candidates=r.n_candidates,
                     flags=r.flags, scene_familiarity=scene)
 

@@ -133,6 +133,49 @@ class ShardedFamiliarity(object):
         return out
 
 
+class ShardedEnsemble(object):
+    """Ensemble of independent agents (BASELINE.json configs[4]; the reference farms trials over MPI ranks,
+    scripts/run_experiment.py:326-347): the AGENTS are partitioned over the ranks in contiguous blocks and every
+    rank holds the whole library, so a step has no data-path collective at all.  `decisions` gathers the three
+    numbers per agent that a driver logs; it is reporting, not part of the step.
+    """
+
+    def __init__(self, engine, rank, world_size):
+        self.engine = engine
+        self.rank = rank
+        self.world_size = world_size
+
+    def set_library(self, scenes, chem_weight=0.0):
+        self.engine.set_library(scenes, chem_weight)
+
+    def agent_bounds(self, n_agents):
+        return shard_bounds(n_agents, self.world_size, self.rank)
+
+    def step(self, patches):
+        """patches uint8[N, A, h, w, 3] for ALL agents (or only this rank's block with `local=True` semantics:
+        pass patches[lo:hi] and use step_local).  Returns this rank's agents' result dicts, in agent order."""
+        lo, hi = self.agent_bounds(len(patches))
+        return self.step_local(patches[lo:hi])
+
+    def step_local(self, patches_local):
+        if len(patches_local) == 0:
+            return []
+        return self.engine.step_batch(np.ascontiguousarray(patches_local))
+
+    def decisions(self, results, n_agents, gather):
+        """All ranks' (best_idex, best_view, step_familiarity) as float64[n_agents, 3] via one all-gather."""
+        per = (n_agents + self.world_size - 1) // self.world_size
+        mine = np.full((per, 3), np.nan)
+        for i, r in enumerate(results):
+            mine[i] = (r["best_idex"], r["best_view"], r["step_familiarity"])
+        allr = gather(mine.reshape(-1)).reshape(self.world_size, per, 3)
+        out = np.empty((n_agents, 3))
+        for rk in range(self.world_size):
+            lo, hi = shard_bounds(n_agents, self.world_size, rk)
+            out[lo:hi] = allr[rk, :hi - lo]
+        return out
+
+
 def torch_gather(device=None):
     """All-gather over torch.distributed (RCCL when the tensors live on the GPU, gloo on CPU)."""
     import torch

@@ -54,6 +54,9 @@ class OracleBackedEngine(object):
         self._last = res
         return res
 
+    def step_batch(self, patches, force_resolve=False):
+        return [self.step(p, force_resolve=force_resolve) for p in patches]
+
     def _resolve_into(self, res):
         res = dict(res)
         exact = self._exact(self._patches)

@@ -95,6 +95,54 @@ def test_sharded_matches_unsharded_reference(world):
     assert exchanged["dups_across_ranks"] >= 1
 
 
+def ensemble_case():
+    lib = synth.synth_views(33, 200, 8, 8)
+    pats = synth.synth_patches(33, 5 * 4, 8, 8).reshape(5, 4, 8, 8, 3).copy()
+    pats[3, 2] = lib[77]                       # agent 3 stands on a stored view
+    pats[0, 1] = pats[0, 3] = lib[5]           # agent 0: two headings tie exactly -> first one wins
+    return lib, pats, 0.25
+
+
+def ensemble_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib, pats, cw = ensemble_case()
+    ens = sharded.ShardedEnsemble(OracleBackedEngine(), rank, world)
+    ens.set_library(lib, cw)
+    res = ens.step(pats)
+    lo, hi = ens.agent_bounds(len(pats))
+    assert len(res) == hi - lo
+    table = ens.decisions(res, len(pats), sharded.torch_gather(device=None))
+    q.put((rank, (lo, hi), table.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_agent_sharded_ensemble_matches_reference(world):
+    """BASELINE configs[4]: agents partitioned over ranks (5 agents on 2 or 3 ranks: uneven blocks), library replicated."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=ensemble_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lib, pats, cw = ensemble_case()
+    want = [oracle.step(lib, p, cw) for p in pats]
+    spans = sorted(g[1] for g in got)
+    assert spans[0][0] == 0 and spans[-1][1] == len(pats) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for rank, _, table in got:
+        for g, w in enumerate(want):
+            assert int(table[g][0]) == w["best_idex"] and int(table[g][1]) == w["best_view"], (rank, g)
+            np.testing.assert_allclose(table[g][2], w["step_familiarity"], rtol=1e-12)
+    assert want[3]["best_idex"] == 2 and want[3]["best_view"] == 77 and want[0]["best_idex"] == 1
+
+
 def test_shard_bounds_cover_the_library():
     for n, w in ((10, 3), (50000, 8), (7, 8), (64, 2)):
         spans = [sharded.shard_bounds(n, w, r) for r in range(w)]
