@@ -191,6 +191,33 @@ int dv_step_wait(dv_ctx *ctx, dv_step_result *result, double *scene_fam);
 int dv_step_record(dv_ctx *ctx, void **device_ptr, int *n_doubles);
 /* Enqueue the exact resolver on the last step's candidates (updates the record); no host synchronisation. */
 int dv_resolve_enqueue(dv_ctx *ctx);
+/*
+ * Hand a device buffer (e.g. the output of an all-gather of the ranks' records) to the host without a blocking
+ * stream synchronisation: dv_publish enqueues, on the context's stream, a copy of n_doubles doubles into mapped host
+ * memory followed by a sequence word; dv_publish_wait polls that word and copies the doubles to dst.
+ */
+int dv_publish(dv_ctx *ctx, const void *device_src, int64_t n_doubles);
+int dv_publish_wait(dv_ctx *ctx, double *dst, int64_t n_doubles);
+
+/*
+ * The global decision from the gathered per-rank records (the sharded form of NavBySceneFamiliarity.py:313-316);
+ * identical on every rank.  records[r * stride .. ] is rank r's record as laid out by dv_step_record.  Host
+ * arithmetic only: no context, no GPU.  When ranks that contend for the maximum (approx_max within delta of the
+ * global one) hold more than one candidate pair between them and one of them has not re-scored its candidates yet,
+ * needs_resolve is set and no decision is made: those ranks (contending_mask, bit r = rank r, world <= 64) run
+ * dv_resolve_enqueue and the records are exchanged again.
+ */
+typedef struct dv_merge_out {
+    int32_t best_heading;
+    int32_t resolved;           /* 1: exact values decided; 0: a single candidate pair, integer scores decided */
+    int64_t best_view;
+    double best_fam;
+    int32_t needs_resolve;
+    int32_t n_contending;
+    uint64_t contending_mask;
+    double angle_fam[DV_MAX_HEADINGS];
+} dv_merge_out;
+int dv_merge_records(const double *records, int world, int n_headings, int64_t stride, double delta, dv_merge_out *out);
 int dv_synchronize(dv_ctx *ctx);
 
 /* ---- measurement ------------------------------------------------------- */

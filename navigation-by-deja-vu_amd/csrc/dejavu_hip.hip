@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -76,6 +77,10 @@ struct dv_ctx {
     bool step_pending = false;
     bool patches_sensed = false;              // resident patches were produced by k_sense (its error flag is live)
     int seq = 0;                              // sequence number of the last enqueued pass (written back by k_tail)
+    double* h_pub = nullptr;                  // mapped host buffer of dv_publish: [8 doubles: sequence word][payload]
+    double* d_pub = nullptr;                  // its device address
+    int64_t pub_cap = 0;                      // payload capacity in doubles
+    unsigned long long pub_seq = 0;
     int spin_wait = 1;                        // poll the mapped result record instead of blocking on the stream (DEJAVU_SPIN)
     bool last_want_scene = false;
     double delta = 0.0;
@@ -178,6 +183,7 @@ extern "C" void dv_destroy(dv_ctx* c) {
     if (c->d_poses) (void)hipFree(c->d_poses);
     if (c->d_sense) (void)hipFree(c->d_sense);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->h_pub) (void)hipHostFree(c->h_pub);
     for (auto e : c->pev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -195,6 +201,119 @@ extern "C" int dv_set_stream(dv_ctx* c, void* s) {
 extern "C" int dv_set_exact(dv_ctx* c, int exact) {
     if (!c) return DV_ERR_INVALID;
     c->exact = exact ? 1 : 0;
+    return DV_OK;
+}
+
+extern "C" int dv_publish(dv_ctx* c, const void* device_src, int64_t n) {
+    if (!c) return DV_ERR_INVALID;
+    if (!device_src || n < 1 || n > (1 << 20)) return fail(c, DV_ERR_INVALID, "dv_publish: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > c->pub_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->h_pub) (void)hipHostFree(c->h_pub);
+        c->h_pub = nullptr;
+        c->pub_cap = 0;
+        HIP_TRY(c, hipHostMalloc(&c->h_pub, (size_t)(n + 8) * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_pub, c->h_pub, 0));
+        memset(c->h_pub, 0, (size_t)(n + 8) * sizeof(double));
+        c->pub_cap = n;
+    }
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, (const double*)device_src, c->d_pub + 8,
+                       (unsigned long long*)c->d_pub, (int)n, ++c->pub_seq);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+extern "C" int dv_publish_wait(dv_ctx* c, double* dst, int64_t n) {
+    if (!c) return DV_ERR_INVALID;
+    if (!dst || n < 1 || n > c->pub_cap || !c->h_pub) return fail(c, DV_ERR_STATE, "dv_publish_wait: nothing published");
+    volatile const unsigned long long* word = (volatile const unsigned long long*)c->h_pub;
+    bool seen = false;
+    if (c->spin_wait) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (!(seen = (*word == c->pub_seq))) {
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+    }
+    if (!seen) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (*word != c->pub_seq) return fail(c, DV_ERR_STATE, "dv_publish_wait: the published sequence word never arrived");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(dst, c->h_pub + 8, (size_t)n * sizeof(double));
+    return DV_OK;
+}
+
+// Host arithmetic of the sharded decision; mirrors navsim_amd/sharded.py (needs_resolve + merge_records), which the
+// CPU tests compare it with on random records.
+extern "C" int dv_merge_records(const double* rec, int world, int A, int64_t stride, double delta, dv_merge_out* out) {
+    if (!rec || !out || world < 1 || world > 64 || A < 1 || A > kMaxHeadings || stride < 3 + 4 * (int64_t)A) return DV_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    auto R = [&](int r, int64_t i) { return rec[(int64_t)r * stride + i]; };
+    double gmax = R(0, 0);
+    for (int r = 1; r < world; ++r) if (R(r, 0) > gmax) gmax = R(r, 0);
+    long long total = 0;
+    bool unresolved = false;
+    for (int r = 0; r < world; ++r) {
+        if (R(r, 0) >= gmax - delta) {
+            out->contending_mask |= 1ull << r;
+            out->n_contending++;
+            total += (long long)R(r, 1);
+            if (R(r, 2) == 0.0) unresolved = true;
+        }
+    }
+    // per-heading maxima of the integer-sum scores over ALL ranks, first rank on ties
+    int owner[kMaxHeadings];
+    for (int a = 0; a < A; ++a) {
+        double m = R(0, 3 + a);
+        int o = 0;
+        for (int r = 1; r < world; ++r) if (R(r, 3 + a) > m) { m = R(r, 3 + a); o = r; }
+        out->angle_fam[a] = m;
+        owner[a] = o;
+    }
+    if (total > 1 && unresolved) {
+        out->needs_resolve = 1;
+        return DV_OK;
+    }
+    if (total <= 1) {
+        int best = 0;
+        for (int a = 1; a < A; ++a) if (out->angle_fam[a] > out->angle_fam[best]) best = a;     // first maximum
+        out->best_heading = best;
+        out->best_view = (int64_t)R(owner[best], 3 + A + best);
+        out->best_fam = out->angle_fam[best];
+        return DV_OK;
+    }
+    const double ninf = -std::numeric_limits<double>::infinity();
+    double ex_a[kMaxHeadings];
+    for (int a = 0; a < A; ++a) {
+        double m = ninf;
+        for (int r = 0; r < world; ++r) {
+            if (!((out->contending_mask >> r) & 1)) continue;
+            const double v = (R(r, 2) == 2.0) ? R(r, 3 + a) : R(r, 3 + 2 * A + a);
+            if (v > m) m = v;
+        }
+        ex_a[a] = m;
+    }
+    int best = 0;
+    for (int a = 1; a < A; ++a) if (ex_a[a] > ex_a[best]) best = a;                               // first maximum
+    int64_t best_view = -1;
+    bool have = false;
+    for (int r = 0; r < world; ++r) {
+        if (!((out->contending_mask >> r) & 1)) continue;
+        const bool all_exact = R(r, 2) == 2.0;
+        const double v = all_exact ? R(r, 3 + best) : R(r, 3 + 2 * A + best);
+        if (v == ex_a[best]) {
+            const int64_t f = (int64_t)(all_exact ? R(r, 3 + A + best) : R(r, 3 + 3 * A + best));
+            if (!have || f < best_view) { best_view = f; have = true; }
+        }
+    }
+    for (int a = 0; a < A; ++a) if (std::isfinite(ex_a[a])) out->angle_fam[a] = ex_a[a];
+    out->best_heading = best;
+    out->best_view = best_view;
+    out->best_fam = ex_a[best];
+    out->resolved = 1;
     return DV_OK;
 }
 

@@ -659,6 +659,17 @@ k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, do
     }
 }
 
+// ------------------------------------------------------------------ device -> host hand-over without a stream wait
+// Copies n doubles to mapped host memory, then the sequence word (system scope, after everything else).
+__global__ void __launch_bounds__(256)
+k_publish(const double* __restrict__ src, double* __restrict__ dst, unsigned long long* __restrict__ flag, int n,
+          unsigned long long seq) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------ exact (sequential fp64) scoring
 // fam[a][f] = the reference's value bit for bit: per-pixel terms in the reference's operation
 // order, accumulated sequentially in row-major pixel order (navsim/util.pyx:44-73).

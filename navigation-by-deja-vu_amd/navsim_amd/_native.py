@@ -63,6 +63,19 @@ class LibInfo(ctypes.Structure):
     ]
 
 
+class MergeOut(ctypes.Structure):
+    _fields_ = [
+        ("best_heading", ctypes.c_int32),
+        ("resolved", ctypes.c_int32),
+        ("best_view", ctypes.c_int64),
+        ("best_fam", ctypes.c_double),
+        ("needs_resolve", ctypes.c_int32),
+        ("n_contending", ctypes.c_int32),
+        ("contending_mask", ctypes.c_uint64),
+        ("angle_fam", ctypes.c_double * DV_MAX_HEADINGS),
+    ]
+
+
 _ctx_p = ctypes.c_void_p
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _f64p = ctypes.POINTER(ctypes.c_double)
@@ -107,6 +120,10 @@ PROTOTYPES = {
     "dv_step_wait": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult), _f64p]),
     "dv_step_record": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
     "dv_resolve_enqueue": (ctypes.c_int, [_ctx_p]),
+    "dv_publish": (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int64]),
+    "dv_publish_wait": (ctypes.c_int, [_ctx_p, _f64p, ctypes.c_int64]),
+    "dv_merge_records": (ctypes.c_int, [_f64p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
+                                        ctypes.POINTER(MergeOut)]),
     "dv_synchronize": (ctypes.c_int, [_ctx_p]),
     "dv_timer_start": (ctypes.c_int, [_ctx_p]),
     "dv_timer_stop": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float)]),

@@ -321,6 +321,15 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_profile_read(self._ctx, ctypes.byref(tot), ctypes.byref(n)), "dv_profile_read")
         return float(tot.value), int(n.value)
 
+    def publish(self, device_ptr, n_doubles):
+        """Enqueue the hand-over of a device buffer of doubles to the host (no stream wait), see dv_publish."""
+        self._check(self._lib.dv_publish(self._ctx, ctypes.c_void_p(int(device_ptr)), int(n_doubles)), "dv_publish")
+
+    def publish_wait(self, out):
+        """Poll for the last publish and copy it into `out` (float64, C-contiguous)."""
+        self._check(self._lib.dv_publish_wait(self._ctx, N.f64ptr(out), out.size), "dv_publish_wait")
+        return out
+
     def stream_read_gbps(self, n_bytes=1 << 30, iters=10):
         g = ctypes.c_double(0)
         self._check(self._lib.dv_stream_read_gbps(self._ctx, int(n_bytes), int(iters), ctypes.byref(g)),

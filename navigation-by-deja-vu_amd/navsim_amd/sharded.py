@@ -94,6 +94,29 @@ def merge_records(records, delta, n_headings):
                 angle_familiarity=out_fam, resolved=True)
 
 
+def merge_records_native(records, delta, n_headings):
+    """needs_resolve + merge_records in one call into the library (dv_merge_records, host arithmetic only).
+
+    Returns (again, ranks, decision): `again`/`ranks` as needs_resolve, `decision` as merge_records (None when
+    `again`).  The Python functions above are the readable statement of the same rules; tests compare the two.
+    """
+    from . import _native as N
+    lib = N.load()
+    records = np.ascontiguousarray(records, dtype=np.float64)
+    world, stride = records.shape
+    out = N.MergeOut()
+    rc = lib.dv_merge_records(N.f64ptr(records), world, int(n_headings), stride, float(delta), out)
+    if rc != 0:
+        raise N.EngineError("dv_merge_records failed (%d)" % rc)
+    mask = out.contending_mask
+    ranks = [r for r in range(world) if (mask >> r) & 1]
+    if out.needs_resolve:
+        return True, ranks, None
+    fam = np.frombuffer(out, dtype=np.float64, count=int(n_headings), offset=N.MergeOut.angle_fam.offset)
+    return False, ranks, dict(best_idex=out.best_heading, best_view=out.best_view, step_familiarity=out.best_fam,
+                              angle_familiarity=fam, resolved=bool(out.resolved))
+
+
 class ShardedFamiliarity(object):
     """One rank's share of a sharded library plus the per-step exchange.
 
@@ -224,20 +247,22 @@ class DeviceExchange(object):
         self.A = (n - 3) // 4
         self.record = torch.as_tensor(_DeviceArray(ptr, n), device=self.device)
         self.gathered = torch.empty(world_size * n, dtype=torch.float64, device=self.device)
-        self.host = torch.empty(world_size * n, dtype=torch.float64).pin_memory()
+        self.host = np.empty((world_size, n), dtype=np.float64)
         self.exchanges = 0
 
     def _gather(self):
+        # all-gather (RCCL) behind the step's kernels on the same stream, then the engine's own hand-over kernel:
+        # the host polls one sequence word instead of blocking on the stream
         self._dist.all_gather_into_tensor(self.gathered, self.record)
-        self.host.copy_(self.gathered, non_blocking=True)
-        self.stream.synchronize()
+        self.engine.publish(self.gathered.data_ptr(), self.world * self.n)
+        self.engine.publish_wait(self.host)
         self.exchanges += 1
-        return self.host.numpy().reshape(self.world, self.n)
+        return self.host
 
     def step(self):
         self.engine.step_enqueue(want_scene=False)
         records = self._gather()
-        again, ranks = needs_resolve(records, self.delta)
+        again, ranks, out = merge_records_native(records, self.delta, self.A)
         if again:
             if self.rank in ranks and records[self.rank, 2] == 0.0:
                 if records[self.rank, 1] > CANDIDATE_CAP:
@@ -248,7 +273,10 @@ class DeviceExchange(object):
                 else:
                     self.engine.resolve_enqueue()
             records = self._gather()
-        return merge_records(records, self.delta, self.A)
+            again, ranks, out = merge_records_native(records, self.delta, self.A)
+            if again:
+                raise RuntimeError("contending ranks %r did not resolve their candidates" % (ranks,))
+        return out
 
 
 def step_resident(engine, gather, rank):

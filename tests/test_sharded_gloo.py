@@ -181,3 +181,40 @@ def test_merge_rules_on_hand_made_records():
     with pytest.raises(RuntimeError):
         sharded.merge_records(np.stack([rec(10.0, 2, 0, [10.0, 1, 1], [1, 2, 3]), rec(10.0, 1, 0, [10.0, 1, 1], [4, 5, 6])]),
                               delta, A)
+
+
+def test_native_merge_matches_python_rules():
+    """dv_merge_records (host C in the library, used by DeviceExchange) against the Python statement of the rules."""
+    rng = np.random.default_rng(7)
+    n_again = n_exact = n_plain = 0
+    for trial in range(600):
+        world = int(rng.choice([1, 2, 3, 8]))
+        A = int(rng.choice([1, 5, 16]))
+        delta = 1e-9
+        rec = np.zeros((world, 3 + 4 * A + int(rng.integers(0, 3))))       # stride may exceed the record
+        levels = np.array([100.0, 100.0 + 5e-10, 100.0 - 4e-10, 99.0, 42.5])
+        for r in range(world):
+            ang = rng.choice(levels, size=A)
+            rec[r, 3:3 + A] = ang
+            rec[r, 0] = ang.max()
+            rec[r, 1] = rng.choice([1, 1, 1, 2, 5])
+            rec[r, 2] = rng.choice([0.0, 1.0, 1.0, 2.0])
+            rec[r, 3 + A:3 + 2 * A] = rng.integers(0, 1000, A) + 1000 * r
+            ex = np.where(rng.random(A) < 0.5, ang + rng.choice([0.0, 1e-13, -1e-13], size=A), -np.inf)
+            ex[int(np.argmax(ang))] = ang.max() + rng.choice([0.0, 1e-13, -1e-13])
+            rec[r, 3 + 2 * A:3 + 3 * A] = ex
+            rec[r, 3 + 3 * A:3 + 4 * A] = np.where(np.isfinite(ex), rng.integers(0, 1000, A) + 1000 * r, -1)
+        again_py, ranks_py = sharded.needs_resolve(rec, delta)
+        again_c, ranks_c, out_c = sharded.merge_records_native(rec, delta, A)
+        assert again_c == again_py and ranks_c == ranks_py, trial
+        if again_py:
+            n_again += 1
+            assert out_c is None
+            continue
+        out_py = sharded.merge_records(rec, delta, A)
+        n_exact += out_py["resolved"]
+        n_plain += not out_py["resolved"]
+        assert out_c["best_idex"] == out_py["best_idex"] and out_c["best_view"] == out_py["best_view"], trial
+        assert out_c["step_familiarity"] == out_py["step_familiarity"] and out_c["resolved"] == out_py["resolved"], trial
+        np.testing.assert_array_equal(out_c["angle_familiarity"], out_py["angle_familiarity"])
+    assert n_again > 20 and n_exact > 20 and n_plain > 20, (n_again, n_exact, n_plain)
