@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--cpu-views", type=int, default=12288, help="views in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--agent-steps", type=int, default=300, help="steps of the full agent loop timed at N=1 (0 = skip)")
+    ap.add_argument("--event-every", type=int, default=4, help="bracket every n-th timed step's scoring kernel with "
+                    "HIP events (roofline.kernel_ms); 1 = every step")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank "
                     "(exercises the RCCL exchange path on a single GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
@@ -168,7 +170,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    eng.profile_kernel(True)
+    # HIP events around the scoring kernel on a sample of the timed steps: a pair costs ~5 us of stream time
+    eng.profile_kernel(True, every=args.event_every)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -221,7 +224,9 @@ def main():
                 "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
                 "bytes_per_pixel_reference": s_ref, "bytes_per_pixel_stored": info["n_planes"], "parallelism": "library sharded x%d" % world,
                 "exchange": "none" if not use_dist else "1 all-gather of per-heading records per step (%s)" % (
-                    "RCCL, device-resident" if args.backend == "nccl" else args.backend),
+                    ("RCCL ncclAllGather on the step's stream, device-resident"
+                     if (exchange is not None and exchange.direct is not None) else "RCCL via torch.distributed, device-resident")
+                    if args.backend == "nccl" else args.backend),
             },
             "nav_steps_per_s": args.steps / dt,
             "best_heading": int(res["best_idex"]),
@@ -248,6 +253,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if exchange is not None:
+        exchange.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -224,7 +224,8 @@ int dv_synchronize(dv_ctx *ctx);
 /* hipEvent pair on the context's stream around whatever is enqueued between the two calls. */
 int dv_timer_start(dv_ctx *ctx);
 int dv_timer_stop(dv_ctx *ctx, float *elapsed_ms);
-/* enable != 0: bracket every launch of the scoring kernel with hipEvents. */
+/* enable = n > 0: bracket every n-th launch of the scoring kernel with hipEvents (1 = every launch; an event pair
+ * costs a few microseconds of stream time, so throughput runs sample); 0: off. */
 int dv_profile_kernel(dv_ctx *ctx, int enable);
 /* Sum and count of the bracketed scoring-kernel launches since the last read; resets. */
 int dv_profile_read(dv_ctx *ctx, double *total_ms, int64_t *n_launches);

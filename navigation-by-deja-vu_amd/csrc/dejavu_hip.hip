@@ -99,7 +99,8 @@ struct dv_ctx {
 
     // measurement
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    int profile = 0;
+    int profile = 0;                          // dv_profile_kernel: bracket every profile-th scoring launch with events
+    long long profile_count = 0;
     std::vector<hipEvent_t> pev;              // pairs
     size_t pev_used = 0;
 };
@@ -1018,7 +1019,8 @@ static int launch_scoring(dv_ctx* c) {
         if (rc) return rc;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profile) {
+    const bool prof = c->profile > 0 && (c->profile_count++ % c->profile) == 0;
+    if (prof) {
         if (c->pev_used + 2 > c->pev.size()) {
             for (int i = 0; i < 2; ++i) {
                 hipEvent_t e;
@@ -1052,13 +1054,13 @@ static int launch_scoring(dv_ctx* c) {
                 return fail(c, DV_ERR_INVALID, "ssd_f32 scores at most 16 headings per step (got %d)", c->A);
             }
             HIP_TRY(c, hipGetLastError());
-            if (c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+            if (prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
             n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
             hipLaunchKernelGGL(k_combine_f32, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_fpart,
                                c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, c->n_agents);
             HIP_TRY(c, hipGetLastError());
         }
-        if (c->exact && c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+        if (c->exact && prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
         c->n_partial = n_partial;
         return DV_OK;
     }
@@ -1068,10 +1070,10 @@ static int launch_scoring(dv_ctx* c) {
         HIP_TRY(c, hipGetLastError());
         n_partial = (int)(g.Fpad / 64);
     } else {
-        rc = launch_int_scoring(c, c->profile ? e1 : nullptr, &n_partial);
+        rc = launch_int_scoring(c, prof ? e1 : nullptr, &n_partial);
         if (rc) return rc;
     }
-    if (c->exact && c->profile) HIP_TRY(c, hipEventRecord(e1, c->stream));
+    if (c->exact && prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->n_partial = n_partial;
     return DV_OK;
 }
@@ -1305,7 +1307,8 @@ extern "C" int dv_timer_stop(dv_ctx* c, float* ms) {
 
 extern "C" int dv_profile_kernel(dv_ctx* c, int enable) {
     if (!c) return DV_ERR_INVALID;
-    c->profile = enable ? 1 : 0;
+    c->profile = enable > 0 ? enable : 0;
+    c->profile_count = 0;
     c->pev_used = 0;
     return DV_OK;
 }

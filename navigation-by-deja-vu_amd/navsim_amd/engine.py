@@ -312,8 +312,9 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_timer_stop(self._ctx, ctypes.byref(ms)), "dv_timer_stop")
         return float(ms.value)
 
-    def profile_kernel(self, enable):
-        self._check(self._lib.dv_profile_kernel(self._ctx, 1 if enable else 0), "dv_profile_kernel")
+    def profile_kernel(self, enable, every=1):
+        """Bracket every `every`-th scoring-kernel launch with hipEvents (an event pair costs stream time)."""
+        self._check(self._lib.dv_profile_kernel(self._ctx, max(1, int(every)) if enable else 0), "dv_profile_kernel")
 
     def profile_read(self):
         tot = ctypes.c_double(0)

@@ -17,6 +17,9 @@ delta of the global maximum is "contending"; if the contending ranks hold more t
 candidate in total, they re-score their candidates with the exact sequential-double kernel
 (`resolve`) and a second all-gather carries the exact per-heading maxima.
 """
+import ctypes
+import os
+
 import numpy as np
 
 
@@ -217,6 +220,54 @@ def torch_gather(device=None):
     return gather
 
 
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+
+class DirectRccl(object):
+    """RCCL all-gather issued straight onto the engine's stream (ctypes into the librccl.so torch ships).
+
+    torch.distributed runs its collectives on a side stream and ties it to the caller's stream with two event
+    waits; for a 2 KB record behind a ~110 us step those hops are a visible share.  The communicator is created from
+    an ncclUniqueId that rank 0 makes and torch.distributed broadcasts; everything else (rendezvous, barriers,
+    timing) stays with torch.distributed.  Raises on any failure so that the caller can keep torch's path.
+    """
+
+    NCCL_FLOAT64 = 8
+
+    def __init__(self, rank, world_size):
+        import torch
+        import torch.distributed as dist
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = ctypes.CDLL(path)
+        self.lib.ncclGetErrorString.restype = ctypes.c_char_p
+        self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        self.lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+        uid = _NcclUniqueId()
+        if rank == 0:
+            self._ok(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        # raw bytes (a c_char array read through .value would stop at the first NUL)
+        box = [ctypes.string_at(ctypes.addressof(uid), 128) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctypes.memmove(ctypes.addressof(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self._ok(self.lib.ncclCommInitRank(ctypes.byref(self.comm), int(world_size), uid, int(rank)), "ncclCommInitRank")
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_gather_f64(self, send_ptr, recv_ptr, count, stream):
+        self._ok(self.lib.ncclAllGather(ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr), count, self.NCCL_FLOAT64,
+                                        self.comm, ctypes.c_void_p(stream)), "ncclAllGather")
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = ctypes.c_void_p()
+
+
 class _DeviceArray(object):
     """Minimal __cuda_array_interface__ carrier so that torch can wrap a raw device pointer without copying."""
 
@@ -249,11 +300,51 @@ class DeviceExchange(object):
         self.gathered = torch.empty(world_size * n, dtype=torch.float64, device=self.device)
         self.host = np.empty((world_size, n), dtype=np.float64)
         self.exchanges = 0
+        # RCCL on the engine's own stream when it can be set up on every rank (DEJAVU_DIRECT_RCCL=0: torch's path)
+        self.direct = None
+        if os.environ.get("DEJAVU_DIRECT_RCCL", "1") != "0":
+            torch.cuda.set_device(self.device)           # RCCL binds the communicator to the calling thread's device
+            try:
+                direct = DirectRccl(rank, world_size)
+                ok = 1
+            except Exception as e:                       # noqa: BLE001 - any failure means: use torch's collective
+                direct, ok = None, 0
+                self.direct_error = repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.direct = direct
+                self._self_test()
+            elif direct is not None:
+                direct.close()
+
+    def _self_test(self):
+        """One all-gather of the rank numbers through the direct communicator; falls back to torch's path on mismatch."""
+        torch = self._torch
+        send = torch.full((self.n,), float(self.rank), dtype=torch.float64, device=self.device)
+        self.direct.all_gather_f64(send.data_ptr(), self.gathered.data_ptr(), self.n, self.stream.cuda_stream)
+        self.stream.synchronize()
+        got = self.gathered.view(self.world, self.n)[:, 0].cpu().numpy()
+        ok = int(np.array_equal(got, np.arange(self.world, dtype=np.float64)))
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            self.direct.close()
+            self.direct = None
+
+    def close(self):
+        if self.direct is not None:
+            self.stream.synchronize()
+            self.direct.close()
+            self.direct = None
 
     def _gather(self):
         # all-gather (RCCL) behind the step's kernels on the same stream, then the engine's own hand-over kernel:
         # the host polls one sequence word instead of blocking on the stream
-        self._dist.all_gather_into_tensor(self.gathered, self.record)
+        if self.direct is not None:
+            self.direct.all_gather_f64(self.record.data_ptr(), self.gathered.data_ptr(), self.n, self.stream.cuda_stream)
+        else:
+            self._dist.all_gather_into_tensor(self.gathered, self.record)
         self.engine.publish(self.gathered.data_ptr(), self.world * self.n)
         self.engine.publish_wait(self.host)
         self.exchanges += 1
