@@ -826,10 +826,28 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     rec += (long long)agent * (3 + 4 * kMaxHeadings);
     fam += (long long)a0 * c.Fpad;
     pmax += (long long)a0 * n_partial;
-    // amax[a]: all partial maxima are fetched in one round of independent loads and folded with LDS atomics
-    if (threadIdx.x < kMaxHeadings) s_amax[threadIdx.x] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < A * n_partial; i += blockDim.x) atomicMax(&s_amax[i / n_partial], pmax[i]);
+    // amax[a]: wave w folds headings w, w+4, ...: lanes stride over the partial maxima with independent loads (eight
+    // in flight), then a shuffle reduction -- redundant in every block, but no grid-wide sync and no global atomics
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int a = wave; a < A; a += 4) {
+            const unsigned long long* row = pmax + (long long)a * n_partial;
+            unsigned long long m = 0;
+            for (int i0 = lane; i0 < n_partial; i0 += 64 * 8) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = row[(i0 + 64 * k < n_partial) ? i0 + 64 * k : n_partial - 1];   // clamped: a maximum does not mind repeats
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m = v[k] > m ? v[k] : m;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(m, o);
+                m = other > m ? other : m;
+            }
+            if (lane == 0) s_amax[a] = m;
+        }
+    }
     __syncthreads();
 
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
