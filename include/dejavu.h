@@ -96,7 +96,8 @@ int dv_create(dv_ctx **out, int device_id);
 void dv_destroy(dv_ctx *ctx);
 /* Message of the last failure on ctx (or of the last failed dv_create when ctx is NULL). */
 const char *dv_last_error(const dv_ctx *ctx);
-/* Run on a caller-provided hipStream_t (NULL restores the context's own stream). */
+/* Run on a caller-provided hipStream_t.  NULL restores the context's own stream, which is NON-BLOCKING: work on the
+ * legacy null stream is not ordered with it, so pass a real stream to order this context with other work. */
 int dv_set_stream(dv_ctx *ctx, void *hip_stream);
 /* exact != 0: every score is the reference's sequential-double value (slower fp64 kernel). */
 int dv_set_exact(dv_ctx *ctx, int exact);

@@ -278,9 +278,9 @@ class _DeviceArray(object):
 class DeviceExchange(object):
     """Per-step exchange that never leaves the GPU until the gathered records are complete.
 
-    The engine's kernels run on torch's current stream and leave this rank's packed record in device memory
-    (dv_step_record); `all_gather_into_tensor` (RCCL) is stream-ordered behind them, one pinned-memory copy brings
-    all ranks' records to the host, and there is ONE host synchronisation per step.  Cross-rank near-ties take a
+    The engine's kernels run on one stream and leave this rank's packed record in device memory (dv_step_record);
+    the RCCL all-gather is ordered behind them on the same stream, then the engine's hand-over kernel (dv_publish)
+    copies all ranks' records to mapped host memory, and the host polls ONE sequence word per exchange.  Cross-rank near-ties take a
     second round (dv_resolve_enqueue + all-gather), exactly like ShardedFamiliarity.step.
     """
 
@@ -290,7 +290,11 @@ class DeviceExchange(object):
         self._torch, self._dist = torch, dist
         self.engine, self.rank, self.world = engine, rank, world_size
         self.device = torch.device(device)
-        self.stream = torch.cuda.current_stream(self.device)
+        # A stream of its own, shared by the engine's kernels and the collective.  (torch's default stream has the null
+        # handle, which dv_set_stream reads as "the context's own stream" -- a non-blocking one the null stream does not
+        # order with: the all-gather could then read the record before k_tail has written it.)
+        self.stream = torch.cuda.Stream(device=self.device)
+        assert self.stream.cuda_stream != 0
         engine.set_stream(self.stream.cuda_stream)
         self.delta = engine.library_info()["delta"]
         ptr, n = engine.step_record()
@@ -322,6 +326,7 @@ class DeviceExchange(object):
         """One all-gather of the rank numbers through the direct communicator; falls back to torch's path on mismatch."""
         torch = self._torch
         send = torch.full((self.n,), float(self.rank), dtype=torch.float64, device=self.device)
+        torch.cuda.synchronize(self.device)              # `send` was filled on torch's current stream
         self.direct.all_gather_f64(send.data_ptr(), self.gathered.data_ptr(), self.n, self.stream.cuda_stream)
         self.stream.synchronize()
         got = self.gathered.view(self.world, self.n)[:, 0].cpu().numpy()
@@ -333,10 +338,11 @@ class DeviceExchange(object):
             self.direct = None
 
     def close(self):
+        self.stream.synchronize()
         if self.direct is not None:
-            self.stream.synchronize()
             self.direct.close()
             self.direct = None
+        self.engine.set_stream(None)                     # back to the context's own stream
 
     def _gather(self):
         # all-gather (RCCL) behind the step's kernels on the same stream, then the engine's own hand-over kernel:
@@ -344,7 +350,8 @@ class DeviceExchange(object):
         if self.direct is not None:
             self.direct.all_gather_f64(self.record.data_ptr(), self.gathered.data_ptr(), self.n, self.stream.cuda_stream)
         else:
-            self._dist.all_gather_into_tensor(self.gathered, self.record)
+            with self._torch.cuda.stream(self.stream):
+                self._dist.all_gather_into_tensor(self.gathered, self.record)
         self.engine.publish(self.gathered.data_ptr(), self.world * self.n)
         self.engine.publish_wait(self.host)
         self.exchanges += 1

@@ -1,0 +1,93 @@
+"""GPU tests of the multi-rank exchange path at world size 1 (one MI355X): the per-step record on the device, the
+hand-over kernel (dv_publish), the RCCL all-gather on the engine's stream and the native merge must reproduce the
+plain single-context step, ties included.  The N > 1 protocol itself is covered on CPU over gloo
+(tests/test_sharded_gloo.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import navsim_amd
+from navsim_amd import sharded, synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = navsim_amd.FamiliarityEngine(0)
+    yield e
+    e.close()
+
+
+def _library_with_ties():
+    lib = synth.synth_views(77, 900, 12, 12)
+    pats = synth.synth_patches(77, 7, 12, 12)
+    lib[500] = lib[40]                      # duplicate views: equal scores, first one must win
+    pats[3] = lib[40]
+    pats[5] = lib[40]                       # and two headings tie exactly: first heading wins
+    return lib, pats
+
+
+def test_publish_hands_the_step_record_to_the_host(eng):
+    lib, pats = _library_with_ties()
+    eng.set_library(lib, 0.3)
+    eng.upload_patches(pats)
+    eng.step_enqueue(want_scene=False)
+    res = eng.step_wait(want_scene=False)
+    ptr, n = eng.step_record()
+    assert n == 3 + 4 * len(pats)
+    for _ in range(3):                      # the sequence word advances with every publish
+        eng.publish(ptr, n)
+        got = eng.publish_wait(np.empty(n))
+    np.testing.assert_array_equal(got, sharded.pack_record(res))
+
+
+def test_device_exchange_single_rank_matches_plain_step(eng):
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for cw in (0.0, 0.3):
+            lib, pats = _library_with_ties()
+            want = oracle.step(lib, pats, cw)
+            eng.set_library(lib, cw)
+            eng.upload_patches(pats)
+            for direct in ("1", "0"):       # RCCL on the engine's stream, then torch.distributed's collective
+                os.environ["DEJAVU_DIRECT_RCCL"] = direct
+                ex = sharded.DeviceExchange(eng, 0, 1, torch.device("cuda", 0))
+                assert (ex.direct is not None) == (direct == "1")
+                for _ in range(3):
+                    out = ex.step()
+                assert out["best_idex"] == want["best_idex"] == 3
+                assert out["best_view"] == want["best_view"] == 40
+                np.testing.assert_allclose(out["step_familiarity"], want["step_familiarity"], rtol=1e-12)
+                np.testing.assert_allclose(out["angle_familiarity"], want["angle_familiarity"], rtol=1e-12)
+                assert ex.exchanges >= 3
+                ex.close()
+    finally:
+        os.environ.pop("DEJAVU_DIRECT_RCCL", None)
+        eng.set_stream(None)
+        dist.destroy_process_group()
+
+
+def test_agent_sharded_ensemble_on_the_engine(eng):
+    lib = synth.synth_views(5, 700, 16, 16)
+    pats = synth.synth_patches(5, 6 * 8, 16, 16).reshape(6, 8, 16, 16, 3).copy()
+    pats[4, 6] = lib[123]
+    ens = sharded.ShardedEnsemble(eng, 0, 1)
+    ens.set_library(lib, 0.25)
+    res = ens.step(pats)
+    assert len(res) == 6
+    for g, r in enumerate(res):
+        want = oracle.step(lib, pats[g], 0.25)
+        assert (r["best_idex"], r["best_view"]) == (want["best_idex"], want["best_view"])
+    assert (res[4]["best_idex"], res[4]["best_view"]) == (6, 123)
