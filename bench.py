@@ -181,6 +181,27 @@ def main():
     kern_ms_total, kern_n = eng.profile_read()
     eng.profile_kernel(False)
 
+    # Known-answer step, outside the timed region: heading a* looks at a view stored on the LAST rank, so the global
+    # decision has to come through the exchange (a stale or mis-ordered record gives the previous answer instead).
+    from navsim_amd import synth
+    a_star, f_star = A // 2, (world - 1) * F + (12345 % F)
+    probe = synth.synth_patches(args.seed, A, h, w)
+    probe[a_star] = synth.synth_views(args.seed, 1, h, w, first_view=f_star)[0]
+    eng.upload_patches(probe)
+    chk = one_step()
+    ok = (int(chk["best_idex"]), int(chk["best_view"])) == (a_star, f_star) and float(chk["step_familiarity"]) == float(h * w)
+    if not ok:
+        sys.stderr.write("rank %d: known-answer step FAILED\n" % rank)
+    if use_dist:                                                 # fail together: nobody is left waiting in a collective
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_ok = bool(flag.item())
+    else:
+        all_ok = ok
+    if not all_ok:
+        raise SystemExit("rank %d: known-answer step failed: got heading %d view %d familiarity %r, expected %d %d %r"
+                         % (rank, chk["best_idex"], chk["best_view"], chk["step_familiarity"], a_star, f_star, float(h * w)))
+
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -230,6 +251,7 @@ def main():
             },
             "nav_steps_per_s": args.steps / dt,
             "best_heading": int(res["best_idex"]),
+            "known_answer_step": "ok on every rank (heading %d, view %d of %d, through the exchange)" % (a_star, f_star, world * F),
             "roofline": {
                 "bound": "hbm", "kernel": "k_sad_tiles", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
