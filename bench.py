@@ -60,9 +60,19 @@ def cpu_baseline(h, w, A, cw, seed, budget_views):
     for a in range(A):
         oracle.sads_hsv(lib, patches[a], cw, fam)
     dt = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return dict(value=budget_views * A / dt, unit="view-comparisons/s", cores=1, kind="port",
                 sample="%d of the stored views x %d headings, %dx%d sensor, chem_weight %g, %.1f s of one host core; "
-                       "linear in views (util.pyx:44)" % (budget_views, A, w, h, cw, dt))
+                       "linear in views (util.pyx:44)" % (budget_views, A, w, h, cw, dt),
+                host_cpu=model, host_logical_cores=os.cpu_count())
 
 
 def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
@@ -101,7 +111,8 @@ def main():
     ap.add_argument("--chem-weight", type=float, default=0.25,
                     help="0 < cw < 1 keeps all three reference bytes per pixel (H,S,V) algorithmically live")
     ap.add_argument("--seed", type=int, default=20261004)
-    ap.add_argument("--cpu-views", type=int, default=12288, help="views in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-views", type=int, default=50000, help="views in the CPU-baseline sample (0 = skip); the "
+                    "default is the whole configs[1] library: ~12 s of one host core")
     ap.add_argument("--agent-steps", type=int, default=300, help="steps of the full agent loop timed at N=1 (0 = skip)")
     ap.add_argument("--event-every", type=int, default=4, help="bracket every n-th timed step's scoring kernel with "
                     "HIP events (roofline.kernel_ms); 1 = every step")
