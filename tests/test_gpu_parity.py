@@ -505,3 +505,39 @@ def test_ssd_f32_ties_and_duplicates(eng):
     p = np.stack([lib2[20], lib2[150] + np.float32(1e-3)])
     r = eng.step_f32(p)
     assert r["best_idex"] == 0 and r["best_view"] == 20 and r["step_ssd"] == 0.0
+
+
+@pytest.mark.parametrize("A", [5, 16, 30, 64])
+def test_every_workgroup_shape_gives_identical_results(A):
+    """k_sad_tiles' workgroup shapes (1 single-wave, 2 four waves + LDS sums, 3/4 heading ways, 5 packed accumulators;
+    csrc/dejavu_hip.hip:launch_tiles_apad) are normally chosen by timing; forced one by one they must produce the same
+    integer sums, hence bit-identical scores and the reference's decision."""
+    import os
+    F, h, w, cw = 1500, 20, 24, 0.25
+    lib = synth.synth_views(91, F, h, w)
+    pats = synth.synth_patches(91, A, h, w)
+    pats[A // 2] = synth.near_match_patch(lib[777], 5)
+    want = oracle.step(lib, pats, cw)
+    fams = {}
+    try:
+        for shape in (1, 2, 3, 4, 5, 0):
+            os.environ["DEJAVU_SHAPE"] = str(shape)
+            e = navsim_amd.FamiliarityEngine(0)
+            try:
+                e.set_library(lib, cw)
+                info = e.library_info()
+                assert info["n_planes"] == 2 and info["signed_saturation"] == 1      # both sums live: shape 5 is valid
+                r = e.step(pats, want_scene=False)
+                assert (r["best_idex"], r["best_view"]) == (want["best_idex"], want["best_view"]), shape
+                fams[shape] = np.array(r["angle_familiarity"])
+                buf = np.empty(F)
+                e.score(pats[0], buf)
+                fams[(shape, "score")] = buf
+            finally:
+                e.close()
+    finally:
+        os.environ.pop("DEJAVU_SHAPE", None)
+    for shape in (2, 3, 4, 5, 0):
+        np.testing.assert_array_equal(fams[shape], fams[1])
+        np.testing.assert_array_equal(fams[(shape, "score")], fams[(1, "score")])
+    np.testing.assert_allclose(fams[1], want["angle_familiarity"], rtol=1e-12)
