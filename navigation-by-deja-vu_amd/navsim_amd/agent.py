@@ -233,6 +233,7 @@ class NavBySceneFamiliarity(object):
                 self.familiar_scenes[i] = self.get_sensor_mat(points[i], view_headings[i])
 
         self.scene_familiarity = np.zeros(n, dtype=np.float64)
+        self._scene_is_inf = False
         self.training_path = points
         self.reset_error()
         # library hand-off (:140): already resident when the views were sensed on the GPU
@@ -252,6 +253,7 @@ class NavBySceneFamiliarity(object):
         self.familiar_scenes = None
         self._familiarity_func = None
         self.scene_familiarity = None
+        self._scene_is_inf = False
         self.training_path_length = None
 
     # ---- sensor (:151-192) ---------------------------------------------------------------------
@@ -337,29 +339,41 @@ class NavBySceneFamiliarity(object):
     def step_forward(self, fake=False):
         position = self.position
         self.angle_familiarity[:] = np.nan
-        self.scene_familiarity[:] = np.inf
         assert len(self.familiar_scenes) == len(self.scene_familiarity)
 
         func = self._familiarity_func
         engine = getattr(func, "engine", None)
         if engine is not None:
             # one fused device step for all headings: kernel + min-merge + max + argmax (:289-315)
-            if engine is self._engine:
-                # patches are sensed on the GPU, straight into the scoring kernel's operand layout
-                self._check_bounds(position)
-                res = engine.sense_step(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi),
-                                        want_scene=self.track_scene_familiarity)
-            else:
-                patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)
-                for a_idex, angle_offset in enumerate(self.angle_offsets):
-                    patches[a_idex] = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
-                res = engine.step(patches, want_scene=self.track_scene_familiarity)
+            try:
+                if engine is self._engine:
+                    # patches are sensed on the GPU, straight into the scoring kernel's operand layout
+                    self._check_bounds(position)
+                    res = engine.sense_step(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi),
+                                            want_scene=self.track_scene_familiarity)
+                else:
+                    patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)
+                    for a_idex, angle_offset in enumerate(self.angle_offsets):
+                        patches[a_idex] = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
+                    res = engine.step(patches, want_scene=self.track_scene_familiarity)
+            except Exception:
+                # the reference resets scene_familiarity to +inf before it senses (:287); a step that stops here
+                # leaves it so.  (A completed step overwrites every entry, so the fill is not paid per step.)
+                self.scene_familiarity[:] = np.inf
+                self._scene_is_inf = True
+                raise
             self.angle_familiarity[:] = res["angle_familiarity"]
             if self.track_scene_familiarity:
                 self.scene_familiarity[:] = res["scene_familiarity"]
+                self._scene_is_inf = False
+            elif not self._scene_is_inf:
+                self.scene_familiarity[:] = np.inf              # not tracked: stays at the reference's reset value
+                self._scene_is_inf = True
             best_idex = res["best_idex"]
         else:
             # any other plug-in: the reference's loop, one model call per heading
+            self.scene_familiarity[:] = np.inf
+            self._scene_is_inf = False
             temp_fam = np.empty_like(self.scene_familiarity)
             for a_idex, angle_offset in enumerate(self.angle_offsets):
                 smat = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
