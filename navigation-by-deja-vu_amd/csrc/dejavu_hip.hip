@@ -49,7 +49,8 @@ struct dv_ctx {
     // per-step buffers (sized at set_library)
     unsigned char* d_raw_patches = nullptr;   // [64][P][3]
     unsigned* d_prep = nullptr;               // [npl][Q][4][64]
-    int* d_hsconst = nullptr;                 // [64]
+    int* d_hsconst_pair = nullptr;            // [2][64]: the sensed path alternates (k_sense_prep clears the other one)
+    int* d_hsconst = nullptr;                 // the buffer of the resident patches
     unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
     unsigned long long* d_pmax = nullptr;     // [64][max(G, Fpad/256)] partial maxima
     int n_partial = 0;                        // partial maxima per heading left in d_pmax by the last scoring
@@ -94,7 +95,9 @@ struct dv_ctx {
     size_t poses_cap = 0;
     unsigned char* d_sense = nullptr;         // [n][sh][sw][3] scratch for dv_sense
     size_t sense_cap = 0;
-    int* d_err = nullptr;
+    int* d_err = nullptr;                     // [3]: [0],[1] alternate with d_hsconst_pair, [2] is k_sense's
+    int sense_parity = 0;
+    bool hsconst_dirty = false;               // k_prep (uploaded patches) wrote constants into d_hsconst
     std::vector<Pose> h_poses;
 
     // measurement
@@ -125,7 +128,7 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
 
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst); F(c->d_fam); F(c->d_scene);
+    F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
     c->metric = 0;
@@ -367,7 +370,8 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_tiles, c->tile_bytes));
     HIP_TRY(c, hipMalloc(&c->d_raw_patches, (size_t)kMaxHeadings * g.P * 3));
     HIP_TRY(c, hipMalloc(&c->d_prep, (size_t)g.npl * g.Q * 4 * kMaxHeadings * sizeof(unsigned)));
-    HIP_TRY(c, hipMalloc(&c->d_hsconst, kMaxHeadings * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_hsconst_pair, 2 * kMaxHeadings * sizeof(int)));
+    c->d_hsconst = c->d_hsconst_pair;
     // Work items = (pixel chunk, view group).  The chunk count is chosen per launch (scoring_grid); the partial-sum
     // buffer is sized for the most chunks a launch can ask for.
     {
@@ -392,7 +396,7 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_result, c->h_result, 0));
     memset(c->h_result, 0, kMaxHeadings * sizeof(StepResultDev));
     HIP_TRY(c, hipHostMalloc(&c->h_scene, (size_t)g.Fpad * sizeof(double)));
-    HIP_TRY(c, hipMemsetAsync(c->d_hsconst, 0, kMaxHeadings * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_hsconst_pair, 0, 2 * kMaxHeadings * sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_state, 0, kMaxHeadings * sizeof(StepState), c->stream));
     c->have_lib = true;
     return DV_OK;
@@ -568,7 +572,10 @@ extern "C" int dv_configure_sensor(dv_ctx* c, int sw, int sh, int pw, int ph, co
     if (mask_n < 0 || mask_n > sw / 2) return fail(c, DV_ERR_INVALID, "mask_middle_n %d outside [0, %d]", mask_n, sw / 2);
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->d_lut) HIP_TRY(c, hipMalloc(&c->d_lut, 768));
-    if (!c->d_err) HIP_TRY(c, hipMalloc(&c->d_err, sizeof(int)));
+    if (!c->d_err) {
+        HIP_TRY(c, hipMalloc(&c->d_err, 3 * sizeof(int)));
+        HIP_TRY(c, hipMemsetAsync(c->d_err, 0, 3 * sizeof(int), c->stream));
+    }
     HIP_TRY(c, hipMemcpyAsync(c->d_lut, lut, 768, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->sensor.sw = sw; c->sensor.sh = sh; c->sensor.pw = pw; c->sensor.ph = ph; c->sensor.mask_n = mask_n;
@@ -591,18 +598,18 @@ static int enqueue_sense(dv_ctx* c, const double* x, const double* y, const doub
         const double rot = -(0.5 * M_PI - angle[i]);
         c->h_poses[(size_t)i] = Pose{x[i], y[i], std::cos(rot), std::sin(rot)};
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_err + 2, 0, sizeof(int), c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), (size_t)n * sizeof(Pose), hipMemcpyHostToDevice, c->stream));
     const long long total = n * c->sensor.sh * c->sensor.sw;
     hipLaunchKernelGGL(k_sense, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, c->d_poses, (int)n,
-                       c->sensor, c->d_lut, d_out, c->d_err);
+                       c->sensor, c->d_lut, d_out, c->d_err + 2);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
 
 static int check_sense_error(dv_ctx* c) {
     int err = 0;
-    HIP_TRY(c, hipMemcpyAsync(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&err, c->d_err + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (err) return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)");
     return DV_OK;
@@ -640,28 +647,29 @@ extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* ang
     if (c->sensor.sw != c->w || c->sensor.sh != c->h)
         return fail(c, DV_ERR_STATE, "sensor is %dx%d but the library holds %dx%d views", c->sensor.sw, c->sensor.sh, c->w, c->h);
     HIP_TRY(c, hipSetDevice(c->device));
-    // poses (cos/sin from the host's libm), then ONE kernel that senses and lays the patches out for the scoring kernel
-    if ((size_t)A > c->poses_cap) {
-        if (c->d_poses) (void)hipFree(c->d_poses);
-        c->d_poses = nullptr;
-        c->poses_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_poses, (size_t)kMaxHeadings * sizeof(Pose)));
-        c->poses_cap = kMaxHeadings;
-    }
-    c->h_poses.resize((size_t)A);
+    // poses (cos/sin from the host's libm) by value, then ONE kernel that senses and lays the patches out for the
+    // scoring kernel; no copy and no memset on the way (see k_sense_prep)
+    PoseSet poses;
     for (int a = 0; a < A; ++a) {
         const double rot = -(0.5 * M_PI - angles[a]);
-        c->h_poses[(size_t)a] = Pose{x, y, std::cos(rot), std::sin(rot)};
+        poses.p[a] = Pose{x, y, std::cos(rot), std::sin(rot)};
     }
+    for (int a = A; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
     c->A = A; c->n_agents = 1; c->A_agent = A;
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
-    HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_hsconst, 0, kMaxHeadings * sizeof(int), c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), (size_t)A * sizeof(Pose), hipMemcpyHostToDevice, c->stream));
+    if (c->hsconst_dirty) {
+        // uploaded patches left their constants in the buffer this step would add into
+        HIP_TRY(c, hipMemsetAsync(c->d_hsconst_pair, 0, 2 * kMaxHeadings * sizeof(int), c->stream));
+        c->hsconst_dirty = false;
+    }
+    c->sense_parity ^= 1;
+    const int cur = c->sense_parity, nxt = cur ^ 1;
+    c->d_hsconst = c->d_hsconst_pair + cur * kMaxHeadings;
     // (prep entries of the padded headings A..APAD-1 are left as they are: their sums are never read)
     const long long total = (long long)A * c->cfg.Q * 4;
-    hipLaunchKernelGGL(k_sense_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, c->d_poses, A,
-                       c->sensor, c->d_lut, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, c->APAD, c->d_err);
+    hipLaunchKernelGGL(k_sense_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, poses, A,
+                       c->sensor, c->d_lut, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, c->APAD, c->d_err + cur,
+                       c->d_hsconst_pair + nxt * kMaxHeadings, c->d_err + nxt);
     HIP_TRY(c, hipGetLastError());
     c->patches_sensed = true;      // no host synchronisation here: the step's result record carries the error flag
     return DV_OK;
@@ -768,6 +776,7 @@ static int prep_patches(dv_ctx* c, int A) {
     c->n_agents = 1;
     c->A_agent = A;
     c->patches_sensed = false;
+    c->hsconst_dirty = true;                  // k_prep writes this step's constants where the sensed path accumulates
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
     const long long total = (long long)c->cfg.npl * c->cfg.Q * 4 * c->APAD;
     const unsigned nb = (unsigned)((total + 255) / 256);
@@ -1087,7 +1096,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
                        c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
                        c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force, ++c->seq,
-                       c->patches_sensed ? c->d_err : nullptr, c->metric == 1 ? 3e-6 : 0.0);
+                       c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->metric == 1 ? 3e-6 : 0.0);
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
         HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -1328,10 +1328,21 @@ __device__ __forceinline__ bool sense_pixel(const unsigned char* __restrict__ la
     return true;
 }
 
+// The headings' poses travel as a kernel argument (64 x 32 bytes): no host-to-device copy on the step's path.
+struct PoseSet { Pose p[kMaxHeadings]; };
+
+// hsconst / err are this step's accumulators (added into with atomics, so they must start at zero); next_hsconst /
+// next_err are the OTHER buffers of their pairs, which nothing uses during this step: block 0 clears them for the
+// next sensed step, so that no memset sits on a step's path.
 __global__ void __launch_bounds__(256)
-k_sense_prep(const unsigned char* __restrict__ land, const Pose* __restrict__ poses, int A, SensorCfg g,
+k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A, SensorCfg g,
              const unsigned char* __restrict__ lut, unsigned char* __restrict__ raw, unsigned* __restrict__ prep,
-             int* __restrict__ hsconst, LibCfg c, int APAD, int* __restrict__ err) {
+             int* __restrict__ hsconst, LibCfg c, int APAD, int* __restrict__ err, int* __restrict__ next_hsconst,
+             int* __restrict__ next_err) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kMaxHeadings) next_hsconst[threadIdx.x] = 0;
+        if (threadIdx.x == 0) *next_err = 0;
+    }
     const int ngroups = c.Q * 4;                           // groups of 4 pixels, incl. the zero padding
     const long long total = (long long)A * ngroups;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1340,7 +1351,7 @@ k_sense_prep(const unsigned char* __restrict__ land, const Pose* __restrict__ po
     if (t < total) {
         a = (int)(t / ngroups);                            // heading-major: a wave never straddles two headings
         const int grp = (int)(t % ngroups);                //   when ngroups is a multiple of 64; handled below otherwise
-        const Pose p = poses[a];
+        const Pose p = poses.p[a];
         unsigned w[kMaxHues + 1];
         for (int pl = 0; pl < c.npl; ++pl) w[pl] = 0;
         for (int i = 0; i < 4; ++i) {
