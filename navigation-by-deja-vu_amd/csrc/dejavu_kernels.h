@@ -826,9 +826,15 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     rec += (long long)agent * (3 + 4 * kMaxHeadings);
     fam += (long long)a0 * c.Fpad;
     pmax += (long long)a0 * n_partial;
-    // amax[a]: wave w folds headings w, w+4, ...: lanes stride over the partial maxima with independent loads (eight
-    // in flight), then a shuffle reduction -- redundant in every block, but no grid-wide sync and no global atomics
-    {
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // amax[a], redundantly in every block (no grid-wide sync, no global atomics).  Many partial maxima (one per view
+    // group after k_exact_all): wave w folds headings w, w+4, ...; lanes stride over them with eight loads in flight
+    if (A * n_partial <= 4096) {
+        // few partial maxima (k_combine's per-block ones): one round of independent loads, folded with LDS atomics
+        if (threadIdx.x < kMaxHeadings) s_amax[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < A * n_partial; i += blockDim.x) atomicMax(&s_amax[i / n_partial], pmax[i]);
+    } else {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int a = wave; a < A; a += 4) {
             const unsigned long long* row = pmax + (long long)a * n_partial;
@@ -850,7 +856,6 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     }
     __syncthreads();
 
-    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (f < c.F) {
         unsigned long long gkey = 0;
         for (int a = 0; a < A; ++a) gkey = s_amax[a] > gkey ? s_amax[a] : gkey;
@@ -877,14 +882,15 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
         if (want_scene) scene[f] = smin;
     }
 
-    // Arrival ticket: every wave drains its own stores/atomics, one lane publishes (release, agent scope).
+    // Arrival ticket.  Everything the last block reads from the others (aview[], ncand) was written with device-scope
+    // atomics, which are performed at the device's coherence point, and every wave waits for its own to be
+    // acknowledged before the workgroup's ticket is taken; the plain stores (cand[], scene[]) are only read after
+    // the kernel boundary.  So no release fence here and no acquire in the last block: on this multi-XCD part they
+    // are an L2 write-back / invalidate each (-1.5 us per step; tools/stress_tail.py checks the decisions of 4000
+    // steps x 196 blocks against known answers).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;
-    }
+    if (threadIdx.x == 0) s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
 
@@ -892,7 +898,6 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     // (the record lives in mapped host memory: a few PCIe writes instead of one per field).
     __shared__ StepResultDev s_res;
     __shared__ unsigned long long s_aview[kMaxHeadings];
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (threadIdx.x < A) {
         st->amax[threadIdx.x] = s_amax[threadIdx.x];                            // for k_decide on the resolve path
         s_aview[threadIdx.x] = __hip_atomic_load(&st->aview[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
