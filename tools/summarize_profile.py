@@ -8,28 +8,42 @@ the read side is doubled; WRITE_SIZE is exact for 4..16-byte-per-lane streaming 
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
 
+def biggest(pattern):
+    """rocprofv3 writes one file set per process; the bench process has the largest."""
+    f = glob.glob(pattern)
+    return max(f, key=os.path.getsize) if f else None
+
+
 def kernel_stats(d):
-    f = glob.glob(d + "/trace/*/*kernel_stats.csv")
+    f = biggest(d + "/trace/*/*kernel_stats.csv")
     out = []
     if f:
-        for r in csv.DictReader(open(f[0])):
+        for r in csv.DictReader(open(f)):
             out.append(dict(name=r["Name"].split("(")[0], calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
                             min_us=float(r["MinNs"]) / 1e3, max_us=float(r["MaxNs"]) / 1e3, pct=float(r["Percentage"])))
     return out
 
 
 def counters(d, sub, kernel_substr):
-    f = glob.glob(d + "/" + sub + "/*/*counter_collection.csv")
-    agg = defaultdict(list)
+    """Per-launch averages of the counters of ONE kernel: of the instantiations whose name contains `kernel_substr`
+    the one dispatched most often (the timed steps' workgroup shape, not the few launches that time the others)."""
+    f = biggest(d + "/" + sub + "/*/*counter_collection.csv")
+    per_name = defaultdict(lambda: defaultdict(list))
     if f:
-        for r in csv.DictReader(open(f[0])):
+        for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+                per_name[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not per_name:
+        return {}
+    name = max(per_name, key=lambda n: max(len(v) for v in per_name[n].values()))
+    out = {k: sum(v) / len(v) for k, v in per_name[name].items()}
+    out["kernel_name"] = name.split("(")[0]
+    return out
 
 
 def main():
