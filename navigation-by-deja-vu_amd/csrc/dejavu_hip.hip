@@ -13,6 +13,7 @@
 #include <cmath>
 #include <limits>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,7 +23,8 @@
 
 using namespace dv;
 
-static_assert(sizeof(StepResultDev) == sizeof(dv_step_result), "device/host result records differ");
+static_assert(sizeof(StepResultDev) == sizeof(dv_step_result) + sizeof(unsigned long long) &&
+              offsetof(StepResultDev, check) == sizeof(dv_step_result), "device record = host record + check word");
 static_assert(kMaxHeadings == DV_MAX_HEADINGS && kMaxHues == DV_MAX_HUE_PLANES, "header constants differ");
 
 static thread_local std::string g_create_error;
@@ -1136,10 +1138,22 @@ extern "C" int dv_step_enqueue(dv_ctx* c, uint32_t flags) {
 // system-scope release, so once all agents show the current sequence number their records are complete.
 static bool spin_for_results(dv_ctx* c) {
     const auto t0 = std::chrono::steady_clock::now();
+    const int A = c->A_agent;
     for (int ag = 0; ag < c->n_agents; ++ag) {
         volatile const int* word = &c->h_result[ag].reserved;
+        volatile const unsigned long long* w = reinterpret_cast<volatile const unsigned long long*>(&c->h_result[ag]);
         unsigned spins = 0;
-        while (*word != c->seq) {
+        for (;;) {
+            if (*word == c->seq) {
+                // k_tail stores the record without a fence: take it only when its check word agrees with its words
+                std::atomic_thread_fence(std::memory_order_acquire);
+                unsigned long long snap[7 + 4 * kMaxHeadings];
+                for (int i = 0; i < 7; ++i) snap[i] = w[i];
+                for (int k = 0; k < 4; ++k)
+                    for (int a = 0; a < A; ++a) snap[7 + k * kMaxHeadings + a] = w[7 + k * kMaxHeadings + a];
+                const unsigned long long check = *reinterpret_cast<volatile const unsigned long long*>(&c->h_result[ag].check);
+                if ((int)(snap[6] >> 32) == c->seq && record_check(snap, A) == check) break;
+            }
             if ((++spins & 1023u) == 0 &&
                 std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;   // fall back
         }

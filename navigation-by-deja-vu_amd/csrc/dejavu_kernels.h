@@ -733,7 +733,19 @@ struct StepResultDev {                   // mirrors dv_step_result (include/deja
     long long angle_view[kMaxHeadings];
     double exact_fam[kMaxHeadings];
     long long exact_view[kMaxHeadings];
+    unsigned long long check;                // internal (not in dv_step_result): XOR of the words k_tail wrote, see record_check
 };
+// Words of a record that k_tail writes for A headings: the header (7 x 8 bytes, word 6 = n_headings | seq << 32) and
+// the first A entries of the four per-heading arrays.  k_tail stores them and their XOR without any fence; the
+// host, polling the sequence number, accepts the record only when the XOR matches (words still in flight make it
+// differ) -- a system-scope fence between payload and flag costs a round trip to host memory on every step.
+__host__ __device__ inline unsigned long long record_check(const unsigned long long* w, int A) {
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 7; ++i) x ^= w[i] * (unsigned long long)(2 * i + 3);
+    for (int k = 0; k < 4; ++k)
+        for (int a = 0; a < A; ++a) x ^= w[7 + k * kMaxHeadings + a] * (unsigned long long)(2 * (7 + k * kMaxHeadings + a) + 3);
+    return x;
+}
 constexpr unsigned kResNeedsResolve = 8u;   // internal: candidates must be re-scored exactly before deciding
 constexpr unsigned kResSenseError = 16u;    // the resident patches were sensed past the end of the landscape
 
@@ -898,39 +910,39 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     // (the record lives in mapped host memory: a few PCIe writes instead of one per field).
     __shared__ StepResultDev s_res;
     __shared__ unsigned long long s_aview[kMaxHeadings];
+    __shared__ unsigned long long s_ncand;
+    __shared__ int s_serr;
     if (threadIdx.x < A) {
         st->amax[threadIdx.x] = s_amax[threadIdx.x];                            // for k_decide on the resolve path
         s_aview[threadIdx.x] = __hip_atomic_load(&st->aview[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the other two things the decision needs, fetched by other waves in the same round trip
+    if (threadIdx.x == 64) s_ncand = __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 128) s_serr = sense_err ? *sense_err : 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long n_all = __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long n_all = s_ncand;
         const bool overflow = n_all > (unsigned long long)kCandCap;
         const bool needs = !exact_all && !overflow && (n_all >= 2 || (force && n_all >= 1));
         // the integer-score decision is always filled in (the sharded exchange wants the per-heading maxima
         // even when local near-ties still have to be re-scored); NEEDS_RESOLVE tells the host it is provisional
         decide_core(s_amax, s_aview, n_all, false, nullptr, nullptr, &s_res, c, A, delta, exact_all);
         if (needs) s_res.flags |= kResNeedsResolve;
-        if (sense_err && *sense_err) s_res.flags |= kResSenseError;     // patches came from k_sense and it ran off the landscape
+        if (s_serr) s_res.flags |= kResSenseError;     // patches came from k_sense and it ran off the landscape
+        s_res.reserved = seq;                           // the host may poll this instead of waiting for the stream
+        s_res.check = record_check(reinterpret_cast<const unsigned long long*>(&s_res), A);
     }
     __syncthreads();
     emit_record(&s_res, rec, A, threadIdx.x, blockDim.x);
-    // header (7 x 8 bytes) + the first A entries of each of the four per-heading arrays; the word holding
-    // n_headings/reserved goes last, behind a system-scope fence: `reserved` carries the step's sequence number,
-    // which the host may poll instead of waiting for the stream.
-    if (threadIdx.x == 0) s_res.reserved = seq;
-    __syncthreads();
+    // The record goes to mapped host memory with wide coalesced stores and no fence: header (7 words), the first A
+    // entries of each of the four per-heading arrays, and the check word (see record_check).
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
-    if (threadIdx.x < 6) dst[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x < 7) dst[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x == 7) out->check = s_res.check;
     for (int i = threadIdx.x; i < 4 * A; i += blockDim.x) {
         const int o = 7 + (i / A) * kMaxHeadings + (i % A);
         dst[o] = src[o];
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&dst[6], src[6], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
