@@ -53,6 +53,10 @@ struct dv_ctx {
     unsigned* d_prep = nullptr;               // [npl][Q][4][64]
     int* d_hsconst_pair = nullptr;            // [2][64]: the sensed path alternates (k_sense_prep clears the other one)
     int* d_hsconst = nullptr;                 // the buffer of the resident patches
+    unsigned long long* d_bsum = nullptr;     // k_finish: per-block, per-heading (maximum, first view) [blocks][2][headings]
+    unsigned long long* d_ctmp = nullptr;     // k_finish: shared extra-candidate list [agents][kTmpCap][2]
+    int int_has_hs = 0, int_has_v = 0;        // which sums the last integer scoring pass produced
+    int finish_fused = 1;                     // DEJAVU_FINISH: integer-path steps end in k_finish (0: k_combine + k_tail)
     unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
     unsigned long long* d_pmax = nullptr;     // [64][max(G, Fpad/256)] partial maxima
     int n_partial = 0;                        // partial maxima per heading left in d_pmax by the last scoring
@@ -131,7 +135,7 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
-    F(c->d_part); F(c->d_pmax); F(c->d_record);
+    F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_bsum); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
     c->metric = 0;
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
@@ -172,6 +176,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_SHAPE", c->shape_env, 0, 5);
+    env_int("DEJAVU_FINISH", c->finish_fused, 0, 1);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -391,6 +396,8 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_scene, (size_t)g.Fpad * sizeof(double)));
     // per-agent state of a batched pass: up to kMaxHeadings agents (one heading each)
     HIP_TRY(c, hipMalloc(&c->d_state, kMaxHeadings * sizeof(StepState)));
+    HIP_TRY(c, hipMalloc(&c->d_bsum, (size_t)((g.F + 255) / 256) * 2 * kMaxHeadings * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc(&c->d_ctmp, (size_t)kMaxHeadings * kTmpCap * 2 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand, (size_t)kMaxHeadings * kCandCap * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand_exact, (size_t)kMaxHeadings * kCandCap * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_record, (size_t)kMaxHeadings * (3 + 4 * kMaxHeadings) * sizeof(double)));
@@ -951,7 +958,7 @@ static void launch_generic_apad(dv_ctx* c) {
 
 // The integer path of one scoring pass: k_sad_tiles / k_sad_generic, then k_combine.  `after_tiles` (optional) is
 // recorded between the two.
-static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial) {
+static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial, bool with_combine = true) {
     const LibCfg& g = c->cfg;
     int has_hs_sum, has_v_sum = g.hasv;
     if (g.generic) {
@@ -974,6 +981,9 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial)
     }
     HIP_TRY(c, hipGetLastError());
     if (after_tiles) HIP_TRY(c, hipEventRecord(after_tiles, c->stream));
+    c->int_has_hs = has_hs_sum;
+    c->int_has_v = has_v_sum;
+    if (!with_combine) return DV_OK;                     // the step ends in k_finish, which does the combining itself
     *n_partial = (int)((g.Fpad + 1023) / 1024);
     hipLaunchKernelGGL(k_combine, dim3((unsigned)*n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
                        c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum, c->n_agents);
@@ -1022,7 +1032,7 @@ static int tune_workgroup_shape(dv_ctx* c) {
 }
 
 // Scoring: integer-sum kernel + combine (or the exact fp64 kernel), then amax[a] without atomics.
-static int launch_scoring(dv_ctx* c) {
+static int launch_scoring(dv_ctx* c, bool with_combine = true) {
     const LibCfg& g = c->cfg;
     int rc = DV_OK;
     if (c->metric == 0 && !c->exact && !g.generic && c->shape_env == 0 && c->tuned_shape[apad_class(c->APAD)] == 0) {
@@ -1081,7 +1091,7 @@ static int launch_scoring(dv_ctx* c) {
         HIP_TRY(c, hipGetLastError());
         n_partial = (int)(g.Fpad / 64);
     } else {
-        rc = launch_int_scoring(c, prof ? e1 : nullptr, &n_partial);
+        rc = launch_int_scoring(c, prof ? e1 : nullptr, &n_partial, with_combine);
         if (rc) return rc;
     }
     if (c->exact && prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
@@ -1090,15 +1100,34 @@ static int launch_scoring(dv_ctx* c) {
 }
 
 // One step on the resident patches: scoring (2 launches) + k_tail.  The result record lands in mapped host memory.
+template <int NT>
+static void launch_finish(dv_ctx* c, int want_scene, int force) {
+    const LibCfg& g = c->cfg;
+    hipLaunchKernelGGL(k_finish<NT>, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream,
+                       c->d_part, c->d_hsconst, c->nchunk, c->APAD, c->int_has_hs, c->int_has_v, c->d_state, c->d_bsum, c->d_ctmp,
+                       c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg, c->A_agent, c->delta, want_scene, force,
+                       ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr);
+}
+
 static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     const LibCfg& g = c->cfg;
     const int force = (flags & DV_STEP_FORCE_RESOLVE) ? 1 : 0;
-    int rc = launch_scoring(c);
+    const int scene_on = (want_scene && c->n_agents == 1) ? 1 : 0;
+    // integer path: the scoring kernel's partial sums go straight to k_finish (combine + reductions + decision in one
+    // launch); the exact mode and ssd_f32 produce fam[] first and end in k_tail
+    const bool fused = c->finish_fused && c->metric == 0 && !c->exact;
+    int rc = launch_scoring(c, !fused);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
-                       c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
-                       c->A_agent, c->delta, (want_scene && c->n_agents == 1) ? 1 : 0, c->exact, force, ++c->seq,
-                       c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->metric == 1 ? 3e-6 : 0.0);
+    if (fused) {
+        if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
+        else if (c->A_agent <= 32) launch_finish<2>(c, scene_on, force);
+        else launch_finish<4>(c, scene_on, force);
+    } else {
+        hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
+                           c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
+                           c->A_agent, c->delta, scene_on, c->exact, force, ++c->seq,
+                           c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->metric == 1 ? 3e-6 : 0.0);
+    }
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
         HIP_TRY(c, hipMemcpyAsync(c->h_scene, c->d_scene, (size_t)g.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1285,7 +1314,6 @@ extern "C" int dv_resolve_enqueue(dv_ctx* c) {
     return enqueue_resolve(c);
 }
 
-static int launch_scoring(dv_ctx* c);
 
 extern "C" int dv_score_f32(dv_ctx* c, const float* patch, double* ssdbuf) {
     int rc = upload_patches_f32(c, patch, 1);

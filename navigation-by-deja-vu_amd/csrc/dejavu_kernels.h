@@ -54,8 +54,8 @@ struct StepState {                       // zeroed by the scoring epilogue (k_co
     unsigned long long amax[kMaxHeadings];      // ordered key of max_f fam[a][f]
     unsigned long long aview[kMaxHeadings];     // ~f of the first view attaining it (0 = none)
     unsigned long long ncand;                   // candidates found (may exceed kCandCap)
-    unsigned done;                              // blocks of k_tail that have finished
-    unsigned pad;
+    unsigned done;                              // blocks of k_tail / k_finish that have finished
+    unsigned ntmp;                              // k_finish: extra candidates in flight (zero between steps)
 };
 
 __device__ __forceinline__ void reset_step_state(StepState* st, int tid, int n_agents) {
@@ -796,6 +796,67 @@ __device__ void decide_core(const unsigned long long* amax, const unsigned long 
     out->flags = flags;
 }
 
+// decide_core for the unresolved case, spread over a 256-thread block (the serial form costs ~3 us at the end of every
+// step): lane a of wave 0 fills heading a's entries, the first maximum is a wave reduction (largest key, then smallest
+// index), and every thread adds its words to the record's check word.  `out` is in LDS; call with all threads.
+__device__ __forceinline__ void decide_block(const unsigned long long* amax, const unsigned long long* aview,
+                                             unsigned long long n_all, StepResultDev* out, unsigned long long* check,
+                                             const LibCfg& c, int A, double delta, unsigned flags, int seq) {
+    const int tid = threadIdx.x;
+    if (tid == 0) *check = 0x9E3779B97F4A7C15ull;
+    if (tid < 64) {
+        const int a = tid;
+        const bool valid = a < A;
+        const unsigned long long k = valid ? amax[a] : 0ull;
+        const long long view = valid ? (long long)(~aview[a]) + c.first : -1;
+        if (valid) {
+            out->angle_fam[a] = key_to_double(k);
+            out->angle_view[a] = view;
+            out->exact_fam[a] = __longlong_as_double(0xfff0000000000000ll);
+            out->exact_view[a] = -1;
+        }
+        unsigned long long m = k;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(m, o);
+            m = other > m ? other : m;
+        }
+        int idx = (valid && k == m) ? a : 64;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(idx, o);
+            idx = other < idx ? other : idx;
+        }
+        if (idx > 63) idx = 0;                                   // no heading has a view (cannot happen with F >= 1)
+        const long long bview = __shfl(view, idx);
+        if (tid == 0) {
+            out->best_heading = idx;
+            out->flags = flags | (n_all > (unsigned long long)kCandCap ? 4u : 0u);
+            out->best_view = bview;
+            out->best_fam = key_to_double(m);
+            out->approx_max = key_to_double(m);
+            out->delta = delta;
+            out->n_candidates = (long long)n_all;
+            out->n_headings = A;
+            out->reserved = seq;
+        }
+    }
+    __syncthreads();
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(out);
+    unsigned long long x = 0;
+    if (tid < 7) x = w[tid] * (unsigned long long)(2 * tid + 3);
+    for (int i = tid; i < 4 * A; i += blockDim.x) {
+        const int o = 7 + (i / A) * kMaxHeadings + (i % A);
+        x ^= w[o] * (unsigned long long)(2 * o + 3);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x ^= __shfl_xor(x, o);
+    if ((tid & 63) == 0 && x != 0) atomicXor(check, x);
+    __syncthreads();
+    if (tid == 0) out->check = *check;
+    __syncthreads();
+}
+
 // Packed per-rank record for the sharded exchange (navsim_amd/sharded.py:pack_record):
 //   [approx_max, n_candidates, state, angle_fam[A], angle_view[A], exact_fam[A], exact_view[A]]   (doubles)
 // state: 0 integer-sum scores only, 1 candidates re-scored exactly, 2 every score exact.
@@ -931,6 +992,7 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
         if (s_serr) s_res.flags |= kResSenseError;     // patches came from k_sense and it ran off the landscape
         s_res.reserved = seq;                           // the host may poll this instead of waiting for the stream
         s_res.check = record_check(reinterpret_cast<const unsigned long long*>(&s_res), A);
+        st->done = 0;                                   // k_finish, which may run the next step, expects it clear
     }
     __syncthreads();
     emit_record(&s_res, rec, A, threadIdx.x, blockDim.x);
@@ -941,6 +1003,257 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     if (threadIdx.x < 7) dst[threadIdx.x] = src[threadIdx.x];
     if (threadIdx.x == 7) out->check = s_res.check;
     for (int i = threadIdx.x; i < 4 * A; i += blockDim.x) {
+        const int o = 7 + (i / A) * kMaxHeadings + (i % A);
+        dst[o] = src[o];
+    }
+}
+
+// ------------------------------------------------------------------ k_finish: combine + tail in ONE launch
+// The integer path's steps end here (k_combine + k_tail remain for dv_score, the exact mode and ssd_f32).  Each block
+// owns 256 views: it turns the scoring kernel's partial sums into scores (k_combine's arithmetic) and keeps them in
+// registers, so fam[] is neither written nor read back.  What k_tail needs the GLOBAL maxima for is rearranged so
+// that every block can finish on its own and only the last one to arrive combines:
+//   * per heading, the block leaves its maximum and the first view attaining it (bsum);
+//   * candidates for exact re-scoring are all (a,f) within delta of the global maximum.  A block does not know
+//     that maximum, but it is at least the block's own: every entry within delta of the BLOCK's best that is not
+//     already one of its per-heading representatives goes to a shared list (normally none does);
+//   * the last block folds the summaries into amax[a] / first view, derives the true threshold, and builds the
+//     candidate list from the representatives and the shared list, dropping what falls short -- the same set
+//     k_tail lists.  It then decides and writes the record as k_tail does, and clears the counters for the next step.
+// Cross-block data travels through device-scope atomic stores/loads (no fences, see k_tail).
+constexpr int kTmpCap = 4096;       // entries of the shared extra-candidate list per agent
+
+template <int NT>                   // headings per agent <= 16 * NT, scores held in registers
+__global__ void __launch_bounds__(256)
+k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, int nchunk, int APAD, int has_hs_sum,
+         int has_v_sum, StepState* __restrict__ st, unsigned long long* __restrict__ bsum,
+         unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand, double* __restrict__ scene,
+         StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene, int force,
+         int seq, const int* __restrict__ sense_err) {
+    __shared__ unsigned long long s_bmax[kMaxHeadings];
+    __shared__ unsigned long long s_bview[kMaxHeadings];
+    __shared__ unsigned long long s_keys[16 * 16 * 17];          // 34 KB: key transposes of phase 2
+    __shared__ int s_last;
+    const int agent = blockIdx.y;
+    const int a_base = agent * A;
+    const int nb = gridDim.x;
+    const int tid = threadIdx.x;
+    st += agent;
+    cand += (long long)agent * kCandCap;
+    ctmp += (long long)agent * kTmpCap * 2;
+    bsum += (long long)agent * nb * 2 * A;
+    out += agent;
+    rec += (long long)agent * (3 + 4 * kMaxHeadings);
+
+    // ---- scores of this thread's view, all headings of the agent
+    const long long f = (long long)blockIdx.x * blockDim.x + tid;
+    const bool inb = f < c.F;
+    const long long fl = inb ? f : c.F - 1;
+    const int nsum = has_hs_sum + has_v_sum;
+    // integer sums first: per chunk, the loads of all headings are issued together (one round trip per chunk)
+    unsigned shs_u[NT * 16], sv_u[NT * 16];
+#pragma unroll
+    for (int k = 0; k < NT * 16; ++k) { shs_u[k] = 0; sv_u[k] = 0; }
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const unsigned* p = part + ((long long)ch * nsum * APAD) * c.Fpad + fl;
+        unsigned th[NT * 16], tv[NT * 16];
+#pragma unroll
+        for (int k = 0; k < NT * 16; ++k) {
+            const int a = a_base + (k < A ? k : A - 1);                            // clamped: no conditional loads
+            th[k] = has_hs_sum ? p[(long long)a * c.Fpad] : 0u;
+            tv[k] = has_v_sum ? p[(long long)((has_hs_sum ? APAD : 0) + a) * c.Fpad] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NT * 16; ++k) { shs_u[k] += th[k]; sv_u[k] += tv[k]; }
+    }
+    double val[NT * 16];
+#pragma unroll
+    for (int k = 0; k < NT * 16; ++k) {
+        val[k] = 0.0;
+        if (k < A) {
+            const long long shs = (long long)hsconst[a_base + k] + (long long)shs_u[k];
+            double acc = c.whs * (double)shs;
+            if (has_v_sum) acc = acc + c.wv * (double)(long long)sv_u[k];
+            val[k] = (double)c.P - acc / 255.;
+        }
+    }
+
+    // ---- per heading: the block's maximum and the first view attaining it.  Keys go through LDS transposed, 16
+    // headings at a time: thread (k = tid/16, j = tid%16) folds the 16 keys of heading k from views j*16..j*16+15
+    // (rows padded to 17 against bank conflicts), then the 16 partial results per heading meet in LDS atomics.
+    if (tid < kMaxHeadings) { s_bmax[tid] = 0; s_bview[tid] = ~0ull; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t * 16 < A) {
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                s_keys[(kk * 16 + (tid >> 4)) * 17 + (tid & 15)] = inb ? ordered_key(val[t * 16 + kk]) : 0ull;
+            __syncthreads();
+            const int k = tid >> 4, j = tid & 15;
+            unsigned long long m = 0;
+            int mi = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned long long x = s_keys[(k * 16 + j) * 17 + i];
+                if (x > m) { m = x; mi = i; }
+            }
+            if (t * 16 + k < A && m != 0) atomicMax(&s_bmax[t * 16 + k], m);
+            __syncthreads();
+            if (t * 16 + k < A && m != 0 && m == s_bmax[t * 16 + k])
+                atomicMin(&s_bview[t * 16 + k], (unsigned long long)((long long)blockIdx.x * blockDim.x + j * 16 + mi));
+        }
+    }
+    __syncthreads();
+    unsigned long long bbest = 0;
+    for (int k = 0; k < A; ++k) bbest = s_bmax[k] > bbest ? s_bmax[k] : bbest;
+    const double thr_b = key_to_double(bbest) - delta;
+    if (inb) {
+        double smin = __longlong_as_double(0x7ff0000000000000ll);
+#pragma unroll
+        for (int k = 0; k < NT * 16; ++k) {
+            if (k < A) {
+                smin = val[k] < smin ? val[k] : smin;
+                if (val[k] >= thr_b && !(ordered_key(val[k]) == s_bmax[k] && (unsigned long long)f == s_bview[k])) {
+                    const unsigned pos = __hip_atomic_fetch_add(&st->ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pos < (unsigned)kTmpCap) {
+                        __hip_atomic_store(&ctmp[2 * pos], ((unsigned long long)k << 40) | (unsigned long long)f, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&ctmp[2 * pos + 1], ordered_key(val[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        if (want_scene) scene[f] = smin;
+    }
+    if (tid < A) {
+        __hip_atomic_store(&bsum[((long long)blockIdx.x * 2 + 0) * A + tid], s_bmax[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&bsum[((long long)blockIdx.x * 2 + 1) * A + tid], s_bview[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- arrival ticket (see k_tail)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&st->done, 1u) == (unsigned)(nb - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+
+    // ---- last block: fold the summaries, list the candidates, decide
+    __shared__ unsigned long long s_amax[kMaxHeadings];
+    __shared__ unsigned long long s_aview[kMaxHeadings];
+    __shared__ unsigned s_ncount;
+    __shared__ unsigned s_ntmp;
+    __shared__ int s_serr;
+    __shared__ StepResultDev s_res;
+    if (tid < kMaxHeadings) { s_amax[tid] = 0; s_aview[tid] = ~0ull; }
+    if (tid == 0) s_ncount = 0;
+    if (tid == 64) s_ntmp = __hip_atomic_load(&st->ntmp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 128) s_serr = sense_err ? *sense_err : 0;
+    __syncthreads();
+    const int G = blockDim.x / A;                       // thread groups; thread (a, r) walks blocks r, r+G, ...
+    const int a = tid % A, r = tid / A;
+    const bool active = r < G;
+    constexpr int kBatch = 16;                          // summaries requested before the first is used
+    // Up to kBatch blocks per thread (50 000 views x 16 headings: 13): maxima AND first views are fetched in one
+    // round trip and stay in registers for the second pass.  Longer lists are walked twice.
+    const bool single = nb <= G * kBatch;
+    unsigned long long k8[kBatch], v8[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) { k8[j] = 0; v8[j] = ~0ull; }
+    if (active) {
+        unsigned long long lk = 0;
+        if (single) {
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int b = (r + j * G < nb) ? r + j * G : nb - 1;               // clamped: no conditional loads
+                k8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 0) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 1) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                if (r + j * G >= nb) k8[j] = 0;                                     // a clamped repeat: not an entry
+                lk = k8[j] > lk ? k8[j] : lk;
+            }
+        } else {
+            for (int b0 = r; b0 < nb; b0 += G * kBatch) {
+                unsigned long long t8[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int b = (b0 + j * G < nb) ? b0 + j * G : nb - 1;
+                    t8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 0) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) lk = t8[j] > lk ? t8[j] : lk;
+            }
+        }
+        atomicMax(&s_amax[a], lk);
+    }
+    __syncthreads();
+    unsigned long long gkey = 0;
+    for (int k = 0; k < A; ++k) gkey = s_amax[k] > gkey ? s_amax[k] : gkey;
+    const unsigned long long thr_key = ordered_key(key_to_double(gkey) - delta);
+    if (active) {
+        // second pass: blocks holding this heading's maximum give its first view; blocks whose maximum reaches the
+        // threshold (normally one in all) give a candidate
+        const unsigned long long amax_a = s_amax[a];
+        if (single) {
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const unsigned long long key = k8[j];
+                if (key != 0 && (key == amax_a || key >= thr_key)) {
+                    if (key == amax_a) atomicMin(&s_aview[a], v8[j]);
+                    if (key >= thr_key) {
+                        const unsigned pos = atomicAdd(&s_ncount, 1u);
+                        if (pos < (unsigned)kCandCap) cand[pos] = ((unsigned long long)a << 40) | v8[j];
+                    }
+                }
+            }
+        } else {
+            for (int b = r; b < nb; b += G) {
+                const unsigned long long key = __hip_atomic_load(&bsum[((long long)b * 2 + 0) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (key != 0 && (key == amax_a || key >= thr_key)) {
+                    const unsigned long long view = __hip_atomic_load(&bsum[((long long)b * 2 + 1) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (key == amax_a) atomicMin(&s_aview[a], view);
+                    if (key >= thr_key) {
+                        const unsigned pos = atomicAdd(&s_ncount, 1u);
+                        if (pos < (unsigned)kCandCap) cand[pos] = ((unsigned long long)a << 40) | view;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned n_tmp = s_ntmp < (unsigned)kTmpCap ? s_ntmp : (unsigned)kTmpCap;
+    for (unsigned i = tid; i < n_tmp; i += blockDim.x) {
+        const unsigned long long e = __hip_atomic_load(&ctmp[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long k = __hip_atomic_load(&ctmp[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k >= thr_key) {
+            const unsigned pos = atomicAdd(&s_ncount, 1u);
+            if (pos < (unsigned)kCandCap) cand[pos] = e;
+        }
+    }
+    __syncthreads();
+    if (tid < A) {
+        s_aview[tid] = ~s_aview[tid];                                          // decide_core / k_decide expect ~f (0 = none)
+        st->amax[tid] = s_amax[tid];
+        st->aview[tid] = s_aview[tid];
+    }
+    __syncthreads();
+    // the shared list overflowing means candidates were lost: report more than the resolver can take
+    const unsigned long long n_all = (s_ntmp > (unsigned)kTmpCap) ? (unsigned long long)kCandCap + 1 : (unsigned long long)s_ncount;
+    const bool needs = n_all <= (unsigned long long)kCandCap && (n_all >= 2 || (force && n_all >= 1));
+    if (tid == 0) {
+        st->ncand = n_all;
+        st->done = 0;                                                          // counters clear for the next step
+        st->ntmp = 0;
+    }
+    __shared__ unsigned long long s_check;
+    decide_block(s_amax, s_aview, n_all, &s_res, &s_check, c, A, delta, (needs ? kResNeedsResolve : 0u) | (s_serr ? kResSenseError : 0u), seq);
+    emit_record(&s_res, rec, A, tid, blockDim.x);
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
+    if (tid < 7) dst[tid] = src[tid];
+    if (tid == 7) out->check = s_res.check;
+    for (int i = tid; i < 4 * A; i += blockDim.x) {
         const int o = 7 + (i / A) * kMaxHeadings + (i % A);
         dst[o] = src[o];
     }
