@@ -254,6 +254,7 @@ def main():
             "config": {
                 "workload": workload,
                 "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
+                "workgroup_shape": eng.workgroup_shape(A),
                 "bytes_per_pixel_reference": s_ref, "bytes_per_pixel_stored": info["n_planes"], "parallelism": "library sharded x%d" % world,
                 "exchange": "none" if not use_dist else "1 all-gather of per-heading records per step (%s)" % (
                     ("RCCL ncclAllGather on the step's stream, device-resident"

@@ -230,6 +230,9 @@ int dv_timer_stop(dv_ctx *ctx, float *elapsed_ms);
 int dv_profile_kernel(dv_ctx *ctx, int enable);
 /* Sum and count of the bracketed scoring-kernel launches since the last read; resets. */
 int dv_profile_read(dv_ctx *ctx, double *total_ms, int64_t *n_launches);
+/* Workgroup shape of the scoring kernel in use for steps of n_headings headings on the resident library (1..5, see
+ * csrc/dejavu_hip.hip:launch_tiles_apad; 0 = not timed yet, or not applicable to this library). */
+int dv_workgroup_shape(dv_ctx *ctx, int n_headings, int *shape);
 /* Streaming-read microbenchmark over n_bytes of device memory (achievable HBM ceiling). */
 int dv_stream_read_gbps(dv_ctx *ctx, int64_t n_bytes, int iters, double *gbps);
 

@@ -1356,6 +1356,14 @@ extern "C" int dv_timer_stop(dv_ctx* c, float* ms) {
     return DV_OK;
 }
 
+extern "C" int dv_workgroup_shape(dv_ctx* c, int A, int* shape) {
+    if (!c || !shape) return DV_ERR_INVALID;
+    if (A < 1 || A > kMaxHeadings) return fail(c, DV_ERR_INVALID, "n_headings %d outside [1, %d]", A, kMaxHeadings);
+    const int apad = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
+    *shape = (c->have_lib && c->metric == 0 && !c->cfg.generic) ? (c->shape_env ? c->shape_env : c->tuned_shape[apad_class(apad)]) : 0;
+    return DV_OK;
+}
+
 extern "C" int dv_profile_kernel(dv_ctx* c, int enable) {
     if (!c) return DV_ERR_INVALID;
     c->profile = enable > 0 ? enable : 0;

@@ -331,6 +331,12 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_publish_wait(self._ctx, N.f64ptr(out), out.size), "dv_publish_wait")
         return out
 
+    def workgroup_shape(self, n_headings):
+        """Shape of the scoring kernel in use for this many headings (0: not timed yet / not applicable)."""
+        v = ctypes.c_int(0)
+        self._check(self._lib.dv_workgroup_shape(self._ctx, int(n_headings), ctypes.byref(v)), "dv_workgroup_shape")
+        return int(v.value)
+
     def stream_read_gbps(self, n_bytes=1 << 30, iters=10):
         g = ctypes.c_double(0)
         self._check(self._lib.dv_stream_read_gbps(self._ctx, int(n_bytes), int(iters), ctypes.byref(g)),
