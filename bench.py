@@ -69,7 +69,19 @@ def cpu_baseline(h, w, A, cw, seed, budget_views):
                     break
     except OSError:
         pass
-    return dict(value=budget_views * A / dt, unit="view-comparisons/s", cores=1, kind="port",
+    # second figure: the integer form of the same arithmetic on several host cores (OpenMP)
+    threads = max(1, min(16, os.cpu_count() or 1))           # the GPU box's CPU share per GPU is 16 threads
+    parallel = None
+    try:
+        oracle.step_fast(lib[:256], patches, cw, threads)       # warm the thread pool
+        t0 = time.perf_counter()
+        oracle.step_fast(lib, patches, cw, threads)
+        dtp = time.perf_counter() - t0
+        parallel = dict(value=budget_views * A / dtp, unit="view-comparisons/s", cores=threads, kind="port",
+                        sample="same sample, integer sums (oracle_step_fast, -O3 -fopenmp), %.2f s" % dtp)
+    except Exception as e:                                       # noqa: BLE001 - the first figure is the contract
+        parallel = dict(error=repr(e))
+    return dict(value=budget_views * A / dt, unit="view-comparisons/s", cores=1, kind="port", multicore=parallel,
                 sample="%d of the stored views x %d headings, %dx%d sensor, chem_weight %g, %.1f s of one host core; "
                        "linear in views (util.pyx:44)" % (budget_views, A, w, h, cw, dt),
                 host_cpu=model, host_logical_cores=os.cpu_count())

@@ -2,9 +2,10 @@
 //
 // One context = one GPU = one stream.  All device buffers are allocated when the library is set (nothing is
 // allocated inside a step), results come back through one pinned, mapped host record that the host polls, and a
-// step is three launches on one stream:
-//   k_sad_tiles (the HBM stream, integer partial sums) -> k_combine (sums -> scores) -> k_tail (reductions + decision)
-// plus, only when near-ties need exact re-scoring, k_resolve -> k_decide.
+// step is two launches on one stream:
+//   k_sad_tiles (the HBM stream, integer partial sums) -> k_finish (sums -> scores, reductions, decision)
+// plus, only when near-ties need exact re-scoring, k_resolve -> k_decide.  (dv_score, the exact mode and ssd_f32 keep
+// scores in fam[]: scoring kernel -> k_combine / k_exact_all -> k_tail.)
 #include "dejavu_kernels.h"
 #include "../../include/dejavu.h"
 

@@ -131,3 +131,29 @@ def int_sums(library, scene):
     lib().oracle_int_sums(library.ctypes.data_as(_u8p), F, h, w, scene.ctypes.data_as(_u8p),
                           s_hs.ctypes.data_as(_i64p), s_v.ctypes.data_as(_i64p))
     return s_hs, s_v
+
+
+_omp = None
+
+
+def step_fast(library, patches, chem_weight, threads):
+    """Multi-core integer form of the step (oracle_step_fast in liboracle_omp.so); bench.py's second CPU figure only."""
+    global _omp
+    if _omp is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle_omp.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle_omp.so is not built (make -C oracle)")
+        _omp = ctypes.CDLL(path)
+        _omp.oracle_step_fast.restype = ctypes.c_int
+        _omp.oracle_step_fast.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _u8p, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_int, _f64p, _i64p, ctypes.POINTER(ctypes.c_int32)]
+    library = _u8(library)
+    patches = _u8(patches)
+    F, h, w, _ = library.shape
+    A = patches.shape[0]
+    fam = np.empty(A, dtype=np.float64)
+    view = np.empty(A, dtype=np.int64)
+    best = ctypes.c_int32(0)
+    _omp.oracle_step_fast(library.ctypes.data_as(_u8p), F, h, w, patches.ctypes.data_as(_u8p), A, float(chem_weight),
+                          int(threads), fam.ctypes.data_as(_f64p), view.ctypes.data_as(_i64p), ctypes.byref(best))
+    return dict(best_idex=int(best.value), best_view=int(view[best.value]), angle_familiarity=fam, angle_view=view)

@@ -155,3 +155,53 @@ void oracle_int_sums(const uint8_t *library, int64_t F, int h, int w,
         s_v[f] = v;
     }
 }
+
+/*
+ * Multi-core integer form of the step, for bench.py's second CPU figure only (SURVEY.md section 8d asks for a
+ * "fast integer variant with OpenMP on all host cores" beside the reference-equivalent one): the same per-pixel
+ * terms as oracle_int_sums (util.pyx:48-56,69), summed as integers, views spread over `threads` OpenMP threads,
+ * fam = P - (0.5*cw*S_hs + (1-cw)*S_v)/255.  Not order-exact in the reference's double sense (differences of a few
+ * ulp, as for the HIP fast path); the decision rule on top is np.max / np.argmax as in oracle_step.
+ * Built in a separate object (liboracle_omp.so, -O3 -fopenmp) so that the pinned liboracle.so keeps its -O2 build.
+ */
+#ifdef ORACLE_WITH_OPENMP
+#include <omp.h>
+int oracle_step_fast(const uint8_t *library, int64_t F, int h, int w, const uint8_t *patches, int A,
+                     double cw, int threads, double *angle_fam, int64_t *best_view, int32_t *best_heading)
+{
+    const int64_t npx = (int64_t)h * (int64_t)w;
+    const double whs = 0.5 * cw, wv = 1.0 - cw;
+    if (threads < 1) threads = 1;
+    for (int a = 0; a < A; ++a) {
+        const uint8_t *scene = patches + (int64_t)a * npx * 3;
+        double best = -1.0 / 0.0;
+        int64_t bestf = -1;
+#pragma omp parallel num_threads(threads)
+        {
+            double lbest = -1.0 / 0.0;
+            int64_t lf = -1;
+#pragma omp for schedule(static) nowait
+            for (int64_t f = 0; f < F; ++f) {
+                const uint8_t *view = library + f * npx * 3;
+                int64_t hs = 0, v = 0;
+                for (int64_t p = 0; p < npx; ++p) {
+                    const int64_t o = p * 3;
+                    const int ss = scene[o + 1], sf = view[o + 1];
+                    hs += (scene[o] == view[o]) ? abs(ss - sf) : ss + sf;
+                    v += abs((int)scene[o + 2] - (int)view[o + 2]);
+                }
+                const double fam = (double)npx - (whs * (double)hs + wv * (double)v) / 255.0;
+                if (fam > lbest) { lbest = fam; lf = f; }
+            }
+#pragma omp critical
+            if (lbest > best || (lbest == best && lf >= 0 && (bestf < 0 || lf < bestf))) { best = lbest; bestf = lf; }
+        }
+        angle_fam[a] = best;
+        best_view[a] = bestf;
+    }
+    int bh = 0;
+    for (int a = 1; a < A; ++a) if (angle_fam[a] > angle_fam[bh]) bh = a;
+    *best_heading = bh;
+    return omp_get_max_threads();
+}
+#endif
