@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--agent-steps", type=int, default=300, help="steps of the full agent loop timed at N=1 (0 = skip)")
     ap.add_argument("--event-every", type=int, default=4, help="bracket every n-th timed step's scoring kernel with "
                     "HIP events (roofline.kernel_ms); 1 = every step")
+    ap.add_argument("--skip-known-answer", action="store_true", help="experiments with deliberately broken kernels only")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank "
                     "(exercises the RCCL exchange path on a single GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
@@ -212,7 +213,8 @@ def main():
     probe[a_star] = synth.synth_views(args.seed, 1, h, w, first_view=f_star)[0]
     eng.upload_patches(probe)
     chk = one_step()
-    ok = (int(chk["best_idex"]), int(chk["best_view"])) == (a_star, f_star) and float(chk["step_familiarity"]) == float(h * w)
+    ok = args.skip_known_answer or ((int(chk["best_idex"]), int(chk["best_view"])) == (a_star, f_star) and
+                                    float(chk["step_familiarity"]) == float(h * w))
     if not ok:
         sys.stderr.write("rank %d: known-answer step FAILED\n" % rank)
     if use_dist:                                                 # fail together: nobody is left waiting in a collective
@@ -275,7 +277,7 @@ def main():
             },
             "nav_steps_per_s": args.steps / dt,
             "best_heading": int(res["best_idex"]),
-            "known_answer_step": "ok on every rank (heading %d, view %d of %d, through the exchange)" % (a_star, f_star, world * F),
+            "known_answer_step": "SKIPPED" if args.skip_known_answer else "ok on every rank (heading %d, view %d of %d, through the exchange)" % (a_star, f_star, world * F),
             "roofline": {
                 "bound": "hbm", "kernel": "k_sad_tiles", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
