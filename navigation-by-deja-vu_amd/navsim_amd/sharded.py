@@ -156,7 +156,40 @@ class ShardedFamiliarity(object):
             self.exchanges += 1
         out = merge_records(records, delta, A)
         out["scene_familiarity_local"] = res.get("scene_familiarity")
+        out["scene_familiarity"] = None                      # sharded: see scene_familiarity_local
         return out
+
+
+def sharded_sads_familiarity(chem_weight, gather, rank, world_size, engine_factory=None):
+    """The reference's plug-in shape (navsim/util.pyx:10-25) over a library sharded across ranks.
+
+    model(scenes) gives this rank's engine its block of `scenes` and returns `func` whose `.engine` is a
+    ShardedFamiliarity: navsim_amd.NavBySceneFamiliarity then runs its fused step through the exchange, and every
+    rank takes the same decision, so the same agent code runs unchanged on every rank (construct the agent with
+    use_gpu_sensor=False, track_scene_familiarity=False: the per-view minimum stays sharded).  Calling `func`
+    itself (one heading, all views) is not offered: the per-view scores live on different ranks.
+    """
+    def model(scenes):
+        assert 0 <= chem_weight <= 1
+        if engine_factory is not None:
+            engine = engine_factory()
+        else:
+            from .engine import FamiliarityEngine
+            engine = FamiliarityEngine()
+        sh = ShardedFamiliarity(engine, gather, rank, world_size)
+        sh.set_library(scenes, chem_weight)
+
+        def func(scene, fambuf):
+            raise NotImplementedError("per-view scores of a sharded library live on different ranks; use the agent's "
+                                      "fused step (func.engine.step)")
+
+        func.max_familiarity = scenes[0].shape[0] * scenes[0].shape[1]
+        func.engine = sh
+        func.chem_weight = chem_weight
+        return func
+
+    model.chem_weight = chem_weight
+    return model
 
 
 class ShardedEnsemble(object):

@@ -91,3 +91,20 @@ def test_agent_sharded_ensemble_on_the_engine(eng):
         want = oracle.step(lib, pats[g], 0.25)
         assert (r["best_idex"], r["best_view"]) == (want["best_idex"], want["best_view"])
     assert (res[4]["best_idex"], res[4]["best_view"]) == (6, 123)
+
+
+def test_sharded_agent_trajectory_on_the_engine():
+    """navsim_amd.NavBySceneFamiliarity over sharded.sharded_sads_familiarity with the real engine (one shard, gather =
+    identity): the reference's golden 250-step trajectory, bit for bit."""
+    import json
+    from tests.test_host_logic import _run_trajectory
+    here = os.path.dirname(os.path.abspath(__file__))
+    case = [c for c in json.load(open(os.path.join(here, "golden", "manifest.json")))["t4_trajectory"] if c["name"] == "traj_px"][0]
+    z = np.load(os.path.join(here, "golden", "t4_trajectory.npz"))
+    land = synth.synth_landscape(case["landscape"]["seed"], case["landscape"]["size"], case["landscape"]["grain"])
+    model = sharded.sharded_sads_familiarity(case["chem_weight"], lambda rec: rec.reshape(1, -1), 0, 1)
+    nsf, best, pos, ang, fam, status = _run_trajectory(case, land, model, use_gpu_sensor=False, track_scene_familiarity=False)
+    assert status == 0 and np.array_equal(best, z["traj_px_best"])
+    assert pos.tobytes() == z["traj_px_pos"].tobytes() and ang.tobytes() == z["traj_px_angle"].tobytes()
+    np.testing.assert_allclose(fam, z["traj_px_fam"], rtol=1e-12, atol=0)
+    nsf._familiarity_func.engine.engine.close()

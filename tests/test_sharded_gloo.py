@@ -143,6 +143,47 @@ def test_agent_sharded_ensemble_matches_reference(world):
     assert want[3]["best_idex"] == 2 and want[3]["best_view"] == 77 and want[0]["best_idex"] == 1
 
 
+def trajectory_worker(rank, world, port, q):
+    """The agent itself on a sharded library: every rank runs the same NavBySceneFamiliarity, decisions come through
+    the exchange (multi-GPU result identical to single-GPU, here against the reference's trajectory)."""
+    import json
+    import navsim_amd
+    from tests.test_host_logic import _run_trajectory
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    here = os.path.dirname(os.path.abspath(__file__))
+    case = [c for c in json.load(open(os.path.join(here, "golden", "manifest.json")))["t4_trajectory"] if c["name"] == "traj_px"][0]
+    land = synth.synth_landscape(case["landscape"]["seed"], case["landscape"]["size"], case["landscape"]["grain"])
+    model = sharded.sharded_sads_familiarity(case["chem_weight"], sharded.torch_gather(device=None), rank, world,
+                                             engine_factory=OracleBackedEngine)
+    nsf, best, pos, ang, fam, status = _run_trajectory(case, land, model, use_gpu_sensor=False, track_scene_familiarity=False)
+    q.put((rank, best.tolist(), pos.tobytes(), ang.tobytes(), fam.tolist(), status, nsf._familiarity_func.engine.exchanges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agent_trajectory_on_a_sharded_library_matches_the_reference():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=trajectory_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t4_trajectory.npz"))
+    for rank, best, pos, ang, fam, status, exchanges in got:
+        assert status == 0 and len(best) == 250
+        assert np.array_equal(np.array(best), z["traj_px_best"]), rank           # heading index: bit-identical
+        assert pos == z["traj_px_pos"].tobytes() and ang == z["traj_px_angle"].tobytes()
+        np.testing.assert_allclose(fam, z["traj_px_fam"], rtol=1e-12, atol=0)
+        assert exchanges >= 250
+
+
 def test_shard_bounds_cover_the_library():
     for n, w in ((10, 3), (50000, 8), (7, 8), (64, 2)):
         spans = [sharded.shard_bounds(n, w, r) for r in range(w)]
