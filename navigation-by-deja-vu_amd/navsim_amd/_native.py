@@ -137,11 +137,32 @@ PROTOTYPES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so; if libdejavu_hip.so pulls in the system
+    one first and torch is imported afterwards (the multi-GPU exchange needs it), the process ends up with two
+    runtimes and torch finds "No HIP GPUs".  Loading torch's copy first -- without importing torch -- makes both
+    resolve to the same library, as happens anyway whenever torch is imported first."""
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return                                   # a runtime is already in: whoever loaded it decides
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:                                    # noqa: BLE001 - best effort; the system runtime still works alone
+        pass
+
+
 def load():
     """Load libdejavu_hip.so and declare its prototypes.  Raises EngineError if it is not built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise EngineError(
             "HIP library not built: %s is missing (run `make -C navigation-by-deja-vu_amd/csrc` or "

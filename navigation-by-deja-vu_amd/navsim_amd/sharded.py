@@ -410,6 +410,111 @@ class DeviceExchange(object):
         return out
 
 
+class ShardedDeviceEngine(object):
+    """What navsim_amd.NavBySceneFamiliarity needs from its engine, over a library sharded across ranks with the
+    sensor model on every GPU: the landscape is replicated, each rank senses and keeps its own block of the training
+    views, and a step senses the heading patches locally (same bytes on every rank), scores them against the local
+    block and takes the global decision through DeviceExchange.  One rank = one process = one GPU.
+    """
+
+    senses_on_device = True
+
+    def __init__(self, engine, rank, world_size, device, gather_views=True):
+        self.engine, self.rank, self.world, self.device = engine, rank, world_size, device
+        self.gather_views = gather_views
+        self.exchange = None
+        self.n_views = 0
+
+    # -- passed through to this rank's context
+    def set_landscape(self, landscape):
+        self.engine.set_landscape(landscape)
+
+    def configure_sensor(self, *args, **kwargs):
+        self.engine.configure_sensor(*args, **kwargs)
+
+    def sense(self, x, y, angle):
+        return self.engine.sense(x, y, angle)
+
+    def set_library_from_poses(self, x, y, angle, chem_weight=0.0):
+        """Every rank passes the whole path; it senses and ingests views [lo, hi) and returns uint8[F,h,w,3] with the
+        other ranks' blocks filled in by one all-gather (gather_views) or left zero."""
+        x, y, angle = (np.ascontiguousarray(v, dtype=np.float64) for v in (x, y, angle))
+        F = len(x)
+        lo, hi = shard_bounds(F, self.world, self.rank)
+        mine = self.engine.set_library_from_poses(x[lo:hi], y[lo:hi], angle[lo:hi], chem_weight, first_view=lo)
+        self.bounds, self.n_views = (lo, hi), F
+        views = np.zeros((F,) + mine.shape[1:], dtype=np.uint8)
+        views[lo:hi] = mine
+        if self.gather_views and self.world > 1:
+            import torch
+            import torch.distributed as dist
+            per = (F + self.world - 1) // self.world
+            block = int(np.prod(mine.shape[1:]))
+            send = torch.zeros(per * block, dtype=torch.uint8, device=self.device)
+            send[:(hi - lo) * block] = torch.from_numpy(mine.reshape(-1)).to(self.device)
+            recv = torch.empty(self.world * per * block, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(recv, send)
+            allv = recv.cpu().numpy().reshape(self.world, per, *mine.shape[1:])
+            for r in range(self.world):
+                rlo, rhi = shard_bounds(F, self.world, r)
+                views[rlo:rhi] = allv[r, :rhi - rlo]
+        if self.exchange is not None:
+            self.exchange.close()
+            self.exchange = None
+        return views
+
+    def sense_step(self, x, y, angles, want_scene=False, force_resolve=False):
+        if want_scene:
+            raise ValueError("scene_familiarity stays sharded: construct the agent with track_scene_familiarity=False")
+        self.engine.sense_patches(x, y, angles)
+        if self.exchange is None:                        # needs resident patches (record size) and the library (delta)
+            self.exchange = DeviceExchange(self.engine, self.rank, self.world, self.device)
+        out = self.exchange.step()
+        out["scene_familiarity"] = None
+        return out
+
+    def clear_library(self):
+        if self.exchange is not None:
+            self.exchange.close()
+            self.exchange = None
+        self.engine.clear_library()
+
+    def close(self):
+        if self.exchange is not None:
+            self.exchange.close()
+            self.exchange = None
+        self.engine.close()
+
+
+def device_sharded_sads_familiarity(chem_weight, rank, world_size, device, gather_views=True):
+    """Plug-in for navsim_amd.NavBySceneFamiliarity with library AND sensor model on the GPUs, sharded over the ranks
+    of an initialised torch.distributed (nccl) group: `NavBySceneFamiliarity(..., familiarity_model=this,
+    track_scene_familiarity=False)` on every rank."""
+    def model(scenes):
+        raise NotImplementedError("this model builds its library on the device from the training path "
+                                  "(NavBySceneFamiliarity with use_gpu_sensor=True)")
+
+    def make_engine():
+        assert 0 <= chem_weight <= 1
+        from .engine import FamiliarityEngine
+        import torch
+        dev = torch.device(device)
+        return ShardedDeviceEngine(FamiliarityEngine(device=dev.index or 0), rank, world_size, dev, gather_views)
+
+    def bind(engine, scenes):
+        def func(scene, fambuf):
+            raise NotImplementedError("per-view scores of a sharded library live on different ranks")
+        func.max_familiarity = scenes[0].shape[0] * scenes[0].shape[1]
+        func.engine = engine
+        func.chem_weight = chem_weight
+        return func
+
+    model.make_engine = make_engine
+    model.from_engine = bind
+    model.chem_weight = chem_weight
+    return model
+
+
 def step_resident(engine, gather, rank):
     """One sharded step on patches already resident on the device (benchmark / pipelined form)."""
     engine.step_enqueue(want_scene=False)

@@ -2,6 +2,7 @@
 hand-over kernel (dv_publish), the RCCL all-gather on the engine's stream and the native merge must reproduce the
 plain single-context step, ties included.  The N > 1 protocol itself is covered on CPU over gloo
 (tests/test_sharded_gloo.py)."""
+import hashlib
 import os
 import socket
 
@@ -108,3 +109,37 @@ def test_sharded_agent_trajectory_on_the_engine():
     assert pos.tobytes() == z["traj_px_pos"].tobytes() and ang.tobytes() == z["traj_px_angle"].tobytes()
     np.testing.assert_allclose(fam, z["traj_px_fam"], rtol=1e-12, atol=0)
     nsf._familiarity_func.engine.engine.close()
+
+
+def test_device_sharded_agent_with_gpu_sensor_single_rank():
+    """The full multi-GPU agent path at world size 1: landscape, sensor model and library shard on the GPU, every step
+    = sense + score + RCCL exchange + merge.  Must reproduce the reference's golden trajectory bit for bit."""
+    torch = pytest.importorskip("torch")
+    import json
+    import torch.distributed as dist
+    from tests.test_host_logic import _run_trajectory
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        z = np.load(os.path.join(here, "golden", "t4_trajectory.npz"))
+        for case in json.load(open(os.path.join(here, "golden", "manifest.json")))["t4_trajectory"]:
+            if case["name"] not in ("traj_px", "traj_cw"):
+                continue
+            land = synth.synth_landscape(case["landscape"]["seed"], case["landscape"]["size"], case["landscape"]["grain"])
+            model = sharded.device_sharded_sads_familiarity(case["chem_weight"], 0, 1, "cuda:0")
+            nsf, best, pos, ang, fam, status = _run_trajectory(case, land, model, track_scene_familiarity=False)
+            name = case["name"]
+            assert isinstance(nsf._engine, sharded.ShardedDeviceEngine) and nsf._engine.exchange.exchanges >= len(best)
+            assert status == case["stop_status"] and np.array_equal(best, z[name + "_best"])
+            assert pos.tobytes() == z[name + "_pos"].tobytes() and ang.tobytes() == z[name + "_angle"].tobytes()
+            np.testing.assert_allclose(fam, z[name + "_fam"], rtol=1e-12, atol=0)
+            assert hashlib.sha256(np.ascontiguousarray(nsf.familiar_scenes).tobytes()).digest() == bytes(z[name + "_scenes_sha"])
+            nsf._engine.close()
+    finally:
+        dist.destroy_process_group()
