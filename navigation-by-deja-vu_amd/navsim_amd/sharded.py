@@ -4,7 +4,7 @@ The stored views are independent units (the reference's kernel loops `for fam_id
 navsim/util.pyx:44, and a step only needs the per-heading maximum over views,
 navsim/NavBySceneFamiliarity.py:313), so rank r keeps the contiguous block
 [r*F/N, (r+1)*F/N) of the library and every rank scores the same patches.  The only exchange
-per step is one all-gather of a (3A+3)-double record per rank over RCCL (backend "nccl" on
+per step is one all-gather of a (3+4A)-double record per rank over RCCL (backend "nccl" on
 ROCm; xGMI is point-to-point and the message is a few hundred bytes, so this is one
 latency-bound hop), after which every rank reduces the records identically:
 
