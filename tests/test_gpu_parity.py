@@ -541,3 +541,26 @@ def test_every_workgroup_shape_gives_identical_results(A):
         np.testing.assert_array_equal(fams[shape], fams[1])
         np.testing.assert_array_equal(fams[(shape, "score")], fams[(1, "score")])
     np.testing.assert_allclose(fams[1], want["angle_familiarity"], rtol=1e-12)
+
+
+def test_random_multi_block_ties(eng):
+    """Duplicated views scattered over several k_finish blocks and repeated headings (tests/manual/stress_blocks.py's
+    generator, 60 fixed cases): decisions, per-heading maxima and per-view minima against the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "stress_blocks", os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual", "stress_blocks.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(2026)
+    resolved = 0
+    for it in range(60):
+        lib, pat, cw = mod.make_case(rng)
+        want = oracle.step(lib, pat, cw)
+        eng.set_library(lib, cw)
+        got = eng.step(pat, want_scene=True)
+        assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]), it
+        np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=1e-9, atol=1e-12)
+        resolved += bool(got["flags"] & 1)
+    assert resolved >= 20
