@@ -1673,6 +1673,10 @@ k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         if (threadIdx.x < kMaxHeadings) next_hsconst[threadIdx.x] = 0;
         if (threadIdx.x == 0) *next_err = 0;
     }
+    // the level tables (3 x 256 bytes) go to LDS: the lookups then cost no second trip to memory
+    __shared__ unsigned char s_lut[768];
+    if (threadIdx.x < 192) reinterpret_cast<unsigned*>(s_lut)[threadIdx.x] = reinterpret_cast<const unsigned*>(lut)[threadIdx.x];
+    __syncthreads();
     const int ngroups = c.Q * 4;                           // groups of 4 pixels, incl. the zero padding
     const long long total = (long long)A * ngroups;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1684,13 +1688,23 @@ k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         const Pose p = poses.p[a];
         unsigned w[kMaxHues + 1];
         for (int pl = 0; pl < c.npl; ++pl) w[pl] = 0;
+        unsigned Hs[4], Ss[4], Vs[4];
+        unsigned char rawb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool okp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // four independent fetches in flight
+            const int px = grp * 4 + i;
+            okp[i] = true;
+            Hs[i] = Ss[i] = Vs[i] = 0;
+            if (px < c.P) okp[i] = sense_pixel(land, g, p, s_lut, px / g.sw, px % g.sw, Hs[i], Ss[i], Vs[i]);
+        }
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = grp * 4 + i;
             if (px >= c.P) break;
-            unsigned H, S, V;
-            if (!sense_pixel(land, g, p, lut, px / g.sw, px % g.sw, H, S, V)) { atomicOr(err, 1); H = S = V = 0; }
-            unsigned char* o = raw + ((long long)a * c.P + px) * 3;
-            o[0] = (unsigned char)H; o[1] = (unsigned char)S; o[2] = (unsigned char)V;
+            unsigned H = Hs[i], S = Ss[i], V = Vs[i];
+            if (!okp[i]) { atomicOr(err, 1); H = S = V = 0; }
+            rawb[3 * i] = (unsigned char)H; rawb[3 * i + 1] = (unsigned char)S; rawb[3 * i + 2] = (unsigned char)V;
             for (int pl = 0; pl < c.npl; ++pl) w[pl] |= plane_byte(c, pl, H, S, V) << (8 * i);
             if (!c.generic && c.cw > 0.0) {
                 const int nk = c.signed_s ? 2 : c.nhs;
@@ -1699,6 +1713,16 @@ k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
                 if (!in_set) konst += (int)S;
                 else if (c.signed_s && S > 127u) konst += (int)S - 127;
             }
+        }
+        // the group's raw bytes (for the exact kernels): three dword stores when the 12 bytes are aligned and all there
+        const long long roff = ((long long)a * c.P + (long long)grp * 4) * 3;
+        if ((roff & 3) == 0 && grp * 4 + 3 < c.P) {
+            unsigned* o = reinterpret_cast<unsigned*>(raw + roff);
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                o[d] = (unsigned)rawb[4 * d] | ((unsigned)rawb[4 * d + 1] << 8) | ((unsigned)rawb[4 * d + 2] << 16) | ((unsigned)rawb[4 * d + 3] << 24);
+        } else {
+            for (int i = 0; i < 12 && grp * 4 + i / 3 < c.P; ++i) raw[roff + i] = rawb[i];
         }
         const int q = grp >> 2, j = grp & 3;
         for (int pl = 0; pl < c.npl; ++pl) prep[(((long long)pl * c.Q + q) * 4 + j) * APAD + a] = w[pl];
