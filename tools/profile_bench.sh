@@ -3,7 +3,8 @@
 #   bash tools/profile_bench.sh r01
 # Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2-3: PMC counters, each in its own run
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Results land in gpurun_out/<tag>/ and a summary JSON
-# is printed by tools/summarize_profile.py; copy both into profiles/.
+# is printed by tools/summarize_profile.py; copy both into profiles/ with tools/copy_profile.py (delete the local
+# gpurun_out/<tag>/ first: gpurun merges into it, and files of an earlier run would go stale there).
 set -e
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
