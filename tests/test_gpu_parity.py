@@ -564,3 +564,15 @@ def test_random_multi_block_ties(eng):
         np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=1e-9, atol=1e-12)
         resolved += bool(got["flags"] & 1)
     assert resolved >= 20
+
+
+def test_workgroup_shape_is_reported_after_the_first_step(eng):
+    lib = synth.synth_views(3, 700, 16, 16)
+    pats = synth.synth_patches(3, 12, 16, 16)
+    eng.set_library(lib, 0.25)
+    assert eng.workgroup_shape(12) == 0                      # nothing timed yet for this library
+    eng.step(pats, want_scene=False)
+    assert 1 <= eng.workgroup_shape(12) <= 5
+    assert eng.workgroup_shape(40) == 0                      # another heading class: timed on its first use
+    with pytest.raises(ValueError):                          # DV_ERR_INVALID maps to ValueError, as for the other calls
+        eng.workgroup_shape(65)
