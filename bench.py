@@ -87,6 +87,30 @@ def cpu_baseline(h, w, A, cw, seed, budget_views):
                 host_cpu=model, host_logical_cores=os.cpu_count())
 
 
+def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
+    """One GPU's share of BASELINE.json configs[4] (256 agents on 8 GPUs, 100k views replicated): n_agents agents x A
+    headings per ensemble step through dv_step_batch, patches uploaded every step; one planted answer is checked."""
+    import navsim_amd
+    from navsim_amd import synth
+    eng = navsim_amd.FamiliarityEngine(0)
+    try:
+        eng.generate_library(seed, n_views, h, w, chem_weight=cw)
+        patches = synth.synth_patches(seed, n_agents * A, h, w).reshape(n_agents, A, h, w, 3)
+        patches[n_agents // 2, A // 3] = synth.synth_views(seed, 1, h, w, first_view=n_views // 3)[0]
+        res = eng.step_batch(patches)
+        if (res[n_agents // 2]["best_idex"], res[n_agents // 2]["best_view"]) != (A // 3, n_views // 3):
+            raise RuntimeError("planted view not found by the ensemble step")
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            eng.step_batch(patches)
+        dt = (time.perf_counter() - t0) / n_steps
+    finally:
+        eng.close()
+    return dict(view_comparisons_per_s=n_agents * A * n_views / dt, agent_steps_per_s=n_agents / dt, ms_per_ensemble_step=dt * 1e3,
+                what="%d agents x %d headings against %d views (%dx%d), dv_step_batch, patches uploaded each step: one "
+                     "GPU's share of BASELINE.json configs[4]" % (n_agents, A, n_views, w, h))
+
+
 def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     """Full navsim-style agent on the same shape: sense (GPU) + score + decide + move, per step."""
     import navsim_amd
@@ -128,6 +152,8 @@ def main():
     ap.add_argument("--agent-steps", type=int, default=300, help="steps of the full agent loop timed at N=1 (0 = skip)")
     ap.add_argument("--event-every", type=int, default=4, help="bracket every n-th timed step's scoring kernel with "
                     "HIP events (roofline.kernel_ms); 1 = every step")
+    ap.add_argument("--batch-agents", type=int, default=32, help="agents of the ensemble block (configs[4] share of one "
+                    "GPU; 0 = skip)")
     ap.add_argument("--skip-known-answer", action="store_true", help="experiments with deliberately broken kernels only")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank "
                     "(exercises the RCCL exchange path on a single GPU)")
@@ -296,6 +322,11 @@ def main():
             out["agent"] = {"nav_steps_per_s": sps, "view_comparisons_per_s": sps * n_lib * A, "library_views": n_lib,
                             "what": "navsim_amd.NavBySceneFamiliarity.step_forward(fake=True): sensor model on the GPU "
                                     "(2000x2000 landscape resident), scoring, decision, position update; Python caller"}
+        if world == 1 and args.batch_agents > 0 and not args.force_dist:
+            try:
+                out["ensemble"] = ensemble_comparisons_per_s(h, w, A, cw, args.seed, args.batch_agents, 100000, 5)
+            except Exception as e:                               # noqa: BLE001 - an extra block must not cost the JSON line
+                out["ensemble"] = {"error": repr(e)}
         if world == 1 and args.cpu_views > 0:
             out["cpu_baseline"] = cpu_baseline(h, w, A, cw, args.seed, min(args.cpu_views, F))
         else:
