@@ -576,3 +576,26 @@ def test_workgroup_shape_is_reported_after_the_first_step(eng):
     assert eng.workgroup_shape(40) == 0                      # another heading class: timed on its first use
     with pytest.raises(ValueError):                          # DV_ERR_INVALID maps to ValueError, as for the other calls
         eng.workgroup_shape(65)
+
+
+@pytest.mark.parametrize("A", [64, 33, 16])
+def test_ties_across_many_blocks(eng, A):
+    """More k_finish blocks than its last block folds in one round (the two-pass walk over the block summaries), with
+    the best view duplicated in far-apart blocks and seen under several headings."""
+    F, h, w, cw = 70000, 4, 4, 0.25
+    lib = synth.synth_views(17, F, h, w)
+    pats = synth.synth_patches(17, A, h, w)
+    star = lib[31000].copy()
+    star[0, 0] = (77, 200, 13)                          # make it unlike the 2-hue, 5-level crowd: a unique best match
+    for f in (69990, 31000, 45000, 300):
+        lib[f] = star
+    for a in (A - 1, A // 2, 3):
+        pats[a] = star
+    want = oracle.step(lib, pats, cw)
+    assert (want["best_idex"], want["best_view"]) == (3, 300)
+    eng.set_library(lib, cw)
+    got = eng.step(pats, want_scene=True)
+    assert (got["best_idex"], got["best_view"]) == (3, 300)
+    assert got["n_candidates"] == 12 and got["flags"] & 1            # 4 views x 3 headings, settled by the exact resolver
+    np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=1e-12)
+    np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=1e-12)
