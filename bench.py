@@ -132,8 +132,27 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
         nsf.step_forward(fake=True)
     dt = time.perf_counter() - t0
     n_lib = len(path)
+    # the same agent as the first of an ensemble of 32 stepping in lockstep (sensing and scoring batched, 64/A agents
+    # per library pass; navsim_amd.NavEnsemble): agent-steps per second of the whole ensemble
+    ens_rate = None
+    try:
+        n_ens = 32
+        idx = np.linspace(5, n_lib - 50, n_ens).astype(int)
+        poses = []
+        for i in idx:
+            dd = path[i + 1] - path[i]
+            poses.append((path[i] + np.array([1.0, -1.0]), float(np.arctan2(dd[1], dd[0]) % (2 * np.pi))))
+        ens = navsim_amd.NavEnsemble.from_agent(nsf, poses)
+        for _ in range(2):
+            ens.step_forward(fake=True)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ens.step_forward(fake=True)
+        ens_rate = n_ens * 10 / (time.perf_counter() - t0)
+    except Exception:                                            # noqa: BLE001 - an extra figure only
+        ens_rate = None
     nsf.clear_training()
-    return n_steps / dt, n_lib
+    return n_steps / dt, n_lib, ens_rate
 
 
 def main():
@@ -318,8 +337,9 @@ def main():
         }
         if world == 1 and args.agent_steps > 0 and not args.force_dist:
             eng.clear_library()                                  # make room: the agent builds its own library
-            sps, n_lib = agent_steps_per_s(h, w, A, cw, F, args.seed, args.agent_steps)
+            sps, n_lib, ens_rate = agent_steps_per_s(h, w, A, cw, F, args.seed, args.agent_steps)
             out["agent"] = {"nav_steps_per_s": sps, "view_comparisons_per_s": sps * n_lib * A, "library_views": n_lib,
+                            "ensemble_of_32_nav_steps_per_s": ens_rate,
                             "what": "navsim_amd.NavBySceneFamiliarity.step_forward(fake=True): sensor model on the GPU "
                                     "(2000x2000 landscape resident), scoring, decision, position update; Python caller"}
         if world == 1 and args.batch_agents > 0 and not args.force_dist:

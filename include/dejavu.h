@@ -137,6 +137,13 @@ int dv_sense_patches(dv_ctx *ctx, double x, double y, const double *angles, int 
 /* One agent step's device work in one call: dv_sense_patches + dv_step_enqueue + dv_step_wait. */
 int dv_sense_step(dv_ctx *ctx, double x, double y, const double *angles, int n_headings, uint32_t flags,
                   dv_step_result *result, double *scene_fam);
+/*
+ * Ensemble form: n_agents agents (positions x[i], y[i]; headings angles[i][0..A)) sensed and scored against the one
+ * resident library, 64/A agents per library pass -- the trial farm of scripts/run_experiment.py:326-347 as agents
+ * batched on one GPU.  results[n_agents].  DV_ERR_INDEX if any footprint leaves the landscape.
+ */
+int dv_sense_step_batch(dv_ctx *ctx, const double *x, const double *y, const double *angles, int n_agents, int n_headings,
+                        uint32_t flags, dv_step_result *results);
 /* train_from_path (:118-140) on the device: sense n poses and ingest them as the library; out_views
  * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */
 int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,

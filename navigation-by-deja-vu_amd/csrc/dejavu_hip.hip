@@ -543,6 +543,8 @@ static int upload_patches_f32(dv_ctx* c, const float* patches, int A) {
 
 static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene);
 static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam);
+static int finish_pass(dv_ctx* c);
+static void copy_result(const dv_ctx* c, int agent, dv_step_result* result);
 
 extern "C" int dv_step_f32(dv_ctx* c, const float* patches, int A, uint32_t flags, dv_step_result* result, double* scene_ssd) {
     int rc = upload_patches_f32(c, patches, A);
@@ -649,23 +651,11 @@ extern "C" int dv_sense(dv_ctx* c, const double* x, const double* y, const doubl
     return check_sense_error(c);
 }
 
-extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* angles, int A) {
-    int rc = check_step_args(c, A);
-    if (rc) return rc;
-    if (!angles) return fail(c, DV_ERR_INVALID, "angles is NULL");
-    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
-    if (c->sensor.sw != c->w || c->sensor.sh != c->h)
-        return fail(c, DV_ERR_STATE, "sensor is %dx%d but the library holds %dx%d views", c->sensor.sw, c->sensor.sh, c->w, c->h);
-    HIP_TRY(c, hipSetDevice(c->device));
-    // poses (cos/sin from the host's libm) by value, then ONE kernel that senses and lays the patches out for the
-    // scoring kernel; no copy and no memset on the way (see k_sense_prep)
-    PoseSet poses;
-    for (int a = 0; a < A; ++a) {
-        const double rot = -(0.5 * M_PI - angles[a]);
-        poses.p[a] = Pose{x, y, std::cos(rot), std::sin(rot)};
-    }
-    for (int a = A; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
-    c->A = A; c->n_agents = 1; c->A_agent = A;
+// Senses the patches of A_total headings (poses by value) straight into the scoring kernel's operand layout: ONE
+// kernel, no copy and no memset on the way (see k_sense_prep).  n_agents agents of A_agent headings each.
+static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int A_agent) {
+    const int A = n_agents * A_agent;
+    c->A = A; c->n_agents = n_agents; c->A_agent = A_agent;
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
     if (c->hsconst_dirty) {
         // uploaded patches left their constants in the buffer this step would add into
@@ -682,6 +672,61 @@ extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* ang
                        c->d_hsconst_pair + nxt * kMaxHeadings, c->d_err + nxt);
     HIP_TRY(c, hipGetLastError());
     c->patches_sensed = true;      // no host synchronisation here: the step's result record carries the error flag
+    return DV_OK;
+}
+
+static int check_sense_args(dv_ctx* c, int A) {
+    int rc = check_step_args(c, A);
+    if (rc) return rc;
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    if (c->sensor.sw != c->w || c->sensor.sh != c->h)
+        return fail(c, DV_ERR_STATE, "sensor is %dx%d but the library holds %dx%d views", c->sensor.sw, c->sensor.sh, c->w, c->h);
+    return DV_OK;
+}
+
+static inline Pose make_pose(double x, double y, double angle) {   // cos/sin from the host's libm, as the reference's come
+    const double rot = -(0.5 * M_PI - angle);
+    return Pose{x, y, std::cos(rot), std::sin(rot)};
+}
+
+extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* angles, int A) {
+    int rc = check_sense_args(c, A);
+    if (rc) return rc;
+    if (!angles) return fail(c, DV_ERR_INVALID, "angles is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PoseSet poses;
+    for (int a = 0; a < A; ++a) poses.p[a] = make_pose(x, y, angles[a]);
+    for (int a = A; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
+    return sense_prep_launch(c, poses, 1, A);
+}
+
+// Ensemble form of dv_sense_step: n_agents agents, each at its own position with its own A headings, sensed and
+// scored against the one resident library, 64/A agents per library pass; nothing but poses goes up.
+extern "C" int dv_sense_step_batch(dv_ctx* c, const double* x, const double* y, const double* angles, int n_agents, int A,
+                                   uint32_t flags, dv_step_result* results) {
+    int rc = check_sense_args(c, A);
+    if (rc) return rc;
+    if (!x || !y || !angles || !results || n_agents < 1) return fail(c, DV_ERR_INVALID, "dv_sense_step_batch: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int per_pass = kMaxHeadings / A;
+    for (int first = 0; first < n_agents; first += per_pass) {
+        const int n = (n_agents - first < per_pass) ? n_agents - first : per_pass;
+        PoseSet poses;
+        for (int ag = 0; ag < n; ++ag)
+            for (int a = 0; a < A; ++a)
+                poses.p[ag * A + a] = make_pose(x[first + ag], y[first + ag], angles[(size_t)(first + ag) * A + a]);
+        for (int a = n * A; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
+        rc = sense_prep_launch(c, poses, n, A);
+        if (rc) return rc;
+        rc = enqueue_step(c, flags, false);
+        if (rc) return rc;
+        rc = finish_pass(c);
+        if (rc) return rc;
+        if (c->h_result[0].flags & kResSenseError)
+            return fail(c, DV_ERR_INDEX, "a sensor footprint of agents %d..%d reaches past the end of the landscape "
+                        "(index out of bounds)", first, first + n - 1);
+        for (int ag = 0; ag < n; ++ag) copy_result(c, ag, &results[first + ag]);
+    }
     return DV_OK;
 }
 

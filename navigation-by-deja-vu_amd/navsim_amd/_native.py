@@ -102,6 +102,8 @@ PROTOTYPES = {
     "dv_sense_patches": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, _f64p, ctypes.c_int]),
     "dv_sense_step": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, _f64p, ctypes.c_int, ctypes.c_uint32,
                                      ctypes.POINTER(StepResult), _f64p]),
+    "dv_sense_step_batch": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                           ctypes.POINTER(StepResult)]),
     "dv_set_library_from_poses": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int64, ctypes.c_double,
                                                  ctypes.c_int64, _u8p]),
     "dv_score": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),

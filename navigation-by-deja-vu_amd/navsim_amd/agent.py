@@ -383,6 +383,11 @@ class NavBySceneFamiliarity(object):
                 self.angle_familiarity[a_idex] = np.max(temp_fam)
             best_idex = np.argmax(self.angle_familiarity)
 
+        self._move(best_idex, fake)
+
+    def _move(self, best_idex, fake=False):
+        """The part of a step after the heading is chosen (:316-329): turn, advance, book-keeping, stop conditions."""
+        position = self.position
         self.step_familiarity = self.angle_familiarity[best_idex]
         angle = (self.angle + self.angle_offsets[best_idex]) % (2 * np.pi)
         self.position = (position[0] + self.step_size * np.cos(angle),
@@ -394,3 +399,28 @@ class NavBySceneFamiliarity(object):
             self.update_error()
             if np.linalg.norm(self.training_path[-1] - self.position) <= self.threshold_factor * self.step_size:
                 raise ReachedEndOfTrainingPathException()
+
+    # ---- ensembles: several agents on one engine and one library (navsim_amd/ensemble.py) --------------------
+    def clone_for_ensemble(self):
+        """Another agent on the SAME engine, landscape and trained library, with its own pose and book-keeping."""
+        import copy
+        if self._engine is None or self.training_path is None:
+            raise ValueError("clone a trained agent whose sensor model runs on the GPU")
+        other = copy.copy(self)                                   # shares engine, library views, training path
+        other.angle_familiarity = np.full_like(self.angle_familiarity, np.nan)
+        other.scene_familiarity = None if self.track_scene_familiarity is False else np.zeros_like(self.scene_familiarity)
+        other.position, other.angle = None, None
+        other.step_familiarity = None
+        other.reset_error()
+        return other
+
+    def headings_to_test(self):
+        """(x, y, absolute test angles) of the coming step, after the reference's bounds check (:153-158, :289-293)."""
+        self.angle_familiarity[:] = np.nan
+        self._check_bounds(self.position)
+        return self.position[0], self.position[1], (self.angle + self.angle_offsets) % (2 * np.pi)
+
+    def apply_step_result(self, res, fake=False):
+        """Finish a step whose device work was done elsewhere (an ensemble pass): same state changes as step_forward."""
+        self.angle_familiarity[:] = res["angle_familiarity"]
+        self._move(res["best_idex"], fake)

@@ -149,6 +149,20 @@ class FamiliarityEngine(object):
                                                   N.f64ptr(scene) if want_scene else None), "dv_sense_step")
         return self._result_dict(r, scene)
 
+    def sense_step_batch(self, x, y, angles, force_resolve=False):
+        """Ensemble step on the device: agent i at (x[i], y[i]) looking along angles[i][0..A) -> list of result dicts."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        angles = np.ascontiguousarray(angles, dtype=np.float64)
+        if angles.ndim != 2 or len(x) != len(y) or angles.shape[0] != len(x):
+            raise ValueError("x[N], y[N] and angles[N, A] expected")
+        n, A = angles.shape
+        res = (N.StepResult * n)()
+        self._check_sense(self._lib.dv_sense_step_batch(self._ctx, N.f64ptr(x), N.f64ptr(y), N.f64ptr(angles), n, A,
+                                                        N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, res),
+                          "dv_sense_step_batch")
+        return [self._result_dict(res[i], None) for i in range(n)]
+
     def set_library_from_poses(self, x, y, angle, chem_weight=0.0, first_view=0, want_views=True):
         """train_from_path on the device: sense the poses and ingest them as the library; returns familiar_scenes."""
         x, y, angle = self._pose_arrays(x, y, angle)

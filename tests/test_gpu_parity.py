@@ -599,3 +599,55 @@ def test_ties_across_many_blocks(eng, A):
     assert got["n_candidates"] == 12 and got["flags"] & 1            # 4 views x 3 headings, settled by the exact resolver
     np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=1e-12)
     np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=1e-12)
+
+
+def test_ensemble_matches_independent_agents():
+    """navsim_amd.NavEnsemble (sensing + scoring of all agents batched per library pass, dv_sense_step_batch) against the
+    same agents stepped one by one: identical headings, poses, familiarities, error metrics and stop codes."""
+    land = synth.synth_landscape(11, 420, 4)
+    path = synth.sin_training_path(0.5, 0.2 * 420, 0.6 * 420, arclen=1.0)[:260]
+    kw = dict(n_test_angles=7, n_sensor_levels=5, saccade_degrees=120.0, max_distance_to_training_path=25.0,
+              track_scene_familiarity=False)
+
+    def trained():
+        nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 12), 1.0, familiarity_model=navsim_amd.sads_familiarity(0.25), **kw)
+        nsf.train_from_path(path)
+        return nsf
+
+    d = path[2] - path[1]
+    a0 = float(np.arctan2(d[1], d[0]) % (2 * np.pi))
+    poses = [(path[1] + np.array([1.0, -0.5]), a0), (path[40] + np.array([-2.0, 1.0]), a0 + 0.2),
+             (path[254] + np.array([0.0, 0.2]), float(np.arctan2(*(path[255] - path[254])[::-1]) % (2 * np.pi))),   # at the end of the path: reaches it
+             (path[10] + np.array([0.0, 30.0]), a0),                  # far off the path: TooFar on its first step
+             ((5.0, 5.0), 0.3),                                       # inside the bounds margin: OutOfLandscapeBounds
+             (path[120] + np.array([3.0, -3.0]), a0 + 0.5), (path[60], a0), (path[61], a0), (path[62], a0), (path[63], a0)]
+    # reference behaviour: each agent alone
+    want = []
+    for pos, ang in poses:
+        nsf = trained()
+        nsf.position, nsf.angle = (float(pos[0]), float(pos[1])), float(ang)
+        row = dict(stop_status=0, completed_frames=0)
+        try:
+            for _ in range(70):
+                nsf.step_forward()
+                row["completed_frames"] += 1
+        except navsim_amd.StopNavigationException as e:
+            row["stop_status"] = e.get_code()
+        if nsf._n_navigation_error:
+            row["rmsd_error"], row["path_coverage"] = float(nsf.navigation_error), float(nsf.percent_recapitulated)
+        want.append((row, nsf.position, nsf.angle, nsf.navigated_for_frames, nsf.angle_familiarity.copy()))
+        nsf._engine.close()
+    ens = navsim_amd.NavEnsemble.from_agent(trained(), poses)
+    done = ens.run(70)
+    codes = set()
+    for i, (row, pos, ang, frames, afam) in enumerate(want):
+        ag = ens.agents[i]
+        assert ens.stop_status[i] == row["stop_status"], i
+        assert done[i] == row["completed_frames"] and ag.navigated_for_frames == frames, i
+        assert tuple(ag.position) == tuple(pos) and ag.angle == ang, i
+        np.testing.assert_array_equal(ag.angle_familiarity, afam)
+        if "rmsd_error" in row:
+            assert float(ag.navigation_error) == row["rmsd_error"] and float(ag.percent_recapitulated) == row["path_coverage"]
+        codes.add(row["stop_status"])
+    assert codes == {0, 1, -1, -2}
+    ens.engine.close()
