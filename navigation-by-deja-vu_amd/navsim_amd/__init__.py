@@ -13,12 +13,12 @@ from .util import sads_familiarity, hip_sads_familiarity
 from .engine import FamiliarityEngine
 from ._native import EngineError
 from . import synth
-from .experiment import run_experiment, chop_path_to_len
+from .experiment import run_experiment, run_ensemble, chop_path_to_len
 from .ensemble import NavEnsemble
 
 __all__ = [
     "NavBySceneFamiliarity", "StopNavigationException", "ReachedEndOfTrainingPathException",
     "NavigatingFailedException", "TooFarFromTrainingPathException", "OutOfLandscapeBoundsException",
     "sads_familiarity", "hip_sads_familiarity", "FamiliarityEngine", "EngineError",
-    "fill_sensor_from", "downscale_chem", "synth", "run_experiment", "chop_path_to_len", "NavEnsemble",
+    "fill_sensor_from", "downscale_chem", "synth", "run_experiment", "run_ensemble", "chop_path_to_len", "NavEnsemble",
 ]

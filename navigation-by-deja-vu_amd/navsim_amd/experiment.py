@@ -47,3 +47,23 @@ def run_experiment(nsf, frames=None):
         "percent_forgiving": nsf.percent_recapitulated_forgiving(n_consecutive_scenes=N_CONSECUTIVE_SCENES),
         "n_captures": nsf.n_captures(n_consecutive_scenes=N_CONSECUTIVE_SCENES),
     }
+
+
+def run_ensemble(ens, frames=None):
+    """run_experiment for a navsim_amd.NavEnsemble: every agent gets the reference's result row (:251-258)."""
+    first = ens.agents[0]
+    if frames is None:
+        frames = int(FRAME_FACTOR * first.training_path_length / first.step_size)
+    done = ens.run(frames)
+    rows = []
+    for i, nsf in enumerate(ens.agents):
+        scored = nsf._n_navigation_error > 0                      # an agent stopped before its first step has no error yet
+        rows.append({
+            "path_coverage": nsf.percent_recapitulated,
+            "rmsd_error": nsf.navigation_error if scored else float("nan"),
+            "completed_frames": done[i],
+            "stop_status": ens.stop_status[i],
+            "percent_forgiving": nsf.percent_recapitulated_forgiving(n_consecutive_scenes=N_CONSECUTIVE_SCENES),
+            "n_captures": nsf.n_captures(n_consecutive_scenes=N_CONSECUTIVE_SCENES),
+        })
+    return rows

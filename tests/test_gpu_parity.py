@@ -650,4 +650,6 @@ def test_ensemble_matches_independent_agents():
             assert float(ag.navigation_error) == row["rmsd_error"] and float(ag.percent_recapitulated) == row["path_coverage"]
         codes.add(row["stop_status"])
     assert codes == {0, 1, -1, -2}
+    rows = navsim_amd.run_ensemble(ens, frames=0)                  # nothing left to run: just the result rows
+    assert [r["stop_status"] for r in rows] == ens.stop_status and all("path_coverage" in r for r in rows)
     ens.engine.close()
