@@ -76,6 +76,7 @@ struct dv_ctx {
     StepState* d_state = nullptr;
     unsigned long long* d_cand = nullptr;     // [kCandCap]
     double* d_cand_exact = nullptr;           // [kCandCap]
+    int result_slot = 0;                      // first result record of the pass being enqueued (pipelined ensemble passes)
     StepResultDev* h_result = nullptr;        // pinned, mapped: the kernels write the result record into it
     StepResultDev* d_result = nullptr;        // device-side address of h_result
     double* d_record = nullptr;               // [3 + 4*64] packed record of the last step, for device-side exchange
@@ -545,6 +546,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene);
 static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam);
 static int finish_pass(dv_ctx* c);
 static void copy_result(const dv_ctx* c, int agent, dv_step_result* result);
+static bool spin_for_records(dv_ctx* c, int slot, int n, int A, int seq);
 
 extern "C" int dv_step_f32(dv_ctx* c, const float* patches, int A, uint32_t flags, dv_step_result* result, double* scene_ssd) {
     int rc = upload_patches_f32(c, patches, A);
@@ -700,6 +702,62 @@ extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* ang
     return sense_prep_launch(c, poses, 1, A);
 }
 
+// Ensemble passes, pipelined: the passes of up to 64 agents are enqueued back to back (their scratch buffers are
+// reused in stream order; only the result records are distinct, `result_slot`), then the host collects the records.
+// A pass whose agents need the exact resolver, overflowed their candidate list or sensed past the landscape is
+// simply run again on its own through the synchronous path, which handles all of that.  `stage(first, n)` makes
+// agents [first, first + n) the resident patches.
+template <class Stage>
+static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_result* results, Stage stage) {
+    struct Pass { int first, n, seq, slot; };
+    const int per_pass = kMaxHeadings / A;
+    int rc = DV_OK;
+    for (int sb = 0; sb < n_agents && rc == DV_OK; sb += kMaxHeadings) {
+        const int cnt = (n_agents - sb < kMaxHeadings) ? n_agents - sb : kMaxHeadings;
+        std::vector<Pass> passes;
+        for (int first = 0; first < cnt && rc == DV_OK; first += per_pass) {
+            const int n = (cnt - first < per_pass) ? cnt - first : per_pass;
+            rc = stage(sb + first, n);
+            if (rc) break;
+            c->result_slot = first;
+            rc = enqueue_step(c, flags, false);
+            passes.push_back(Pass{sb + first, n, c->seq, first});
+        }
+        c->result_slot = 0;
+        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+        bool polled = c->spin_wait != 0;
+        for (const Pass& p : passes)
+            if (polled && !spin_for_records(c, p.slot, p.n, A, p.seq)) polled = false;
+        if (!polled) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<Pass> again;
+        for (const Pass& p : passes) {
+            unsigned bad = 0;
+            for (int ag = 0; ag < p.n; ++ag) bad |= c->h_result[p.slot + ag].flags & (kResNeedsResolve | DV_RES_OVERFLOW | kResSenseError);
+            if (bad) { again.push_back(p); continue; }
+            for (int ag = 0; ag < p.n; ++ag) {
+                memcpy(&results[p.first + ag], &c->h_result[p.slot + ag], sizeof(dv_step_result));
+                for (int a = A; a < kMaxHeadings; ++a) {
+                    results[p.first + ag].angle_fam[a] = 0.0; results[p.first + ag].angle_view[a] = -1;
+                    results[p.first + ag].exact_fam[a] = 0.0; results[p.first + ag].exact_view[a] = -1;
+                }
+            }
+        }
+        for (const Pass& p : again) {
+            rc = stage(p.first, p.n);
+            if (rc) return rc;
+            rc = enqueue_step(c, flags, false);
+            if (rc) return rc;
+            rc = finish_pass(c);
+            if (rc) return rc;
+            if (c->h_result[0].flags & kResSenseError)
+                return fail(c, DV_ERR_INDEX, "a sensor footprint of agents %d..%d reaches past the end of the landscape "
+                            "(index out of bounds)", p.first, p.first + p.n - 1);
+            for (int ag = 0; ag < p.n; ++ag) copy_result(c, ag, &results[p.first + ag]);
+        }
+    }
+    return rc;
+}
+
 // Ensemble form of dv_sense_step: n_agents agents, each at its own position with its own A headings, sensed and
 // scored against the one resident library, 64/A agents per library pass; nothing but poses goes up.
 extern "C" int dv_sense_step_batch(dv_ctx* c, const double* x, const double* y, const double* angles, int n_agents, int A,
@@ -708,26 +766,14 @@ extern "C" int dv_sense_step_batch(dv_ctx* c, const double* x, const double* y, 
     if (rc) return rc;
     if (!x || !y || !angles || !results || n_agents < 1) return fail(c, DV_ERR_INVALID, "dv_sense_step_batch: bad arguments");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int per_pass = kMaxHeadings / A;
-    for (int first = 0; first < n_agents; first += per_pass) {
-        const int n = (n_agents - first < per_pass) ? n_agents - first : per_pass;
+    return run_batch(c, n_agents, A, flags, results, [&](int first, int n) {
         PoseSet poses;
         for (int ag = 0; ag < n; ++ag)
             for (int a = 0; a < A; ++a)
                 poses.p[ag * A + a] = make_pose(x[first + ag], y[first + ag], angles[(size_t)(first + ag) * A + a]);
         for (int a = n * A; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
-        rc = sense_prep_launch(c, poses, n, A);
-        if (rc) return rc;
-        rc = enqueue_step(c, flags, false);
-        if (rc) return rc;
-        rc = finish_pass(c);
-        if (rc) return rc;
-        if (c->h_result[0].flags & kResSenseError)
-            return fail(c, DV_ERR_INDEX, "a sensor footprint of agents %d..%d reaches past the end of the landscape "
-                        "(index out of bounds)", first, first + n - 1);
-        for (int ag = 0; ag < n; ++ag) copy_result(c, ag, &results[first + ag]);
-    }
-    return DV_OK;
+        return sense_prep_launch(c, poses, n, A);
+    });
 }
 
 // One full agent step's device work in one call: sense the heading patches at (x, y), score them, decide.
@@ -1151,7 +1197,8 @@ static void launch_finish(dv_ctx* c, int want_scene, int force) {
     const LibCfg& g = c->cfg;
     hipLaunchKernelGGL(k_finish<NT>, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream,
                        c->d_part, c->d_hsconst, c->nchunk, c->APAD, c->int_has_hs, c->int_has_v, c->d_state, c->d_bsum, c->d_ctmp,
-                       c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg, c->A_agent, c->delta, want_scene, force,
+                       c->d_cand, c->d_scene, c->d_result + c->result_slot,
+                       c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta, want_scene, force,
                        ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr);
 }
 
@@ -1170,7 +1217,8 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
         else launch_finish<4>(c, scene_on, force);
     } else {
         hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
-                           c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result, c->d_record, c->cfg,
+                           c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result + c->result_slot,
+                           c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,
                            c->A_agent, c->delta, scene_on, c->exact, force, ++c->seq,
                            c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->metric == 1 ? 3e-6 : 0.0);
     }
@@ -1211,23 +1259,23 @@ extern "C" int dv_step_enqueue(dv_ctx* c, uint32_t flags) {
 // scores if a candidate list overflowed.  Results are left in c->h_result[0 .. n_agents).
 // Host wait for k_tail: the last word of every agent's record (n_headings | seq << 32) is stored after a
 // system-scope release, so once all agents show the current sequence number their records are complete.
-static bool spin_for_results(dv_ctx* c) {
+// Polls result records [slot, slot + n) until each shows sequence number `seq` and a matching check word.
+static bool spin_for_records(dv_ctx* c, int slot, int n, int A, int seq) {
     const auto t0 = std::chrono::steady_clock::now();
-    const int A = c->A_agent;
-    for (int ag = 0; ag < c->n_agents; ++ag) {
-        volatile const int* word = &c->h_result[ag].reserved;
-        volatile const unsigned long long* w = reinterpret_cast<volatile const unsigned long long*>(&c->h_result[ag]);
+    for (int ag = 0; ag < n; ++ag) {
+        volatile const int* word = &c->h_result[slot + ag].reserved;
+        volatile const unsigned long long* w = reinterpret_cast<volatile const unsigned long long*>(&c->h_result[slot + ag]);
         unsigned spins = 0;
         for (;;) {
-            if (*word == c->seq) {
-                // k_tail stores the record without a fence: take it only when its check word agrees with its words
+            if (*word == seq) {
+                // the record is stored without a fence: take it only when its check word agrees with its words
                 std::atomic_thread_fence(std::memory_order_acquire);
                 unsigned long long snap[7 + 4 * kMaxHeadings];
                 for (int i = 0; i < 7; ++i) snap[i] = w[i];
                 for (int k = 0; k < 4; ++k)
                     for (int a = 0; a < A; ++a) snap[7 + k * kMaxHeadings + a] = w[7 + k * kMaxHeadings + a];
-                const unsigned long long check = *reinterpret_cast<volatile const unsigned long long*>(&c->h_result[ag].check);
-                if ((int)(snap[6] >> 32) == c->seq && record_check(snap, A) == check) break;
+                const unsigned long long check = *reinterpret_cast<volatile const unsigned long long*>(&c->h_result[slot + ag].check);
+                if ((int)(snap[6] >> 32) == seq && record_check(snap, A) == check) break;
             }
             if ((++spins & 1023u) == 0 &&
                 std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;   // fall back
@@ -1236,6 +1284,8 @@ static bool spin_for_results(dv_ctx* c) {
     std::atomic_thread_fence(std::memory_order_acquire);
     return true;
 }
+
+static bool spin_for_results(dv_ctx* c) { return spin_for_records(c, 0, c->n_agents, c->A_agent, c->seq); }
 
 static int finish_pass(dv_ctx* c) {
     if (!c->step_pending) return fail(c, DV_ERR_STATE, "no step enqueued");
@@ -1315,23 +1365,17 @@ extern "C" int dv_step_batch(dv_ctx* c, const uint8_t* patches, int n_agents, in
     if (rc) return rc;
     if (!patches || !results || n_agents < 1) return fail(c, DV_ERR_INVALID, "dv_step_batch: bad arguments");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int per_pass = kMaxHeadings / A;
     const size_t agent_bytes = (size_t)A * c->cfg.P * 3;
-    for (int first = 0; first < n_agents; first += per_pass) {
-        const int n = (n_agents - first < per_pass) ? n_agents - first : per_pass;
-        HIP_TRY(c, hipMemcpyAsync(c->d_raw_patches, patches + (size_t)first * agent_bytes, (size_t)n * agent_bytes,
-                                  hipMemcpyHostToDevice, c->stream));
-        rc = prep_patches(c, n * A);
-        if (rc) return rc;
+    return run_batch(c, n_agents, A, flags, results, [&](int first, int n) {
+        if (hipMemcpyAsync(c->d_raw_patches, patches + (size_t)first * agent_bytes, (size_t)n * agent_bytes, hipMemcpyHostToDevice,
+                           c->stream) != hipSuccess)
+            return fail(c, DV_ERR_HIP, "dv_step_batch: patch upload failed: %s", hipGetErrorString(hipGetLastError()));
+        const int rc2 = prep_patches(c, n * A);
+        if (rc2) return rc2;
         c->n_agents = n;
         c->A_agent = A;
-        rc = enqueue_step(c, flags, false);
-        if (rc) return rc;
-        rc = finish_pass(c);
-        if (rc) return rc;
-        for (int ag = 0; ag < n; ++ag) copy_result(c, ag, &results[first + ag]);
-    }
-    return DV_OK;
+        return (int)DV_OK;
+    });
 }
 
 extern "C" int dv_resolve(dv_ctx* c, dv_step_result* result) {
