@@ -173,6 +173,8 @@ def main():
                     "HIP events (roofline.kernel_ms); 1 = every step")
     ap.add_argument("--batch-agents", type=int, default=32, help="agents of the ensemble block (configs[4] share of one "
                     "GPU; 0 = skip)")
+    ap.add_argument("--exchange", choices=["rccl", "mailbox"], default="rccl", help="per-step exchange between ranks: one RCCL "
+                    "all-gather (default), or the single-node mailbox in host-shared memory (no collective kernel)")
     ap.add_argument("--skip-known-answer", action="store_true", help="experiments with deliberately broken kernels only")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank "
                     "(exercises the RCCL exchange path on a single GPU)")
@@ -220,7 +222,9 @@ def main():
     info = eng.library_info()
 
     exchange = None
-    if use_dist and args.backend == "nccl":
+    if use_dist and args.exchange == "mailbox":
+        exchange = sharded.MailboxExchange(eng, rank, world)
+    elif use_dist and args.backend == "nccl":
         exchange = sharded.DeviceExchange(eng, rank, world, torch.device("cuda", device_index))
 
     def one_step():
@@ -316,9 +320,10 @@ def main():
                 "workgroup_shape": eng.workgroup_shape(A),
                 "bytes_per_pixel_reference": s_ref, "bytes_per_pixel_stored": info["n_planes"], "parallelism": "library sharded x%d" % world,
                 "exchange": "none" if not use_dist else "1 all-gather of per-heading records per step (%s)" % (
-                    ("RCCL ncclAllGather on the step's stream, device-resident"
-                     if (exchange is not None and exchange.direct is not None) else "RCCL via torch.distributed, device-resident")
-                    if args.backend == "nccl" else args.backend),
+                    "mailbox in host-shared memory, no collective" if args.exchange == "mailbox" else
+                    (("RCCL ncclAllGather on the step's stream, device-resident"
+                      if (exchange is not None and exchange.direct is not None) else "RCCL via torch.distributed, device-resident")
+                     if args.backend == "nccl" else args.backend)),
             },
             "nav_steps_per_s": args.steps / dt,
             "best_heading": int(res["best_idex"]),

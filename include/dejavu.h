@@ -208,6 +208,20 @@ int dv_publish(dv_ctx *ctx, const void *device_src, int64_t n_doubles);
 int dv_publish_wait(dv_ctx *ctx, double *dst, int64_t n_doubles);
 
 /*
+ * Mailbox exchange for the ranks of ONE node (an alternative to an all-gather: no collective kernel at all).
+ * host_base: a page-aligned host segment that every rank's process has mapped (e.g. a file in /dev/shm), laid out as
+ * [slots][world][512 doubles]; dv_set_mailbox registers it with this context's GPU (NULL detaches).
+ * dv_mailbox_post enqueues, behind the step's kernels, the copy of this rank's packed record (dv_step_record) into
+ * entry [slot][rank] with sequence number seq; dv_mailbox_wait polls (host) until the ranks of rank_mask have posted
+ * seq into `slot` and copies their records to records[r * stride ..] (timeout_ms <= 0: wait for ever).  A slot may be
+ * reused once every rank has read it: two slots per exchange round alternate safely, because nobody posts step
+ * s + 2 before everybody has posted step s + 1, i.e. has finished reading step s.
+ */
+int dv_set_mailbox(dv_ctx *ctx, void *host_base, int64_t bytes, int rank, int world);
+int dv_mailbox_post(dv_ctx *ctx, int slot, uint64_t seq);
+int dv_mailbox_wait(dv_ctx *ctx, int slot, uint64_t seq, uint64_t rank_mask, double *records, int64_t stride, int timeout_ms);
+
+/*
  * The global decision from the gathered per-rank records (the sharded form of NavBySceneFamiliarity.py:313-316);
  * identical on every rank.  records[r * stride .. ] is rank r's record as laid out by dv_step_record.  Host
  * arithmetic only: no context, no GPU.  When ranks that contend for the maximum (approx_max within delta of the

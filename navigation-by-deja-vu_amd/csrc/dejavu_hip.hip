@@ -15,6 +15,7 @@
 #include <limits>
 #include <cstdarg>
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -86,6 +87,9 @@ struct dv_ctx {
     bool step_pending = false;
     bool patches_sensed = false;              // resident patches were produced by k_sense (its error flag is live)
     int seq = 0;                              // sequence number of the last enqueued pass (written back by k_tail)
+    double* h_mbox = nullptr;                 // mailbox exchange: the node's shared host segment [slots][world][kMboxEntry]
+    double* d_mbox = nullptr;                 // its address on this GPU (hipHostRegister)
+    int mbox_rank = 0, mbox_world = 0, mbox_slots = 0;
     double* h_pub = nullptr;                  // mapped host buffer of dv_publish: [8 doubles: sequence word][payload]
     double* d_pub = nullptr;                  // its device address
     int64_t pub_cap = 0;                      // payload capacity in doubles
@@ -197,6 +201,7 @@ extern "C" void dv_destroy(dv_ctx* c) {
     if (c->d_sense) (void)hipFree(c->d_sense);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->h_pub) (void)hipHostFree(c->h_pub);
+    if (c->h_mbox) (void)hipHostUnregister(c->h_mbox);
     for (auto e : c->pev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -214,6 +219,66 @@ extern "C" int dv_set_stream(dv_ctx* c, void* s) {
 extern "C" int dv_set_exact(dv_ctx* c, int exact) {
     if (!c) return DV_ERR_INVALID;
     c->exact = exact ? 1 : 0;
+    return DV_OK;
+}
+
+extern "C" int dv_set_mailbox(dv_ctx* c, void* host_base, int64_t bytes, int rank, int world) {
+    if (!c) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_mbox) { (void)hipHostUnregister(c->h_mbox); c->h_mbox = nullptr; c->d_mbox = nullptr; }
+    if (!host_base) return DV_OK;                                   // detach
+    const int64_t per_slot = (int64_t)world * kMboxEntry * (int64_t)sizeof(double);
+    if (world < 1 || world > 64 || rank < 0 || rank >= world || bytes < per_slot || ((uintptr_t)host_base & 4095))
+        return fail(c, DV_ERR_INVALID, "dv_set_mailbox: bad arguments");
+    HIP_TRY(c, hipHostRegister(host_base, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    c->h_mbox = (double*)host_base;
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_mbox, host_base, 0));
+    c->mbox_rank = rank; c->mbox_world = world; c->mbox_slots = (int)(bytes / per_slot);
+    return DV_OK;
+}
+
+extern "C" int dv_mailbox_post(dv_ctx* c, int slot, uint64_t seq) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->d_mbox || slot < 0 || slot >= c->mbox_slots) return fail(c, DV_ERR_STATE, "dv_mailbox_post: no mailbox or bad slot");
+    if (!c->have_lib || c->A < 1) return fail(c, DV_ERR_STATE, "no library or no resident patches");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double* entry = c->d_mbox + ((size_t)slot * c->mbox_world + c->mbox_rank) * kMboxEntry;
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(256), 0, c->stream, c->d_record, entry, 3 + 4 * c->A, (unsigned long long)seq);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+extern "C" int dv_mailbox_wait(dv_ctx* c, int slot, uint64_t seq, uint64_t rank_mask, double* records, int64_t stride,
+                               int timeout_ms) {
+    if (!c || !records) return DV_ERR_INVALID;
+    if (!c->h_mbox || slot < 0 || slot >= c->mbox_slots || c->A < 1) return fail(c, DV_ERR_STATE, "dv_mailbox_wait: no mailbox or bad slot");
+    const int n = 3 + 4 * c->A;
+    if (stride < n) return fail(c, DV_ERR_INVALID, "dv_mailbox_wait: stride %lld < record size %d", (long long)stride, n);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < c->mbox_world; ++r) {
+        if (!((rank_mask >> r) & 1)) continue;
+        volatile const unsigned long long* e =
+            reinterpret_cast<volatile const unsigned long long*>(c->h_mbox + ((size_t)slot * c->mbox_world + r) * kMboxEntry);
+        double* out = records + (size_t)r * stride;
+        unsigned spins = 0;
+        for (;;) {
+            if (e[0] == seq) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                unsigned long long x = 0x9E3779B97F4A7C15ull ^ (seq * 0xD1B54A32D192ED03ull);
+                for (int i = 0; i < n; ++i) {
+                    const unsigned long long w = e[2 + i];
+                    memcpy(&out[i], &w, sizeof w);
+                    x ^= w * (unsigned long long)(2 * i + 3);
+                }
+                if (e[0] == seq && x == e[1]) break;
+            }
+            if ((++spins & 1023u) == 0 && timeout_ms > 0 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms))
+                return fail(c, DV_ERR_STATE, "dv_mailbox_wait: rank %d has not posted sequence %llu within %d ms", r,
+                            (unsigned long long)seq, timeout_ms);
+        }
+    }
     return DV_OK;
 }
 

@@ -670,6 +670,33 @@ k_publish(const double* __restrict__ src, double* __restrict__ dst, unsigned lon
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------ mailbox exchange (one node, host-shared memory)
+// One entry per (slot, rank) of a host segment that every rank's process has mapped and registered with its GPU:
+//   entry = kMboxEntry doubles: [0] sequence number, [1] check word (bits), [2 .. 2+n) the rank's packed record.
+// k_post copies this rank's record into its entry (the stores go over PCIe to host memory; the other ranks' HOSTS
+// poll them), payload and check word first, no fence: the reader validates the check word, as for the step record.
+constexpr int kMboxEntry = 512;     // 4 KB: 3 + 4*64 record doubles fit
+__global__ void __launch_bounds__(256)
+k_post(const double* __restrict__ rec, double* __restrict__ entry, int n, unsigned long long seq) {
+    __shared__ unsigned long long s_x;
+    if (threadIdx.x == 0) s_x = 0x9E3779B97F4A7C15ull ^ (seq * 0xD1B54A32D192ED03ull);
+    __syncthreads();
+    unsigned long long x = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = rec[i];
+        entry[2 + i] = v;
+        x ^= (unsigned long long)__double_as_longlong(v) * (unsigned long long)(2 * i + 3);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x ^= __shfl_xor(x, o);
+    if ((threadIdx.x & 63) == 0 && x != 0) atomicXor(&s_x, x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        reinterpret_cast<unsigned long long*>(entry)[1] = s_x;
+        reinterpret_cast<unsigned long long*>(entry)[0] = seq;
+    }
+}
+
 // ------------------------------------------------------------------ exact (sequential fp64) scoring
 // fam[a][f] = the reference's value bit for bit: per-pixel terms in the reference's operation
 // order, accumulated sequentially in row-major pixel order (navsim/util.pyx:44-73).

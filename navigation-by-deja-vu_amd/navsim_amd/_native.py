@@ -124,6 +124,9 @@ PROTOTYPES = {
     "dv_resolve_enqueue": (ctypes.c_int, [_ctx_p]),
     "dv_publish": (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int64]),
     "dv_publish_wait": (ctypes.c_int, [_ctx_p, _f64p, ctypes.c_int64]),
+    "dv_set_mailbox": (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "dv_mailbox_post": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_uint64]),
+    "dv_mailbox_wait": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, _f64p, ctypes.c_int64, ctypes.c_int]),
     "dv_merge_records": (ctypes.c_int, [_f64p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                                         ctypes.POINTER(MergeOut)]),
     "dv_synchronize": (ctypes.c_int, [_ctx_p]),

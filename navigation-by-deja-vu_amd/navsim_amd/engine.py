@@ -345,6 +345,19 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_publish_wait(self._ctx, N.f64ptr(out), out.size), "dv_publish_wait")
         return out
 
+    def set_mailbox(self, address, n_bytes, rank, world):
+        """Attach (address = 0: detach) the node's shared host segment of the mailbox exchange, see dv_set_mailbox."""
+        self._check(self._lib.dv_set_mailbox(self._ctx, ctypes.c_void_p(int(address) or None), int(n_bytes), int(rank), int(world)),
+                    "dv_set_mailbox")
+
+    def mailbox_post(self, slot, seq):
+        self._check(self._lib.dv_mailbox_post(self._ctx, int(slot), int(seq)), "dv_mailbox_post")
+
+    def mailbox_wait(self, slot, seq, rank_mask, records, timeout_ms=20000):
+        self._check(self._lib.dv_mailbox_wait(self._ctx, int(slot), int(seq), int(rank_mask), N.f64ptr(records),
+                                              records.shape[1], int(timeout_ms)), "dv_mailbox_wait")
+        return records
+
     def workgroup_shape(self, n_headings):
         """Shape of the scoring kernel in use for this many headings (0: not timed yet / not applicable)."""
         v = ctypes.c_int(0)

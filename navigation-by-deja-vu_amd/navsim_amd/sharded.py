@@ -410,6 +410,96 @@ class DeviceExchange(object):
         return out
 
 
+class MailboxExchange(object):
+    """Per-step exchange of the ranks of ONE node through a host segment they all map (dv_set_mailbox): every rank's
+    GPU writes its 2 KB record into its entry of the segment behind the step's kernels (one tiny kernel, the stores
+    cross PCIe), every rank's host polls the entries.  No collective kernel, no stream hops, no device-to-host copy;
+    torch.distributed (any backend) is used once, to agree on the segment's name.  Same records, same merge and same
+    tie protocol as DeviceExchange, hence the same decisions.  Opt-in: bench.py --exchange mailbox.
+
+    Slots: (step parity) x (round 1 / round 2).  Reusing a slot two steps later is safe: nobody posts step s + 2 before
+    everybody has posted step s + 1, which each rank does only after it has finished reading step s.
+    """
+
+    SLOTS = 4
+    ENTRY = 512                     # doubles per (slot, rank) entry, kMboxEntry of csrc/dejavu_kernels.h
+
+    def __init__(self, engine, rank, world_size, rendezvous=None, timeout_ms=20000):
+        import mmap
+        self.engine, self.rank, self.world, self.timeout_ms = engine, rank, world_size, timeout_ms
+        if rendezvous is None:
+            import torch.distributed as dist
+
+            def rendezvous(obj):
+                box = [obj]
+                dist.broadcast_object_list(box, src=0)
+                dist.barrier()
+                return box[0]
+        size = (self.SLOTS * world_size * self.ENTRY * 8 + 4095) // 4096 * 4096
+        name = None
+        if rank == 0:
+            name = "/dev/shm/dejavu_mbox_%d_%08x" % (os.getpid(), int.from_bytes(os.urandom(4), "little"))
+            with open(name, "wb") as f:
+                f.truncate(size)
+        name = rendezvous(name)                              # everybody knows the name, and the file exists
+        fd = os.open(name, os.O_RDWR)
+        try:
+            self._mm = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        rendezvous(None)                                     # everybody has mapped it: the name can go
+        if rank == 0:
+            os.unlink(name)
+        self._anchor = ctypes.c_char.from_buffer(self._mm)
+        engine.set_mailbox(ctypes.addressof(self._anchor), size, rank, world_size)
+        self.delta = engine.library_info()["delta"]
+        _, n = engine.step_record()
+        self.n, self.A = n, (n - 3) // 4
+        self.host = np.empty((world_size, n), dtype=np.float64)
+        self._round2 = np.empty((world_size, n), dtype=np.float64)
+        self.all_mask = (1 << world_size) - 1
+        self.step_no = 0
+        self.exchanges = 0
+
+    def step(self):
+        self.step_no += 1
+        base = (self.step_no & 1) * 2
+        seq = 2 * self.step_no
+        eng = self.engine
+        eng.step_enqueue(want_scene=False)
+        eng.mailbox_post(base, seq)
+        records = eng.mailbox_wait(base, seq, self.all_mask, self.host, self.timeout_ms)
+        self.exchanges += 1
+        again, ranks, out = merge_records_native(records, self.delta, self.A)
+        if again:
+            redo = [r for r in ranks if records[r, 2] == 0.0]        # known to every rank from the first round
+            if self.rank in redo:
+                if records[self.rank, 1] > CANDIDATE_CAP:
+                    eng.set_exact(True)
+                    eng.step_enqueue(want_scene=False)
+                    eng.set_exact(False)
+                else:
+                    eng.resolve_enqueue()
+                eng.mailbox_post(base + 1, seq + 1)
+            mask = 0
+            for r in redo:
+                mask |= 1 << r
+            eng.mailbox_wait(base + 1, seq + 1, mask, self._round2, self.timeout_ms)
+            for r in redo:
+                records[r] = self._round2[r]
+            self.exchanges += 1
+            again, ranks, out = merge_records_native(records, self.delta, self.A)
+            if again:
+                raise RuntimeError("contending ranks %r did not resolve their candidates" % (ranks,))
+        return out
+
+    def close(self):
+        self.engine.synchronize()
+        self.engine.set_mailbox(0, 0, 0, 1)
+        del self._anchor
+        self._mm.close()
+
+
 class ShardedDeviceEngine(object):
     """What navsim_amd.NavBySceneFamiliarity needs from its engine, over a library sharded across ranks with the
     sensor model on every GPU: the landscape is replicated, each rank senses and keeps its own block of the training

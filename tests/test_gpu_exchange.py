@@ -143,3 +143,63 @@ def test_device_sharded_agent_with_gpu_sensor_single_rank():
             nsf._engine.close()
     finally:
         dist.destroy_process_group()
+
+
+def _mailbox_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # rendezvous only: the exchange is the mailbox
+    out = []
+    try:
+        eng = navsim_amd.FamiliarityEngine(0)
+        for name, cw in (("plain", 0.0), ("ties", 0.3)):
+            lib, pats = _library_with_ties()
+            if name == "plain":
+                pats = synth.synth_patches(78, 7, 12, 12)
+                pats[2] = synth.near_match_patch(lib[700], 3)
+            lo, hi = sharded.shard_bounds(len(lib), world, rank)
+            eng.set_library(lib[lo:hi], cw, first_view=lo)
+            eng.upload_patches(pats)
+            ex = sharded.MailboxExchange(eng, rank, world)
+            for _ in range(5):                                         # slots are reused from the third step on
+                res = ex.step()
+            out.append((name, res["best_idex"], res["best_view"], float(res["step_familiarity"]),
+                        np.asarray(res["angle_familiarity"]).tolist(), ex.exchanges))
+            ex.close()
+        eng.close()
+        q.put((rank, out))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_mailbox_exchange_three_ranks_on_one_gpu():
+    """The mailbox exchange with three processes sharing this GPU (one context and one library shard each): decisions,
+    cross-rank ties included, equal the unsharded reference on every rank."""
+    import torch.multiprocessing as mp
+    world = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mailbox_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lib, tie_pats = _library_with_ties()
+    plain = synth.synth_patches(78, 7, 12, 12)
+    plain[2] = synth.near_match_patch(lib[700], 3)
+    want = {"plain": oracle.step(lib, plain, 0.0), "ties": oracle.step(lib, tie_pats, 0.3)}
+    for rank in range(world):
+        for name, best, view, fam, angle, exchanges in got[rank]:
+            w = want[name]
+            assert (best, view) == (w["best_idex"], w["best_view"]), (rank, name)
+            np.testing.assert_allclose(fam, w["step_familiarity"], rtol=1e-12)
+            np.testing.assert_allclose(angle, w["angle_familiarity"], rtol=1e-12)
+            assert exchanges >= (10 if name == "ties" else 5)          # ties take the second round every step
