@@ -1273,13 +1273,14 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     const int scene_on = (want_scene && c->n_agents == 1) ? 1 : 0;
     // integer path: the scoring kernel's partial sums go straight to k_finish (combine + reductions + decision in one
     // launch); the exact mode and ssd_f32 produce fam[] first and end in k_tail
-    const bool fused = c->finish_fused && c->metric == 0 && !c->exact;
+    // (more than 32 headings of ONE agent would put 64 scores per thread in registers -- one wave per SIMD -- and
+    // measured slower than the two-kernel form: 1103 vs 1029 us at 200 000 views x 64 headings)
+    const bool fused = c->finish_fused && c->metric == 0 && !c->exact && c->A_agent <= 32;
     int rc = launch_scoring(c, !fused);
     if (rc) return rc;
     if (fused) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
-        else if (c->A_agent <= 32) launch_finish<2>(c, scene_on, force);
-        else launch_finish<4>(c, scene_on, force);
+        else launch_finish<2>(c, scene_on, force);
     } else {
         hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
                            c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result + c->result_slot,

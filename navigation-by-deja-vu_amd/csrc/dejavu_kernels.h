@@ -1236,14 +1236,24 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, int
                 }
             }
         } else {
-            for (int b = r; b < nb; b += G) {
-                const unsigned long long key = __hip_atomic_load(&bsum[((long long)b * 2 + 0) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (key != 0 && (key == amax_a || key >= thr_key)) {
-                    const unsigned long long view = __hip_atomic_load(&bsum[((long long)b * 2 + 1) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (key == amax_a) atomicMin(&s_aview[a], view);
-                    if (key >= thr_key) {
-                        const unsigned pos = atomicAdd(&s_ncount, 1u);
-                        if (pos < (unsigned)kCandCap) cand[pos] = ((unsigned long long)a << 40) | view;
+            for (int b0 = r; b0 < nb; b0 += G * kBatch) {              // the maxima again, a batch per round trip
+                unsigned long long t8[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int b = (b0 + j * G < nb) ? b0 + j * G : nb - 1;
+                    t8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 0) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int b = b0 + j * G;
+                    const unsigned long long key = t8[j];
+                    if (b < nb && key != 0 && (key == amax_a || key >= thr_key)) {   // few blocks qualify: their views one by one
+                        const unsigned long long view = __hip_atomic_load(&bsum[((long long)b * 2 + 1) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (key == amax_a) atomicMin(&s_aview[a], view);
+                        if (key >= thr_key) {
+                            const unsigned pos = atomicAdd(&s_ncount, 1u);
+                            if (pos < (unsigned)kCandCap) cand[pos] = ((unsigned long long)a << 40) | view;
+                        }
                     }
                 }
             }
