@@ -58,7 +58,7 @@ struct dv_ctx {
     unsigned long long* d_bsum = nullptr;     // k_finish: per-block, per-heading (maximum, first view) [blocks][2][headings]
     unsigned long long* d_ctmp = nullptr;     // k_finish: shared extra-candidate list [agents][kTmpCap][2]
     int int_has_hs = 0, int_has_v = 0;        // which sums the last integer scoring pass produced
-    int finish_fused = 1;                     // DEJAVU_FINISH: integer-path steps end in k_finish (0: k_combine + k_tail)
+    int finish_fused = 1;                     // DEJAVU_FINISH: integer-path steps end in k_finish where it pays (0: never, 2: whenever possible)
     unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
     unsigned long long* d_pmax = nullptr;     // [64][max(G, Fpad/256)] partial maxima
     int n_partial = 0;                        // partial maxima per heading left in d_pmax by the last scoring
@@ -182,7 +182,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
     env_int("DEJAVU_SHAPE", c->shape_env, 0, 5);
-    env_int("DEJAVU_FINISH", c->finish_fused, 0, 1);
+    env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -1273,9 +1273,11 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     const int scene_on = (want_scene && c->n_agents == 1) ? 1 : 0;
     // integer path: the scoring kernel's partial sums go straight to k_finish (combine + reductions + decision in one
     // launch); the exact mode and ssd_f32 produce fam[] first and end in k_tail
-    // (more than 32 headings of ONE agent would put 64 scores per thread in registers -- one wave per SIMD -- and
-    // measured slower than the two-kernel form: 1103 vs 1029 us at 200 000 views x 64 headings)
-    const bool fused = c->finish_fused && c->metric == 0 && !c->exact && c->A_agent <= 32;
+    // Where it pays (measured, DEJAVU_FINISH=0/1/2): up to 16 headings per agent and libraries from ~32 k views.
+    // 32 headings per agent: equal at 200 000 views, 5 us slower at 20 000; 64 (64 scores per thread in registers,
+    // one wave per SIMD): 1103 vs 1029 us at 200 000 views; 8-16 headings on 20 000 views: 1-2 us slower.
+    const bool fused = c->metric == 0 && !c->exact && c->A_agent <= 32 &&
+                       (c->finish_fused == 2 || (c->finish_fused == 1 && c->A_agent <= 16 && g.F >= 32768));
     int rc = launch_scoring(c, !fused);
     if (rc) return rc;
     if (fused) {

@@ -14,9 +14,20 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
-    e = navsim_amd.FamiliarityEngine(device=0)
+@pytest.fixture(scope="module", params=["k_finish", "k_combine+k_tail"])
+def eng(request):
+    """Every test runs with steps ending in k_finish wherever possible and in the two-kernel form (by default the
+    engine picks per library size and heading count, csrc/dejavu_hip.hip:enqueue_step)."""
+    import os
+    before = os.environ.get("DEJAVU_FINISH")
+    os.environ["DEJAVU_FINISH"] = "2" if request.param == "k_finish" else "0"
+    try:
+        e = navsim_amd.FamiliarityEngine(device=0)
+    finally:
+        if before is None:
+            os.environ.pop("DEJAVU_FINISH", None)
+        else:
+            os.environ["DEJAVU_FINISH"] = before
     yield e
     e.close()
 
