@@ -293,8 +293,9 @@ def main():
         # hues and no saturation above 127, one signed plane carries (H,S), i.e. 2 bytes per pixel instead of 3.
         stored_bytes = float(F) * h * w * info["n_planes"]
         achieved_stored = stored_bytes / (kern_ms * 1e-3) / 1e9
-        workload = ("%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g "
-                    "(BASELINE.json configs[1])" % (w, h, F, A, cw))
+        named = {(64, 50000, 16): " (BASELINE.json configs[1])", (128, 500000, 32): " (BASELINE.json configs[2])"}
+        workload = ("%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g%s"
+                    % (w, h, F, A, cw, named.get((w, F, A), "") if w == h else ""))
         traffic = committed_traffic(workload)
         # SURVEY.md 8(d) asks for both peaks: the spec figure and what a pure streaming read reaches on this device
         try:

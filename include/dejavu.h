@@ -89,6 +89,12 @@ typedef struct dv_lib_info {
     uint8_t hues[DV_MAX_HUE_PLANES];
     int32_t n_hues;             /* distinct hues with S > 0 in the library (entries of hues[] that are valid) */
     int32_t signed_saturation;  /* 1: two hues, S <= 127: one plane holds 128 + S(hue0) - S(hue1) */
+    /* bit-plane copy for the int8 matrix-core scoring path (libraries whose stored bytes come from few levels) */
+    int32_t bit_planes_hs;      /* thermometer planes of the saturation bytes (0: no bit-plane copy, or none needed) */
+    int32_t bit_planes_v;       /* thermometer planes of the value byte */
+    int32_t has_bit_planes;     /* 1: the bit-plane copy exists (scoring shape 6 is available) */
+    int32_t reserved_;
+    int64_t bit_tile_bytes;     /* bytes the matrix-core scoring kernel streams per pass */
 } dv_lib_info;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -116,6 +122,14 @@ int dv_generate_library(dv_ctx *ctx, uint64_t seed, int64_t n_views, int h, int 
                         double chem_weight, int64_t first_view);
 int dv_clear_library(dv_ctx *ctx);
 int dv_get_library_info(const dv_ctx *ctx, dv_lib_info *out);
+/*
+ * Host arithmetic of the bit-plane layout (no context, no GPU): the thermometer planes of one stored byte plane from
+ * the 256-bit presence map of its values (bit v of presence[v / 32] = value v occurs).  One plane per gap between
+ * consecutive levels, gaps wider than 127 split, so that |a - b| = const(a) + sum_t bit_t(b) * (w[t] - 2 * clamp(a -
+ * lo[t], 0, w[t])) with int8 coefficients for every byte a.  Returns the number of planes written to lo[] / w[]
+ * (0 for a single level), -1 when more than `cap` would be needed.
+ */
+int dv_bitplane_plan(const uint32_t *presence, int cap, uint8_t *lo, uint8_t *w, int *lmin, int *lmax);
 /* Copy the stored planes of local views [v0, v0+n) back as uint8[n, n_planes, h*w] (layout check). */
 int dv_read_planes(dv_ctx *ctx, int64_t v0, int64_t n, uint8_t *out);
 
@@ -251,8 +265,9 @@ int dv_timer_stop(dv_ctx *ctx, float *elapsed_ms);
 int dv_profile_kernel(dv_ctx *ctx, int enable);
 /* Sum and count of the bracketed scoring-kernel launches since the last read; resets. */
 int dv_profile_read(dv_ctx *ctx, double *total_ms, int64_t *n_launches);
-/* Workgroup shape of the scoring kernel in use for steps of n_headings headings on the resident library (1..5, see
- * csrc/dejavu_hip.hip:launch_tiles_apad; 0 = not timed yet, or not applicable to this library). */
+/* Workgroup shape of the scoring kernel in use for steps of n_headings headings on the resident library (1..5: forms
+ * of the byte-plane kernels, csrc/dejavu_hip.hip:launch_tiles_apad; 6: the bit-plane matrix-core kernel k_sad_mfma;
+ * 0 = not timed yet, or not applicable to this library). */
 int dv_workgroup_shape(dv_ctx *ctx, int n_headings, int *shape);
 /* Streaming-read microbenchmark over n_bytes of device memory (achievable HBM ceiling). */
 int dv_stream_read_gbps(dv_ctx *ctx, int64_t n_bytes, int iters, double *gbps);

@@ -69,7 +69,19 @@ struct dv_ctx {
     int shape_env = 0;                        // DEJAVU_SHAPE: workgroup shape of k_sad_tiles, 1..4 (0: timed once per library)
     int force_shape = 0;                      // set while tune_workgroup_shape() times a candidate
     int tuned_shape[4] = {0, 0, 0, 0};        // chosen shape per heading class (8, 16, 32, 64 resident); 0 = not timed yet
-    float tuned_us[4][5] = {};                // what the timing saw per shape (DEJAVU_VERBOSE prints it)
+    float tuned_us[4][6] = {};                // what the timing saw per shape (DEJAVU_VERBOSE prints it)
+    // bit-plane copy of the library for the int8 MFMA scoring path (k_sad_mfma), when its values come from few levels
+    bool bits_ok = false;
+    BitCfg bcfg{};
+    uint4* d_btiles = nullptr;                // [Fpad/32][GS][64]
+    size_t btile_bytes = 0;                   // of which streamed per pass: (Fpad/32) * (NK_hs + NK_v) KB
+    uint4* d_coef = nullptr;                  // [2 passes][NK][8][64] int8 coefficient image of the resident patches
+    int* d_bconst = nullptr;                  // [2][64] per-heading constants of the two sums
+    bool coef_ready = false;                  // d_coef / d_bconst describe the resident patches
+    int bits_env = 1;                         // DEJAVU_BITS: 0 never build the bit planes, 1 when they save bytes, 2 whenever possible
+    int mfma_tiles_env = 0, mfma_chunk_env = 0;   // DEJAVU_MFMA_TILES / DEJAVU_MFMA_CHUNK (0 = by library size)
+    const int* int_hsconst = nullptr;         // constants that go with the partial sums of the last integer scoring pass
+    const int* int_vconst = nullptr;
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -143,6 +155,8 @@ static void free_library(dv_ctx* c) {
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_bsum); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
+    F(c->d_btiles); F(c->d_coef); F(c->d_bconst);
+    c->bits_ok = false; c->coef_ready = false; c->btile_bytes = 0;
     c->metric = 0;
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
     if (c->h_result) { (void)hipHostFree(c->h_result); c->h_result = nullptr; c->d_result = nullptr; }
@@ -181,7 +195,10 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     };
     env_int("DEJAVU_TARGET_ITEMS", c->target_items, 1, 1 << 24);
     env_int("DEJAVU_WPC", c->waves_per_cu, 1, 32);
-    env_int("DEJAVU_SHAPE", c->shape_env, 0, 5);
+    env_int("DEJAVU_SHAPE", c->shape_env, 0, 6);
+    env_int("DEJAVU_BITS", c->bits_env, 0, 2);
+    env_int("DEJAVU_MFMA_TILES", c->mfma_tiles_env, 0, 2);
+    env_int("DEJAVU_MFMA_CHUNK", c->mfma_chunk_env, 0, 32);
     env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
@@ -410,6 +427,116 @@ static long long group_stride(const dv_ctx* c, long long kb) {
     return (kb + pad) * 64;
 }
 
+// ------------------------------------------------------------------ bit planes (MFMA scoring path)
+// Thermometer planes of one byte plane from the 256-bit presence map of its values: one plane per gap between
+// consecutive levels, gaps wider than 127 split so that every coefficient w - 2*alpha fits an int8.
+// Returns the number of planes (0 for a single level), or -1 when there are more than `cap`.
+static int plan_byte_plane(const uint32_t presence[8], int cap, uint8_t* lo, uint8_t* w, int* lmin, int* lmax) {
+    int levels[256], n = 0;
+    for (int v = 0; v < 256; ++v)
+        if (presence[v >> 5] & (1u << (v & 31))) levels[n++] = v;
+    if (n == 0) { levels[n++] = 0; }                    // nothing stored (cannot happen with F >= 1): one level, 0
+    *lmin = levels[0];
+    *lmax = levels[n - 1];
+    int t = 0;
+    for (int i = 0; i + 1 < n; ++i) {
+        int a = levels[i];
+        const int b = levels[i + 1];
+        while (a < b) {
+            const int step = (b - a) > 127 ? 127 : (b - a);
+            if (t >= cap) return -1;
+            lo[t] = (uint8_t)a;
+            w[t] = (uint8_t)step;
+            ++t;
+            a += step;
+        }
+    }
+    return t;
+}
+
+extern "C" int dv_bitplane_plan(const uint32_t* presence, int cap, uint8_t* lo, uint8_t* w, int* lmin, int* lmax) {
+    if (!presence || !lo || !w || !lmin || !lmax || cap < 0 || cap > 255) return DV_ERR_INVALID;
+    return plan_byte_plane(presence, cap, lo, w, lmin, lmax);
+}
+
+// Builds the bit-plane copy of the resident byte tiles when the library's values allow it.  Never fails the ingest:
+// a library that does not qualify simply keeps the byte path.
+static int build_bit_planes(dv_ctx* c) {
+    const LibCfg& g = c->cfg;
+    c->bits_ok = false;
+    if (c->bits_env == 0 || c->metric != 0 || g.generic) return DV_OK;
+    unsigned* d_presence = nullptr;
+    uint32_t presence[(kMaxHues + 1) * 8];
+    HIP_TRY(c, hipMalloc(&d_presence, sizeof presence));
+    hipError_t e = hipMemsetAsync(d_presence, 0, sizeof presence, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_level_scan, dim3(2048), dim3(256), 0, c->stream, c->d_tiles, c->cfg, d_presence);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(presence, d_presence, sizeof presence, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_presence);
+    if (e != hipSuccess) return fail(c, DV_ERR_HIP, "level scan: %s", hipGetErrorString(e));
+
+    BitCfg b{};
+    b.nbp = g.npl;
+    int t = 0;
+    for (int bp = 0; bp < g.npl; ++bp) {
+        if (bp == g.nhs) b.T[0] = t;                                   // HS planes come first
+        int lmin = 0, lmax = 0;
+        const int n = plan_byte_plane(presence + bp * 8, kMaxBitPlanes - t, b.lo + t, b.w + t, &lmin, &lmax);
+        if (n < 0) return DV_OK;                                        // too many levels: byte path
+        for (int k = 0; k < n; ++k) b.pl[t + k] = (unsigned char)bp;
+        b.lmin[bp] = (unsigned char)lmin;
+        b.lmax[bp] = (unsigned char)lmax;
+        t += n;
+    }
+    if (g.nhs == g.npl) b.T[0] = t;                                     // no value plane
+    b.T[1] = t - b.T[0];
+    const int total = t;
+    if (total == 0) return DV_OK;                                       // a constant library: nothing to stream either way
+    // worth it when it streams at most 3/4 of the bytes (DEJAVU_BITS=2: whenever the planes fit)
+    if (c->bits_env == 1 && total * 4 > g.npl * 8 * 3) return DV_OK;
+    // a segment's sum must fit an int32 with room to spare
+    for (int seg = 0; seg < 2; ++seg)
+        if ((double)b.T[seg] * g.P * 127.0 > 1.9e9) return DV_OK;
+    for (int seg = 0; seg < 2; ++seg) b.NK[seg] = (int)(((long long)b.T[seg] * g.P + 255) / 256);
+    const int nkt = b.NK[0] + b.NK[1];
+    b.GS = nkt | 1;
+    const long long G32 = g.Fpad / 32;
+    c->btile_bytes = (size_t)G32 * nkt * 1024;
+    if (hipMalloc(&c->d_btiles, (size_t)G32 * b.GS * 1024) != hipSuccess || hipMalloc(&c->d_coef, (size_t)2 * nkt * 8192) != hipSuccess ||
+        hipMalloc(&c->d_bconst, 2 * kMaxHeadings * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();                                        // not enough memory for the second copy: byte path
+        if (c->d_btiles) { (void)hipFree(c->d_btiles); c->d_btiles = nullptr; }
+        if (c->d_coef) { (void)hipFree(c->d_coef); c->d_coef = nullptr; }
+        if (c->d_bconst) { (void)hipFree(c->d_bconst); c->d_bconst = nullptr; }
+        return DV_OK;
+    }
+    c->bcfg = b;
+    const long long total_t = G32 * nkt * 64;
+    hipLaunchKernelGGL(k_bitpack, dim3((unsigned)((total_t + 255) / 256)), dim3(256), 0, c->stream, c->d_tiles, c->d_btiles, c->cfg, b);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->bits_ok = true;
+    c->coef_ready = false;
+    return DV_OK;
+}
+
+// Coefficient image + constants of the resident patches (raw bytes in d_raw_patches), when the MFMA path may score them.
+static bool mfma_path_possible(const dv_ctx* c);
+static int enqueue_bit_prep(dv_ctx* c, bool force = false) {
+    c->coef_ready = false;
+    if (!c->bits_ok || !(force || mfma_path_possible(c))) return DV_OK;
+    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
+    const int npass = c->APAD > 32 ? 2 : 1;
+    hipLaunchKernelGGL(k_bit_prep, dim3((unsigned)(nkt * npass + c->A)), dim3(512), 0, c->stream, c->d_raw_patches, c->d_coef,
+                       c->d_bconst, c->cfg, c->bcfg, c->A, npass);
+    HIP_TRY(c, hipGetLastError());
+    c->coef_ready = true;
+    return DV_OK;
+}
+
 // ------------------------------------------------------------------ library
 static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t first,
                          int n_hues, const unsigned char* hues, int generic, int max_s = 255) {
@@ -516,6 +643,8 @@ static int ingest_raw(dv_ctx* c, const unsigned char* d_raw, int64_t F, int h, i
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "retile: %s", hipGetErrorString(e)); }
+    rc = build_bit_planes(c);
+    if (rc) { free_library(c); return rc; }
     return DV_OK;
 }
 
@@ -739,7 +868,7 @@ static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int 
                        c->d_hsconst_pair + nxt * kMaxHeadings, c->d_err + nxt);
     HIP_TRY(c, hipGetLastError());
     c->patches_sensed = true;      // no host synchronisation here: the step's result record carries the error flag
-    return DV_OK;
+    return enqueue_bit_prep(c);
 }
 
 static int check_sense_args(dv_ctx* c, int A) {
@@ -885,6 +1014,8 @@ extern "C" int dv_generate_library(dv_ctx* c, uint64_t seed, int64_t F, int h, i
                        c->cfg, (unsigned long long)seed);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = build_bit_planes(c);
+    if (rc) { free_library(c); return rc; }
     return DV_OK;
 }
 
@@ -915,6 +1046,10 @@ extern "C" int dv_get_library_info(const dv_ctx* c, dv_lib_info* o) {
     for (int k = 0; k < kMaxHues; ++k) o->hues[k] = c->cfg.hues[k];
     o->n_hues = 0;
     if (c->cfg.cw > 0.0 && !c->cfg.generic) o->n_hues = c->cfg.signed_s ? 2 : c->cfg.nhs;
+    o->has_bit_planes = c->bits_ok ? 1 : 0;
+    o->bit_planes_hs = c->bits_ok ? c->bcfg.T[0] : 0;
+    o->bit_planes_v = c->bits_ok ? c->bcfg.T[1] : 0;
+    o->bit_tile_bytes = c->bits_ok ? (int64_t)c->btile_bytes : 0;
     return DV_OK;
 }
 
@@ -949,7 +1084,7 @@ static int prep_patches(dv_ctx* c, int A) {
     hipLaunchKernelGGL(k_prep, dim3(nb + A), dim3(256), 0, c->stream, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, A,
                        c->APAD);
     HIP_TRY(c, hipGetLastError());
-    return DV_OK;
+    return enqueue_bit_prep(c);
 }
 
 static int check_step_args(dv_ctx* c, int A) {
@@ -1056,10 +1191,12 @@ static void launch_packed_apad(dv_ctx* c) {
 // Which one wins depends on the library size and the heading count (tools/sweep_grid.sh), so the shapes are timed once
 // per library and heading class (tune_workgroup_shape).  The integer sums are identical in every shape.
 static int apad_class(int APAD) { return APAD == 8 ? 0 : (APAD == 16 ? 1 : (APAD == 32 ? 2 : 3)); }
-//   5: k_sad_packed (libraries with both sums only), all resident headings in one pass.
-constexpr int kMaxShape = 5;
+//   5: k_sad_packed (libraries with both sums only), all resident headings in one pass;
+//   6: k_sad_mfma on the bit-plane copy of the library (libraries whose values come from few levels).
+constexpr int kMaxShape = 6;
 static bool shape_valid(const dv_ctx* c, int cls, int sh) {
     if (sh >= 1 && sh <= (cls == 0 ? 2 : (cls == 3 ? 4 : 3))) return true;
+    if (sh == 6) return c->bits_ok;
     const bool both_sums = !c->cfg.generic && c->cfg.nhs > 0 && c->cfg.hasv;
     return sh == 5 && both_sums;
 }
@@ -1113,12 +1250,77 @@ static void launch_generic_apad(dv_ctx* c) {
     else launch_generic<HAS_HS, HASV, 32, 64>(c);
 }
 
+// May the next integer scoring pass of the resident heading class go through k_sad_mfma?  (Decides whether the
+// per-step coefficient image is worth preparing.)
+static bool mfma_path_possible(const dv_ctx* c) {
+    if (!c->bits_ok || c->metric != 0) return false;
+    if (c->force_shape) return c->force_shape == 6;
+    if (c->shape_env) return c->shape_env == 6;
+    const int t = c->tuned_shape[apad_class(c->APAD)];
+    return t == 0 || t == 6;
+}
+
+template <int SK, int TILES>
+static void launch_mfma_variant(dv_ctx* c, int nchunk, int has_hs) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * SK * 8 * 1024;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma<SK, TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long long G32 = c->cfg.Fpad / 32;
+    const long long items = ((G32 + 8 * TILES - 1) / (8 * TILES)) * nchunk;
+    const unsigned grid = (unsigned)(items < 256 ? items : 256);          // one 8-wave workgroup per CU, grid-stride
+    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
+    for (int a_off = 0; a_off < c->APAD; a_off += 32)
+        hipLaunchKernelGGL((k_sad_mfma<SK, TILES>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+                           c->d_coef + (size_t)(a_off / 32) * nkt * 512, reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk,
+                           c->APAD, a_off, has_hs);
+}
+
+// Work items of k_sad_mfma = (chunk of K-steps, 8*TILES view groups of 32).  Two view groups per wave halve the
+// coefficient traffic (every A operand serves both) once the library is large enough to keep every CU busy that way;
+// small libraries cut the K-steps into chunks instead so that there are at least as many items as CUs.
+static void launch_mfma(dv_ctx* c, int has_hs) {
+    const long long G32 = c->cfg.Fpad / 32;
+    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (G32 >= 16ll * 256 * 4 ? 2 : 1);
+    const long long GQ = (G32 + 8 * tiles - 1) / (8 * tiles);
+    int nchunk = 1;
+    if (c->mfma_chunk_env) {
+        nchunk = c->mfma_chunk_env;
+    } else if (GQ < 256) {
+        // fewest chunks that fill at least 90 % of the last round of 256 workgroups, else the best filling
+        double best = 0.0;
+        for (int n = 1; n <= c->nchunk_cap && n <= 16; ++n) {
+            const long long items = GQ * n;
+            const double eff = (double)items / (double)(((items + 255) / 256) * 256);
+            if (eff > best + 1e-9) { best = eff; nchunk = n; }
+            if (eff >= 0.9) break;
+        }
+    }
+    const int nk_min = c->bcfg.NK[1] > 0 ? (c->bcfg.NK[0] > 0 && c->bcfg.NK[0] < c->bcfg.NK[1] ? c->bcfg.NK[0] : c->bcfg.NK[1]) : c->bcfg.NK[0];
+    while (nchunk > 1 && nk_min / nchunk < 4) --nchunk;                  // keep a few K-steps per chunk
+    if (nchunk > c->nchunk_cap) nchunk = c->nchunk_cap;
+    if (nchunk < 1) nchunk = 1;
+    c->nchunk = nchunk;
+    if (tiles == 2) launch_mfma_variant<2, 2>(c, nchunk, has_hs);
+    else launch_mfma_variant<4, 1>(c, nchunk, has_hs);
+}
+
 // The integer path of one scoring pass: k_sad_tiles / k_sad_generic, then k_combine.  `after_tiles` (optional) is
 // recorded between the two.
 static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial, bool with_combine = true) {
     const LibCfg& g = c->cfg;
     int has_hs_sum, has_v_sum = g.hasv;
-    if (g.generic) {
+    c->int_hsconst = c->d_hsconst;
+    c->int_vconst = nullptr;
+    if (!g.generic && shape_now(c) == 6) {
+        if (!c->coef_ready) { const int rc = enqueue_bit_prep(c, true); if (rc) return rc; }
+        has_hs_sum = g.nhs > 0 ? 1 : 0;
+        launch_mfma(c, has_hs_sum);
+        c->int_hsconst = c->d_bconst;
+        c->int_vconst = c->d_bconst + kMaxHeadings;
+    } else if (g.generic) {
         has_hs_sum = 1;
         if (g.hasv) launch_generic_apad<1, 1>(c); else launch_generic_apad<1, 0>(c);
     } else {
@@ -1142,8 +1344,8 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial,
     c->int_has_v = has_v_sum;
     if (!with_combine) return DV_OK;                     // the step ends in k_finish, which does the combining itself
     *n_partial = (int)((g.Fpad + 1023) / 1024);
-    hipLaunchKernelGGL(k_combine, dim3((unsigned)*n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->d_hsconst,
-                       c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum, c->n_agents);
+    hipLaunchKernelGGL(k_combine, dim3((unsigned)*n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->int_hsconst,
+                       c->int_vconst, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, has_hs_sum, has_v_sum, c->n_agents);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
@@ -1261,7 +1463,7 @@ template <int NT>
 static void launch_finish(dv_ctx* c, int want_scene, int force) {
     const LibCfg& g = c->cfg;
     hipLaunchKernelGGL(k_finish<NT>, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream,
-                       c->d_part, c->d_hsconst, c->nchunk, c->APAD, c->int_has_hs, c->int_has_v, c->d_state, c->d_bsum, c->d_ctmp,
+                       c->d_part, c->int_hsconst, c->int_vconst, c->nchunk, c->APAD, c->int_has_hs, c->int_has_v, c->d_state, c->d_bsum, c->d_ctmp,
                        c->d_cand, c->d_scene, c->d_result + c->result_slot,
                        c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta, want_scene, force,
                        ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr);

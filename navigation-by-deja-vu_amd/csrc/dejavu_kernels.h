@@ -605,9 +605,9 @@ k_sad_generic(const uint4* __restrict__ tiles, const unsigned* __restrict__ prep
 // grid = (ceil(Fpad/1024), A), four views per thread; also leaves each block's maximum in blockmax[a][blockIdx.x] (no atomics:
 // thousands of atomics on one 128-byte line serialise at the memory side, ~10 ns each).
 __global__ void __launch_bounds__(256)
-k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, double* __restrict__ fam,
-          unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD,
-          int has_hs_sum, int has_v_sum, int n_agents) {
+k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, const int* __restrict__ vconst,
+          double* __restrict__ fam, unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk,
+          int APAD, int has_hs_sum, int has_v_sum, int n_agents) {
     __shared__ unsigned long long wmax[4];
     // four consecutive views per thread: one 16-byte load per (chunk, sum) row
     const long long f0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -616,18 +616,20 @@ k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, do
     if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x, n_agents);
     unsigned long long key = 0;
     if (f0 < c.Fpad) {
+        // a chunk's sum is an int32: the bit-plane path keeps the per-heading constants out of it, so it may be negative
         const long long base = hsconst[a];
+        const long long vbase = vconst ? vconst[a] : 0;
         long long shs[4] = {base, base, base, base};
-        long long sv[4] = {0, 0, 0, 0};
+        long long sv[4] = {vbase, vbase, vbase, vbase};
         for (int ch = 0; ch < nchunk; ++ch) {
             const unsigned* p = part + ((long long)ch * nsum * APAD) * c.Fpad + f0;
             if (has_hs_sum) {
                 const uint4 q = *reinterpret_cast<const uint4*>(p + (long long)a * c.Fpad);
-                shs[0] += q.x; shs[1] += q.y; shs[2] += q.z; shs[3] += q.w;
+                shs[0] += (int)q.x; shs[1] += (int)q.y; shs[2] += (int)q.z; shs[3] += (int)q.w;
             }
             if (has_v_sum) {
                 const uint4 q = *reinterpret_cast<const uint4*>(p + (long long)((has_hs_sum ? APAD : 0) + a) * c.Fpad);
-                sv[0] += q.x; sv[1] += q.y; sv[2] += q.z; sv[3] += q.w;
+                sv[0] += (int)q.x; sv[1] += (int)q.y; sv[2] += (int)q.z; sv[3] += (int)q.w;
             }
         }
         double val[4];
@@ -1052,8 +1054,8 @@ constexpr int kTmpCap = 4096;       // entries of the shared extra-candidate lis
 
 template <int NT>                   // headings per agent <= 16 * NT, scores held in registers
 __global__ void __launch_bounds__(256)
-k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, int nchunk, int APAD, int has_hs_sum,
-         int has_v_sum, StepState* __restrict__ st, unsigned long long* __restrict__ bsum,
+k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, const int* __restrict__ vconst, int nchunk,
+         int APAD, int has_hs_sum, int has_v_sum, StepState* __restrict__ st, unsigned long long* __restrict__ bsum,
          unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand, double* __restrict__ scene,
          StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene, int force,
          int seq, const int* __restrict__ sense_err) {
@@ -1098,9 +1100,11 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, int
     for (int k = 0; k < NT * 16; ++k) {
         val[k] = 0.0;
         if (k < A) {
-            const long long shs = (long long)hsconst[a_base + k] + (long long)shs_u[k];
+            // the chunk sums are int32 and may wrap on the way (bit-plane path: negative chunks); their total fits
+            const long long shs = (long long)hsconst[a_base + k] + (long long)(int)shs_u[k];
+            const long long sv = (long long)(vconst ? vconst[a_base + k] : 0) + (long long)(int)sv_u[k];
             double acc = c.whs * (double)shs;
-            if (has_v_sum) acc = acc + c.wv * (double)(long long)sv_u[k];
+            if (has_v_sum) acc = acc + c.wv * (double)sv;
             val[k] = (double)c.P - acc / 255.;
         }
     }
@@ -1774,6 +1778,324 @@ k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         if ((threadIdx.x & 63) == 0 && sum != 0) atomicAdd(&hsconst[a_first], sum);
     } else if (t < total && konst != 0) {
         atomicAdd(&hsconst[a], konst);
+    }
+}
+
+// ------------------------------------------------------------------ bit-plane library + int8 MFMA scoring
+// |a - b| is not bilinear, but it becomes linear in b once b is known to come from a small level set
+// l_0 < l_1 < ... (the reference's sensor quantises V to n_sensor_levels values, NavBySceneFamiliarity.py:176-186, and
+// the experiments' saturation is 0 or 127, scripts/run_experiment.py:192).  With the thermometer bits
+// B_t = [b >= l_{t+1}] of a library byte and alpha_t = clamp(a - l_t, 0, w_t), w_t = l_{t+1} - l_t, of ANY patch byte a:
+//     |a - b| = (l_0 - a)+ + (a - l_max)+ + sum_t alpha_t  +  sum_t B_t * (w_t - 2 alpha_t)
+// (gap t contributes its overlap with [min(a,b), max(a,b)]: alpha_t when b is below the gap, w_t - alpha_t when above).
+// The first three terms depend on the patch only (a per-heading constant); the last is an exact integer GEMM:
+// M = headings, N = views, K = pixels x planes, A = int8 coefficients (gaps wider than 127 are split), B = library BITS.
+// So the library is stored as bits (0.75 B/px where the byte planes take 2), and scored on the matrix cores:
+//   btiles[g][ks][lane] : uint4 -- view group g = 32 views, K-step ks = 256 K-elements; lane = (view & 31) + 32*half;
+//     bit beta of dword j of that lane = K-element ((ks*2 + half)*4 + j)*32 + beta of its segment (HS planes first,
+//     then V planes; element n of a segment = plane n % T of pixel n / T; zero beyond the last pixel);
+//   coef[ks][s][lane] : uint4 -- A operand of slice s of K-step ks: lane = (heading & 31) + 32*half, byte b of dword j =
+//     coefficient of bit beta = s + 8b of library dword j;
+//   slice s of a K-step = v_mfma_i32_32x32x32_i8 with B operand (x_j & (0x01010101 << s)), j = 0..3: bytes of value
+//     2^s * bit, ONE v_and_b32 per operand dword, the factor 2^s divided out of the accumulator at the end (exact: every
+//     term is a multiple of it).  Slices 4..7 use x >> 4, so four accumulators carry the eight slices.
+// The integer sums are the ones k_sad_tiles produces, so everything downstream (k_finish / k_combine, tie rule) is shared.
+constexpr int kMaxBitPlanes = 16;
+struct BitCfg {
+    int T[2];               // planes of the HS segment and of the V segment
+    int NK[2];              // K-steps (256 K-elements) of each segment
+    int GS;                 // 1-KB rows between consecutive view groups in btiles (>= NK[0] + NK[1], odd)
+    int nbp;                // byte planes described below (= LibCfg::npl)
+    unsigned char pl[kMaxBitPlanes];   // byte plane of bit plane t (HS planes first, then V)
+    unsigned char lo[kMaxBitPlanes];   // lower level of its gap
+    unsigned char w[kMaxBitPlanes];    // width of the gap (<= 127)
+    unsigned char lmin[kMaxHues + 1], lmax[kMaxHues + 1];   // per byte plane: smallest / largest library value
+};
+
+// presence[pl][v >> 5] bit (v & 31): byte value v occurs in plane pl at a real pixel of a real view
+__global__ void __launch_bounds__(256)
+k_level_scan(const uint4* __restrict__ tiles, LibCfg c, unsigned* __restrict__ presence) {
+    __shared__ unsigned local[(kMaxHues + 1) * 8];
+    for (int i = threadIdx.x; i < (kMaxHues + 1) * 8; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    const long long total = (c.Fpad / 64) * (long long)c.npl * c.Q * 64;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(t & 63);
+        long long r = t >> 6;
+        const int q = (int)(r % c.Q); r /= c.Q;
+        const int pl = (int)(r % c.npl);
+        const long long g = r / c.npl;
+        if (g * 64 + lane >= c.F) continue;
+        const uint4 v = tiles[g * c.gstride + ((long long)pl * c.Q + q) * 64 + lane];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        unsigned seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 16; ++i) {
+            if (q * 16 + i >= c.P) break;
+            const unsigned b = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+            seen[b >> 5] |= 1u << (b & 31);
+        }
+        for (int k = 0; k < 8; ++k)
+            if (seen[k] & ~local[pl * 8 + k]) atomicOr(&local[pl * 8 + k], seen[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (kMaxHues + 1) * 8; i += blockDim.x)
+        if (local[i]) atomicOr(&presence[i], local[i]);
+}
+
+// K-element n of segment seg -> (bit plane, pixel); false beyond the last pixel
+__device__ __forceinline__ bool bit_element(const BitCfg& b, int P, int seg, long long n, int& plane, int& px) {
+    const int T = b.T[seg];
+    if (T == 0) return false;
+    px = (int)(n / T);
+    plane = (seg ? b.T[0] : 0) + (int)(n % T);
+    return px < P;
+}
+
+// byte tiles -> bit tiles.  One thread per (view group of 32, K-step, lane) uint4.
+__global__ void __launch_bounds__(256)
+k_bitpack(const uint4* __restrict__ tiles, uint4* __restrict__ btiles, LibCfg c, BitCfg b) {
+    const int NKT = b.NK[0] + b.NK[1];
+    const long long G32 = c.Fpad / 32;
+    const long long total = G32 * NKT * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long r = t >> 6;
+    const int ks = (int)(r % NKT);
+    const long long g = r / NKT;
+    const long long f = g * 32 + (lane & 31);
+    const int half = lane >> 5;
+    const int seg = ks >= b.NK[0] ? 1 : 0;
+    const int ksl = ks - (seg ? b.NK[0] : 0);
+    unsigned w[4] = {0, 0, 0, 0};
+    if (f < c.F) {
+        const unsigned char* tb = reinterpret_cast<const unsigned char*>(tiles + (f >> 6) * c.gstride + (f & 63));
+        for (int j = 0; j < 4; ++j) {
+            const long long n0 = (((long long)ksl * 2 + half) * 4 + j) * 32;
+            for (int beta = 0; beta < 32; ++beta) {
+                int plane, px;
+                if (!bit_element(b, c.P, seg, n0 + beta, plane, px)) continue;
+                const unsigned byte = tb[((long long)b.pl[plane] * c.Q + (px >> 4)) * 64 * 16 + (px & 15)];
+                if (byte >= (unsigned)b.lo[plane] + (unsigned)b.w[plane]) w[j] |= 1u << beta;
+            }
+        }
+    }
+    btiles[(g * b.GS + ks) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Per-step operand of the MFMA path, from the raw patches uint8[A][P][3] (left by k_prep / k_sense_prep):
+//   blocks [0, NKT * npass): the 8 KB coefficient image of one K-step for headings [32*pass, 32*pass + 32);
+//   blocks beyond: one per heading, its two constants bconst[0][a] (HS) and bconst[1][a] (V): everything of the sums
+//   that does not depend on the view (incl. the hue-outside-the-set and clamped-saturation terms of k_prep).
+__global__ void __launch_bounds__(512)
+k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int* __restrict__ bconst, LibCfg c, BitCfg b,
+           int A, int npass) {
+    const int NKT = b.NK[0] + b.NK[1];
+    const int ncoef = NKT * npass;
+    if ((int)blockIdx.x < ncoef) {
+        const int pass = blockIdx.x / NKT, ks = blockIdx.x % NKT;
+        const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+        const int a = pass * 32 + (lane & 31), half = lane >> 5;
+        const int seg = ks >= b.NK[0] ? 1 : 0;
+        const int ksl = ks - (seg ? b.NK[0] : 0);
+        unsigned w[4] = {0, 0, 0, 0};
+        if (a < A) {
+            const unsigned char* p = raw + (long long)a * c.P * 3;
+            for (int j = 0; j < 4; ++j) {
+                const long long n0 = (((long long)ksl * 2 + half) * 4 + j) * 32;
+                for (int bb = 0; bb < 4; ++bb) {
+                    int plane, px;
+                    if (!bit_element(b, c.P, seg, n0 + s + 8 * bb, plane, px)) continue;
+                    const int av = (int)plane_byte(c, b.pl[plane], p[px * 3], p[px * 3 + 1], p[px * 3 + 2]);
+                    int alpha = av - (int)b.lo[plane];
+                    alpha = alpha < 0 ? 0 : (alpha > (int)b.w[plane] ? (int)b.w[plane] : alpha);
+                    w[j] |= ((unsigned)((int)b.w[plane] - 2 * alpha) & 0xffu) << (8 * bb);
+                }
+            }
+        }
+        coef[((long long)blockIdx.x * 8 + s) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        return;
+    }
+    const int a = blockIdx.x - ncoef;
+    __shared__ int red[2][512];
+    int k_hs = 0, k_v = 0;
+    const unsigned char* p = raw + (long long)a * c.P * 3;
+    const int nplanes = b.T[0] + b.T[1];
+    for (int px = threadIdx.x; px < c.P; px += blockDim.x) {
+        const unsigned H = p[px * 3], S = p[px * 3 + 1], V = p[px * 3 + 2];
+        for (int bp = 0; bp < b.nbp; ++bp) {
+            const int av = (int)plane_byte(c, bp, H, S, V);
+            int k = 0;
+            if (av < (int)b.lmin[bp]) k += (int)b.lmin[bp] - av;
+            if (av > (int)b.lmax[bp]) k += av - (int)b.lmax[bp];
+            for (int t = 0; t < nplanes; ++t) {
+                if (b.pl[t] != bp) continue;
+                const int al = av - (int)b.lo[t];
+                k += al < 0 ? 0 : (al > (int)b.w[t] ? (int)b.w[t] : al);
+            }
+            if (bp < c.nhs) k_hs += k; else k_v += k;
+        }
+        if (c.cw > 0.0) {                                   // as k_prep's hsconst
+            const int nk = c.signed_s ? 2 : c.nhs;
+            bool in_set = false;
+            for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
+            if (!in_set) k_hs += (int)S;
+            else if (c.signed_s && S > 127u) k_hs += (int)S - 127;
+        }
+    }
+    red[0][threadIdx.x] = k_hs;
+    red[1][threadIdx.x] = k_v;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bconst[a] = red[0][0]; bconst[kMaxHeadings + a] = red[1][0]; }
+}
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// The scoring kernel of the bit-plane path.  Workgroup = 8 waves (two per SIMD), wave w scores TILES view groups of 32
+// views against 32 headings; item = (chunk of K-steps, 8*TILES view groups), grid-stride over a resident grid.
+//   * coefficients of a stage (SK K-steps, SK*8 KB) go global -> LDS by LDS-DMA one stage ahead (two buffers, one
+//     barrier per stage; they are the same for every workgroup and come out of L2);
+//   * library bits are loaded one stage ahead into registers (non-temporal: each byte is used once per step);
+//   * the four A operands of the next half K-step are read from LDS before the current half's MFMAs start;
+//   * every A operand serves the wave's TILES view groups.
+// Output: part[(ch*nsum + type_row)*APADtot + a_off + m][f], the same integer sums k_sad_tiles leaves (minus the
+// per-heading constants, which k_finish / k_combine add), so a chunk's sum may be negative: consumers read int32.
+template <int SK, int TILES>
+__global__ void __launch_bounds__(512, 2)
+k_sad_mfma(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, LibCfg c, BitCfg b,
+           int nchunk, int apad_total, int a_off, int has_hs_sum) {
+    extern __shared__ uint4 lds_coef[];           // [2][SK][8][64]
+    constexpr int NW = 8;
+    constexpr int VW = NW * TILES;
+    constexpr int STAGE16 = SK * 8 * 64;
+    constexpr int PER_W = STAGE16 / (64 * NW);    // 1-KB rows each wave fetches per stage
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long G32 = c.Fpad / 32;
+    const long long GQ = (G32 + VW - 1) / VW;
+    const long long n_items = GQ * nchunk;
+    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;      // headings this pass owns
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ch = (int)(item / GQ);
+        const long long gq = item - (long long)ch * GQ;
+        const uint4* lib[TILES];
+        long long gidx[TILES];
+        bool live[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            long long g = gq * VW + wave * TILES + t;
+            live[t] = g < G32;
+            if (!live[t]) g = G32 - 1;
+            gidx[t] = g;
+            lib[t] = btiles + (g * b.GS) * 64 + lane;
+        }
+#pragma unroll 1
+        for (int seg = 0; seg < 2; ++seg) {
+            if (seg == 0 && !has_hs_sum) continue;
+            if (seg == 1 && !c.hasv) continue;
+            const int kbase = seg ? b.NK[0] : 0;
+            const int k0 = kbase + (int)(((long long)ch * b.NK[seg]) / nchunk);
+            const int k1 = kbase + (int)(((long long)(ch + 1) * b.NK[seg]) / nchunk);
+            const int nst = (k1 - k0 + SK - 1) / SK;
+            v16i_t acc[TILES][4];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][s][r] = 0;
+            if (nst > 0) {
+                v4u_t ring[2][TILES][SK];
+                auto kclamp = [&](int k) { return k < k1 ? k : k1 - 1; };
+                auto dma_stage = [&](int st) {
+                    const int kb = k0 + st * SK;
+#pragma unroll
+                    for (int i = 0; i < PER_W; ++i) {
+                        const int row = wave * PER_W + i;                 // (K-step, slice) row of the stage
+                        long long src = ((long long)kb * 8 + row) * 64 + lane;
+                        const long long lim = (long long)k1 * 512;
+                        if (src >= lim) src = lim - 64 + lane;            // past the chunk: any valid row (masked below)
+                        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(coef + src),
+                                                         (lds_ptr_t)(lds_coef + (st & 1) * STAGE16 + row * 64), 16, 0, 0);
+                    }
+                };
+                dma_stage(0);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int k = 0; k < SK; ++k)
+                        ring[0][t][k] = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(lib[t] + (long long)kclamp(k0 + k) * 64));
+                for (int st0 = 0; st0 < nst; st0 += 2) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {           // register set of stage st is st & 1
+                        const int st = st0 + u;
+                        if (st < nst) {
+                            const int kb = k0 + st * SK;
+                            __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's DMA rows and library bits are in
+                            __syncthreads();                          // everybody's are, and nobody still reads the other buffer
+                            if (st + 1 < nst) dma_stage(st + 1);
+#pragma unroll
+                            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                                for (int k = 0; k < SK; ++k)
+                                    ring[u ^ 1][t][k] = __builtin_nontemporal_load(
+                                        reinterpret_cast<const v4u_t*>(lib[t] + (long long)kclamp(kb + SK + k) * 64));
+                            __builtin_amdgcn_sched_barrier(0);
+                            const uint4* buf = lds_coef + (st & 1) * STAGE16 + lane;
+                            v4i_t a[2][4];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) { const uint4 w = buf[s * 64]; a[0][s] = v4i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
+#pragma unroll
+                            for (int hs = 0; hs < 2 * SK; ++hs) {
+                                if (hs + 1 < 2 * SK) {
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s) {
+                                        const uint4 w = buf[((hs + 1) * 4 + s) * 64];
+                                        a[(hs + 1) & 1][s] = v4i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+                                    }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int k = hs >> 1;
+                                const bool on = kb + k < k1;
+#pragma unroll
+                                for (int t = 0; t < TILES; ++t) {
+                                    const v4u_t x = ring[u][t][k];
+                                    const v4u_t src = (hs & 1) ? v4u_t{x.x >> 4, x.y >> 4, x.z >> 4, x.w >> 4} : x;
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s) {
+                                        const unsigned m = on ? (0x01010101u << s) : 0u;
+                                        const v4i_t bo = v4i_t{(int)(src.x & m), (int)(src.y & m), (int)(src.z & m), (int)(src.w & m)};
+                                        acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[hs & 1][s], bo, acc[t][s], 0, 0, 0);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();                  // the next segment / item refills LDS buffer 0
+            }
+            const int type_row = seg ? has_hs_sum : 0;
+            const int nsum = has_hs_sum + c.hasv;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                if (live[t]) {
+                    int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int tot = acc[t][0][r] + (acc[t][1][r] >> 1) + (acc[t][2][r] >> 2) + (acc[t][3][r] >> 3);
+                        if (m < rows) dst[(long long)m * c.Fpad] = tot;
+                    }
+                }
+            }
+        }
     }
 }
 

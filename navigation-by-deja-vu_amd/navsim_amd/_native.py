@@ -60,6 +60,11 @@ class LibInfo(ctypes.Structure):
         ("hues", ctypes.c_uint8 * DV_MAX_HUE_PLANES),
         ("n_hues", ctypes.c_int32),
         ("signed_saturation", ctypes.c_int32),
+        ("bit_planes_hs", ctypes.c_int32),
+        ("bit_planes_v", ctypes.c_int32),
+        ("has_bit_planes", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
+        ("bit_tile_bytes", ctypes.c_int64),
     ]
 
 
@@ -95,6 +100,8 @@ PROTOTYPES = {
     "dv_clear_library": (ctypes.c_int, [_ctx_p]),
     "dv_get_library_info": (ctypes.c_int, [_ctx_p, ctypes.POINTER(LibInfo)]),
     "dv_read_planes": (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, _u8p]),
+    "dv_bitplane_plan": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, _u8p, _u8p,
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "dv_set_landscape": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dv_configure_sensor": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u8p,
                                            ctypes.c_int]),

@@ -85,7 +85,8 @@ class FamiliarityEngine(object):
                     n_planes=info.n_planes, n_hue_planes=info.n_hue_planes, generic_hue=bool(info.generic_hue),
                     has_value_plane=bool(info.has_value_plane), tile_bytes=info.tile_bytes,
                     chem_weight=info.chem_weight, delta=info.delta, hues=[int(x) for x in info.hues][:info.n_hues],
-                    signed_saturation=bool(info.signed_saturation))
+                    signed_saturation=bool(info.signed_saturation), has_bit_planes=bool(info.has_bit_planes),
+                    bit_planes_hs=info.bit_planes_hs, bit_planes_v=info.bit_planes_v, bit_tile_bytes=info.bit_tile_bytes)
 
     def read_planes(self, v0, n):
         info = self.library_info()

@@ -44,3 +44,42 @@ def step_case_inputs(case):
             lib[7, 1, 1, 2] ^= 0xFF
     assert sha(lib) == case["lib_sha"] and sha(patches) == case["patches_sha"], "input regeneration drifted"
     return lib, patches
+
+
+# Forms of the scoring path every GPU engine test runs under.  The engine reads these variables when it is created.
+#   k_finish / k_combine+k_tail : the two ways a step ends (DEJAVU_FINISH=2 / 0), byte-plane kernels timed as usual;
+#   mfma    : the bit-plane copy is built whenever the library's values allow it (DEJAVU_BITS=2) and scored on the matrix
+#             cores (DEJAVU_SHAPE=6, k_sad_mfma); libraries it cannot describe fall back to the byte-plane kernels;
+#   default : nothing set -- what ships (the engine times the kernel forms and picks the step ending by library size).
+ENGINE_MODES = ["k_finish", "k_combine+k_tail", "mfma", "default"]
+_MODE_ENV = {
+    "k_finish": {"DEJAVU_FINISH": "2"},
+    "k_combine+k_tail": {"DEJAVU_FINISH": "0"},
+    "mfma": {"DEJAVU_FINISH": "2", "DEJAVU_SHAPE": "6", "DEJAVU_BITS": "2"},
+    "default": {},
+}
+_MODE_KEYS = ("DEJAVU_FINISH", "DEJAVU_SHAPE", "DEJAVU_BITS")
+
+
+class engine_mode(object):
+    """Context manager: the environment of one engine mode while an engine is created."""
+
+    def __init__(self, mode):
+        self.env = _MODE_ENV[mode]
+
+    def __enter__(self):
+        import os
+        self.before = {k: os.environ.get(k) for k in _MODE_KEYS}
+        for k in _MODE_KEYS:
+            os.environ.pop(k, None)
+        os.environ.update(self.env)
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False

@@ -10,7 +10,7 @@ import pytest
 import navsim_amd
 from navsim_amd import synth
 from oracle import oracle
-from tests.helpers import kernel_case_inputs, step_case_inputs
+from tests.helpers import ENGINE_MODES, engine_mode, kernel_case_inputs, step_case_inputs
 from tests.test_host_logic import check_trajectory
 
 pytestmark = pytest.mark.gpu
@@ -18,20 +18,13 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-@pytest.fixture(scope="module", params=["k_finish", "k_combine+k_tail"])
+@pytest.fixture(scope="module", params=ENGINE_MODES)
 def eng(request):
-    """Every test runs with steps ending in k_finish wherever possible and in the two-kernel form (by default the
-    engine picks per library size and heading count, csrc/dejavu_hip.hip:enqueue_step)."""
-    import os
-    before = os.environ.get("DEJAVU_FINISH")
-    os.environ["DEJAVU_FINISH"] = "2" if request.param == "k_finish" else "0"
-    try:
+    """Every test runs under each form of the scoring path (tests/helpers.py:ENGINE_MODES): both step endings, the
+    bit-plane matrix-core kernel, and the product default."""
+    with engine_mode(request.param):
         e = navsim_amd.FamiliarityEngine(device=0)
-    finally:
-        if before is None:
-            os.environ.pop("DEJAVU_FINISH", None)
-        else:
-            os.environ["DEJAVU_FINISH"] = before
+    e.mode = request.param
     yield e
     e.close()
 
@@ -520,8 +513,8 @@ def test_ssd_f32_ties_and_duplicates(eng):
 
 @pytest.mark.parametrize("A", [5, 16, 30, 64])
 def test_every_workgroup_shape_gives_identical_results(A):
-    """k_sad_tiles' workgroup shapes (1 single-wave, 2 four waves + LDS sums, 3/4 heading ways, 5 packed accumulators;
-    csrc/dejavu_hip.hip:launch_tiles_apad) are normally chosen by timing; forced one by one they must produce the same
+    """The scoring kernel's forms (1 single-wave, 2 four waves + LDS sums, 3/4 heading ways, 5 packed accumulators;
+    csrc/dejavu_hip.hip:launch_tiles_apad; 6 the bit-plane matrix-core kernel k_sad_mfma) are normally chosen by timing; forced one by one they must produce the same
     integer sums, hence bit-identical scores and the reference's decision."""
     import os
     F, h, w, cw = 1500, 20, 24, 0.25
@@ -531,13 +524,14 @@ def test_every_workgroup_shape_gives_identical_results(A):
     want = oracle.step(lib, pats, cw)
     fams = {}
     try:
-        for shape in (1, 2, 3, 4, 5, 0):
+        for shape in (1, 2, 3, 4, 5, 6, 0):
             os.environ["DEJAVU_SHAPE"] = str(shape)
             e = navsim_amd.FamiliarityEngine(0)
             try:
                 e.set_library(lib, cw)
                 info = e.library_info()
                 assert info["n_planes"] == 2 and info["signed_saturation"] == 1      # both sums live: shape 5 is valid
+                assert info["has_bit_planes"] and (info["bit_planes_hs"], info["bit_planes_v"]) == (2, 4)   # shape 6 is
                 r = e.step(pats, want_scene=False)
                 assert (r["best_idex"], r["best_view"]) == (want["best_idex"], want["best_view"]), shape
                 fams[shape] = np.array(r["angle_familiarity"])
@@ -548,7 +542,7 @@ def test_every_workgroup_shape_gives_identical_results(A):
                 e.close()
     finally:
         os.environ.pop("DEJAVU_SHAPE", None)
-    for shape in (2, 3, 4, 5, 0):
+    for shape in (2, 3, 4, 5, 6, 0):
         np.testing.assert_array_equal(fams[shape], fams[1])
         np.testing.assert_array_equal(fams[(shape, "score")], fams[(1, "score")])
     np.testing.assert_allclose(fams[1], want["angle_familiarity"], rtol=1e-12)
@@ -581,9 +575,14 @@ def test_workgroup_shape_is_reported_after_the_first_step(eng):
     lib = synth.synth_views(3, 700, 16, 16)
     pats = synth.synth_patches(3, 12, 16, 16)
     eng.set_library(lib, 0.25)
+    if eng.mode == "mfma":                                   # DEJAVU_SHAPE=6: forced, nothing is timed
+        assert eng.workgroup_shape(12) == 6 and eng.library_info()["has_bit_planes"]
+        eng.step(pats, want_scene=False)
+        assert eng.workgroup_shape(12) == 6
+        return
     assert eng.workgroup_shape(12) == 0                      # nothing timed yet for this library
     eng.step(pats, want_scene=False)
-    assert 1 <= eng.workgroup_shape(12) <= 5
+    assert 1 <= eng.workgroup_shape(12) <= 6
     assert eng.workgroup_shape(40) == 0                      # another heading class: timed on its first use
     with pytest.raises(ValueError):                          # DV_ERR_INVALID maps to ValueError, as for the other calls
         eng.workgroup_shape(65)

@@ -11,23 +11,18 @@ import navsim_amd
 from navsim_amd import sharded, synth
 from oracle import oracle
 
+from tests.helpers import ENGINE_MODES, engine_mode
+
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["k_finish", "k_combine+k_tail"])
+@pytest.fixture(scope="module", params=ENGINE_MODES)
 def eng(request):
-    """Every test runs with steps ending in k_finish wherever possible and in the two-kernel form (by default the
-    engine picks per library size and heading count, csrc/dejavu_hip.hip:enqueue_step)."""
-    import os
-    before = os.environ.get("DEJAVU_FINISH")
-    os.environ["DEJAVU_FINISH"] = "2" if request.param == "k_finish" else "0"
-    try:
+    """Every test runs under each form of the scoring path (tests/helpers.py:ENGINE_MODES): both step endings, the
+    bit-plane matrix-core kernel, and the product default."""
+    with engine_mode(request.param):
         e = navsim_amd.FamiliarityEngine(device=0)
-    finally:
-        if before is None:
-            os.environ.pop("DEJAVU_FINISH", None)
-        else:
-            os.environ["DEJAVU_FINISH"] = before
+    e.mode = request.param
     yield e
     e.close()
 

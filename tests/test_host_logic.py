@@ -200,3 +200,40 @@ def test_experiment_loop_reports_the_reference_row():
     if row["stop_status"] == 1:
         assert isinstance(nsf.stopped_with_exception, navsim_amd.ReachedEndOfTrainingPathException)
         assert row["path_coverage"] > 0.5
+
+
+def test_bit_plane_decomposition_is_exact():
+    """The identity behind the matrix-core scoring path (csrc/dejavu_kernels.h, 'bit-plane library'): for a library
+    byte b from the level set and ANY patch byte a,
+        |a - b| = (lmin - a)+ + (a - lmax)+ + sum_t alpha_t + sum_t bit_t(b) * (w_t - 2 alpha_t),
+    with the planes dv_bitplane_plan derives (gaps wider than 127 split, int8 coefficients)."""
+    import ctypes
+    from navsim_amd import _native as N
+    lib = N.load()
+    rng = np.random.default_rng(7)
+    level_sets = [[0, 63, 127, 191, 255], [1, 128, 255], [0, 255], [17], [0, 1, 2, 3], list(range(0, 256, 17)),
+                  sorted(rng.choice(256, 12, replace=False).tolist())]
+    for levels in level_sets:
+        presence = (ctypes.c_uint32 * 8)()
+        for v in levels:
+            presence[v >> 5] |= 1 << (v & 31)
+        lo = (ctypes.c_uint8 * 64)()
+        w = (ctypes.c_uint8 * 64)()
+        lmin, lmax = ctypes.c_int(), ctypes.c_int()
+        n = lib.dv_bitplane_plan(presence, 64, lo, w, ctypes.byref(lmin), ctypes.byref(lmax))
+        assert n >= 0 and (lmin.value, lmax.value) == (levels[0], levels[-1])
+        lo_a, w_a = np.array(lo[:n], dtype=int), np.array(w[:n], dtype=int)
+        assert (w_a >= 1).all() and (w_a <= 127).all()
+        assert n == sum(-(-(b - a) // 127) for a, b in zip(levels, levels[1:]))
+        a = np.arange(256)[:, None]                                   # every patch byte
+        b = np.array(levels)[None, :]                                 # every library byte
+        alpha = np.clip(a[:, :, None] - lo_a[None, None, :], 0, w_a[None, None, :])           # [a, 1, t]
+        bits = (b[:, :, None] >= (lo_a + w_a)[None, None, :]).astype(int)                       # [1, b, t]
+        coef = w_a[None, None, :] - 2 * alpha
+        assert n == 0 or (coef.min() >= -127 and coef.max() <= 127)
+        const = np.maximum(levels[0] - a, 0) + np.maximum(a - levels[-1], 0) + alpha.sum(axis=2)
+        got = const + (bits * coef).sum(axis=2)
+        assert np.array_equal(got, np.abs(a - b)), levels
+    # too many planes for the cap: refused, the byte-plane kernels keep such a library
+    presence = (ctypes.c_uint32 * 8)(*([0xffffffff] * 8))
+    assert lib.dv_bitplane_plan(presence, 16, lo, w, ctypes.byref(lmin), ctypes.byref(lmax)) == -1

@@ -50,9 +50,9 @@ def main():
     d = sys.argv[1]
     ks = kernel_stats(d)
     out = dict(kernels=ks)
-    for kern in ("k_sad_tiles", "k_finish", "k_combine", "k_tail"):
+    for kern in ("k_sad_mfma", "k_sad_tiles", "k_sad_packed", "k_ssd_tiles", "k_finish", "k_combine", "k_tail"):
         c = {}
-        for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst", "pmc_sqc"):
             c.update(counters(d, sub, kern))
         if "FETCH_SIZE" in c:
             c["hbm_read_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2      # gfx950: FETCH_SIZE counts half
@@ -60,7 +60,8 @@ def main():
             c["hbm_write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024
         if "hbm_read_bytes_per_launch" in c and "hbm_write_bytes_per_launch" in c:
             c["hbm_traffic_bytes_per_launch"] = c["hbm_read_bytes_per_launch"] + c["hbm_write_bytes_per_launch"]
-        out[kern] = c
+        if c:
+            out[kern] = c
     try:
         out["bench_under_trace"] = json.loads(open(d + "/bench_under_trace.json").read().strip().splitlines()[-1])
     except Exception as e:   # noqa: BLE001
