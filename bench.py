@@ -5,10 +5,11 @@ One "step" = one navigation step's scoring: A sensor patches against every store
 library resident in HBM (scoring kernel, per-view/per-heading reductions, tie resolver, result
 read-back), i.e. what replaces navsim/NavBySceneFamiliarity.py:283-316 + navsim/util.pyx:31-73.
 
-Workload at N=1: BASELINE.json configs[1] -- 64x64 sensor, 50 000 stored views, 16 headings,
-synthetic views (navsim_amd.synth, generated on the device).  With N>1 every rank holds its own
-50 000-view shard of an N*50 000-view library (weak scaling) and the per-step exchange is one
-all-gather of per-heading records over RCCL (navsim_amd/sharded.py).
+Workload at N=1: BASELINE.json configs[2] -- 128x128 sensor, 500 000 stored views, 32 headings (the largest
+single-GPU configuration), synthetic views (navsim_amd.synth, generated on the device).  With N>1 every rank holds
+its own 500 000-view shard of an N*500 000-view library -- at N=8 that is configs[3], 4 M views -- and the per-step
+exchange is one RCCL collective (navsim_amd/sharded.py).  configs[1] (64x64, 50 000 views, 16 headings), the agent
+loop, the ensemble share of configs[4] and the ssd_f32 metric are timed after the headline as secondary blocks.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -27,9 +28,15 @@ for _p in (REPO, os.path.join(REPO, "navigation-by-deja-vu_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 matrix-core peak: 2x the ~2.5 PF dense bf16 figure (MI355X_MICROARCH.md, Matrix cores)
+CLOCK_PEAK_GHZ = 2.4
 
 
-def committed_traffic(workload_key):
+def kernel_of_shape(shape):
+    return {5: "k_sad_packed", 6: "k_sad_mfma"}.get(shape, "k_sad_tiles")
+
+
+def committed_traffic(workload_key, kernel="k_sad_tiles"):
     """HBM bytes per launch of the scoring kernel from the committed PMC passes (profiles/*_summary.json).
 
     bench.py cannot run rocprofv3 on itself; tools/profile_bench.sh collects FETCH_SIZE and WRITE_SIZE in their own
@@ -42,7 +49,7 @@ def committed_traffic(workload_key):
         try:
             d = json.load(open(f))
             if d["bench_under_trace"]["config"]["workload"] == workload_key:
-                best = (float(d["k_sad_tiles"]["hbm_traffic_bytes_per_launch"]), os.path.basename(f))
+                best = (float(d[kernel]["hbm_traffic_bytes_per_launch"]), os.path.basename(f))
         except Exception:   # noqa: BLE001
             continue
     return best
@@ -112,7 +119,8 @@ def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
 
 
 def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
-    """Full navsim-style agent on the same shape: sense (GPU) + score + decide + move, per step."""
+    """Full navsim-style agent on the configs[1] shape: sense (GPU) + score + decide + move + error metrics, per step:
+    step_forward() exactly as scripts/run_experiment.py:243-245 calls it (fake=False, nothing skipped)."""
     import navsim_amd
     from navsim_amd import synth
     L = 2000                                                    # scripts/run_experiment.py:40 mentions 2000x2000 landscapes
@@ -125,12 +133,22 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     d = path[2] - path[1]
     nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi))
     nsf.position = path[1] + np.array([1.0, -1.0])
-    for _ in range(10):
-        nsf.step_forward(fake=True)
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        nsf.step_forward(fake=True)
-    dt = time.perf_counter() - t0
+    rates = {}
+    for fake in (True, False):
+        nsf.position = path[1] + np.array([1.0, -1.0])
+        nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi))
+        nsf.reset_error()
+        done = 0
+        try:
+            for _ in range(10):
+                nsf.step_forward(fake=fake)
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                nsf.step_forward(fake=fake)
+                done += 1
+            rates[fake] = done / (time.perf_counter() - t0)
+        except navsim_amd.StopNavigationException:              # left the path before n_steps: rate over what ran
+            rates[fake] = done / max(time.perf_counter() - t0, 1e-9) if done else None
     n_lib = len(path)
     # the same agent as the first of an ensemble of 32 stepping in lockstep (sensing and scoring batched, 64/A agents
     # per library pass; navsim_amd.NavEnsemble): agent-steps per second of the whole ensemble
@@ -152,29 +170,123 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     except Exception:                                            # noqa: BLE001 - an extra figure only
         ens_rate = None
     nsf.clear_training()
-    return n_steps / dt, n_lib, ens_rate
+    return rates, n_lib, ens_rate
+
+
+def workload_name(w, h, F, A, cw, world):
+    named = ""
+    if w == h:
+        if (w, F, A) == (64, 50000, 16):
+            named = " (BASELINE.json configs[1])"
+        elif (w, F, A) == (128, 500000, 32):
+            named = " (BASELINE.json configs[2])" if world == 1 else (
+                " (BASELINE.json configs[3]: %d views over %d GPUs)" % (world * F, world) if world == 8 else
+                " (per-rank share of BASELINE.json configs[3], %d ranks)" % world)
+    return "%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g%s" % (w, h, F, A, cw, named)
+
+
+def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, with_ceiling=True):
+    """Roofline of the scoring kernel.  `achieved` / `frac` are on the bytes the kernel MOVES: the HBM traffic of the
+    committed PMC passes when they are of this workload, else the bytes it streams by construction (stored library
+    bytes + the partial sums it writes).  The SURVEY section 8(d) figure (F*P*s reference bytes) is kept as
+    `algorithmic_*`: it counts 3 B/px where the bit-plane layout stores 0.75."""
+    kernel = kernel_of_shape(shape)
+    s_ref = 3 if cw > 0 else 1
+    algo_bytes = float(F) * h * w * s_ref
+    streamed = float(info["bit_tile_bytes"] if shape == 6 else info["tile_bytes"])
+    nsum = (1 if info["n_hue_planes"] > 0 or info["generic_hue"] else 0) + (1 if info["has_value_plane"] else 0)
+    apad = 8 if A <= 8 else (16 if A <= 16 else (32 if A <= 32 else 64))
+    traffic = committed_traffic(workload, kernel)
+    moved = traffic[0] if traffic else None
+    t = kern_ms * 1e-3
+    # partial sums written once per chunk; their count is the engine's choice, so only a lower bound (one chunk) is
+    # known here -- the PMC figure, when present, has the real number
+    constructed = streamed + float(nsum) * apad * F * 4
+    basis = moved if moved is not None else constructed
+    out = {
+        "bound": "hbm", "kernel": kernel, "achieved": basis / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": basis / t / 1e9 / HBM_PEAK_GBPS,
+        "traffic": moved, "traffic_source": ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch, " + traffic[1]) if traffic else None,
+        "bytes_basis": "pmc traffic" if moved is not None else "streamed library bytes + partial sums (by construction)",
+        "streamed_library_bytes_per_launch": streamed, "kernel_ms": kern_ms, "launches_timed": kern_n,
+        "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_achieved": algo_bytes / t / 1e9,
+        "frac_algorithmic": algo_bytes / t / 1e9 / HBM_PEAK_GBPS,
+    }
+    if shape == 6:
+        # int8 MFMA work actually issued: 32 heading rows x 32 views x 32 K per instruction, K = planes x pixels
+        # rounded up to 256 per segment; one pass per 32 resident headings
+        k_total = streamed / (((F + 63) // 64) * 64 / 32.0) / 1024.0 * 256.0
+        passes = (apad + 31) // 32
+        ops = 2.0 * 32 * (((F + 63) // 64) * 64) * k_total * passes
+        out["mfma"] = {"dtype": "i8", "ops_per_launch": ops, "achieved": ops / t / 1e12, "peak": I8_MFMA_PEAK_TOPS,
+                       "unit": "TOP/s", "frac": ops / t / 1e12 / I8_MFMA_PEAK_TOPS,
+                       "useful_ops_per_launch": 2.0 * A * F * h * w * (info["bit_planes_hs"] + info["bit_planes_v"])}
+    else:
+        # v_sad_u8 issues one wave64 instruction per SIMD every 4 cycles: 256 CUs x 4 SIMDs x 64 lanes / 4
+        lane_ops = float(apad) * F * h * w * info["n_planes"] / 4.0
+        peak = 256 * 4 * 64 / 4.0 * CLOCK_PEAK_GHZ * 1e9
+        out["valu"] = {"lane_ops_per_launch": lane_ops, "achieved": lane_ops / t, "peak": peak, "unit": "v_sad_u8 lane-ops/s",
+                       "frac": lane_ops / t / peak, "clock_ghz_assumed": CLOCK_PEAK_GHZ}
+    if with_ceiling:
+        try:
+            out["measured_read_ceiling"] = float(eng.stream_read_gbps(1 << 30, 10))
+        except Exception:                                        # measurement aid only
+            out["measured_read_ceiling"] = None
+    return out
+
+
+def secondary_scoring(device_index, seed, F, h, w, A, cw, steps, warmup):
+    """One more workload on a fresh engine (N=1 only): value, step and kernel time, roofline."""
+    import navsim_amd
+    eng = navsim_amd.FamiliarityEngine(device=device_index)
+    try:
+        eng.generate_library(seed, F, h, w, cw)
+        eng.generate_patches(seed, A)
+        info = eng.library_info()
+        for _ in range(warmup):
+            eng.step_enqueue(want_scene=False)
+            eng.step_wait(want_scene=False)
+        eng.profile_kernel(True, every=4)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step_enqueue(want_scene=False)
+            eng.step_wait(want_scene=False)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        kms, kn = eng.profile_read()
+        eng.profile_kernel(False)
+        shape = eng.workgroup_shape(A)
+        workload = workload_name(w, h, F, A, cw, 1)
+        return {"workload": workload, "value": F * A * steps / dt, "unit": "view-comparisons/s", "ms_per_step": dt / steps * 1e3,
+                "steps": steps, "workgroup_shape": shape,
+                "roofline": roofline_block(eng, info, shape, kms / max(kn, 1), kn, F, h, w, A, cw, workload, with_ceiling=False)}
+    finally:
+        eng.close()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--views", type=int, default=50000, help="stored views per GPU")
-    ap.add_argument("--sensor", type=int, default=64, help="sensor is SENSOR x SENSOR pixels")
-    ap.add_argument("--headings", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--views", type=int, default=500000, help="stored views per GPU")
+    ap.add_argument("--sensor", type=int, default=128, help="sensor is SENSOR x SENSOR pixels")
+    ap.add_argument("--headings", type=int, default=32)
     ap.add_argument("--chem-weight", type=float, default=0.25,
                     help="0 < cw < 1 keeps all three reference bytes per pixel (H,S,V) algorithmically live")
     ap.add_argument("--seed", type=int, default=20261004)
-    ap.add_argument("--cpu-views", type=int, default=50000, help="views in the CPU-baseline sample (0 = skip); the "
-                    "default is the whole configs[1] library: ~12 s of one host core")
+    ap.add_argument("--cpu-views", type=int, default=8000, help="views in the CPU-baseline sample (0 = skip); the "
+                    "default is ~15 s of one host core at the headline shape")
     ap.add_argument("--agent-steps", type=int, default=300, help="steps of the full agent loop timed at N=1 (0 = skip)")
-    ap.add_argument("--event-every", type=int, default=4, help="bracket every n-th timed step's scoring kernel with "
-                    "HIP events (roofline.kernel_ms); 1 = every step")
+    ap.add_argument("--event-every", type=int, default=1, help="bracket every n-th timed step's scoring kernel with "
+                    "HIP events (roofline.kernel_ms); an event pair costs ~5 us of stream time")
     ap.add_argument("--batch-agents", type=int, default=32, help="agents of the ensemble block (configs[4] share of one "
                     "GPU; 0 = skip)")
+    ap.add_argument("--secondary", type=int, default=1, help="1: also time configs[1] (64x64, 50 000 views, 16 headings) "
+                    "at N=1; 0 = skip")
     ap.add_argument("--exchange", choices=["rccl", "mailbox"], default="rccl", help="per-step exchange between ranks: one RCCL "
-                    "all-gather (default), or the single-node mailbox in host-shared memory (no collective kernel)")
+                    "collective (default), or the single-node mailbox in host-shared memory (no collective kernel)")
     ap.add_argument("--skip-known-answer", action="store_true", help="experiments with deliberately broken kernels only")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank "
                     "(exercises the RCCL exchange path on a single GPU)")
@@ -243,7 +355,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    # HIP events around the scoring kernel on a sample of the timed steps: a pair costs ~5 us of stream time
+    # HIP events around the scoring kernel (on the engine's own stream) of the timed steps
     eng.profile_kernel(True, every=args.event_every)
     fence()
     t0 = time.perf_counter()
@@ -284,24 +396,8 @@ def main():
     if rank == 0:
         comparisons = float(world) * F * A * args.steps
         kern_ms = kern_ms_total / max(kern_n, 1)
-        # Algorithmic bytes per launch, SURVEY.md section 8(d): F*P*s with s = 3 for sads_hsv with chem_weight > 0
-        # (H,S,V all live) and s = 1 for chem_weight = 0 (V only); one launch reads the library once for all headings.
-        s_ref = 3 if cw > 0 else 1
-        algo_bytes = float(F) * h * w * s_ref
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-        # What this build actually keeps in HBM and streams per launch: when the library has two
-        # hues and no saturation above 127, one signed plane carries (H,S), i.e. 2 bytes per pixel instead of 3.
-        stored_bytes = float(F) * h * w * info["n_planes"]
-        achieved_stored = stored_bytes / (kern_ms * 1e-3) / 1e9
-        named = {(64, 50000, 16): " (BASELINE.json configs[1])", (128, 500000, 32): " (BASELINE.json configs[2])"}
-        workload = ("%dx%d sensor, %d stored views per GPU, %d headings, sads_hsv chem_weight=%g%s"
-                    % (w, h, F, A, cw, named.get((w, F, A), "") if w == h else ""))
-        traffic = committed_traffic(workload)
-        # SURVEY.md 8(d) asks for both peaks: the spec figure and what a pure streaming read reaches on this device
-        try:
-            read_ceiling = float(eng.stream_read_gbps(1 << 30, 10))
-        except Exception:                                        # measurement aid only
-            read_ceiling = None
+        shape = eng.workgroup_shape(A)
+        workload = workload_name(w, h, F, A, cw, world)
         out = {
             "metric": "view-comparisons/sec (sensor x library x headings)",
             "value": comparisons / dt,
@@ -318,39 +414,50 @@ def main():
             "config": {
                 "workload": workload,
                 "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
-                "workgroup_shape": eng.workgroup_shape(A),
-                "bytes_per_pixel_reference": s_ref, "bytes_per_pixel_stored": info["n_planes"], "parallelism": "library sharded x%d" % world,
-                "exchange": "none" if not use_dist else "1 all-gather of per-heading records per step (%s)" % (
+                "timed_region": "scoring kernel + reductions + decision + result read-back on patches resident in HBM; "
+                                "sensing the patches (k_sense_prep, timed in the `agent` block) and the per-view "
+                                "scene_familiarity output (plot-only in the reference, NavBySceneFamiliarity.py:301-303) "
+                                "are not in it",
+                "precision": "the reference's arithmetic: uint8 HSV in, exact integer sums, float64 scores "
+                             "(util.pyx:31-73); BASELINE.json's 'fp32' SSD wording is the ssd_f32 block",
+                "scoring_kernel": kernel_of_shape(shape), "workgroup_shape": shape,
+                "bytes_per_pixel_reference": 3 if cw > 0 else 1,
+                "bytes_per_pixel_streamed": (info["bit_planes_hs"] + info["bit_planes_v"]) / 8.0 if shape == 6 else info["n_planes"],
+                "parallelism": "library sharded x%d" % world,
+                "exchange": "none" if not use_dist else "1 exchange of per-heading records per step (%s)" % (
                     "mailbox in host-shared memory, no collective" if args.exchange == "mailbox" else
-                    (("RCCL ncclAllGather on the step's stream, device-resident"
+                    (("RCCL on the step's stream, device-resident"
                       if (exchange is not None and exchange.direct is not None) else "RCCL via torch.distributed, device-resident")
                      if args.backend == "nccl" else args.backend)),
             },
             "nav_steps_per_s": args.steps / dt,
             "best_heading": int(res["best_idex"]),
             "known_answer_step": "SKIPPED" if args.skip_known_answer else "ok on every rank (heading %d, view %d of %d, through the exchange)" % (a_star, f_star, world * F),
-            "roofline": {
-                "bound": "hbm", "kernel": "k_sad_tiles", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic[0] if traffic else None,
-                "traffic_source": ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch, " + traffic[1]) if traffic else None,
-                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kern_ms, "launches_timed": kern_n,
-                "stored_bytes_per_launch": stored_bytes, "achieved_stored": achieved_stored,
-                "frac_stored": achieved_stored / HBM_PEAK_GBPS,
-                "measured_read_ceiling": read_ceiling,
-                "frac_stored_of_measured_ceiling": (achieved_stored / read_ceiling) if read_ceiling else None,
-            },
+            "roofline": roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload),
         }
-        if world == 1 and args.agent_steps > 0 and not args.force_dist:
-            eng.clear_library()                                  # make room: the agent builds its own library
-            sps, n_lib, ens_rate = agent_steps_per_s(h, w, A, cw, F, args.seed, args.agent_steps)
-            out["agent"] = {"nav_steps_per_s": sps, "view_comparisons_per_s": sps * n_lib * A, "library_views": n_lib,
-                            "ensemble_of_32_nav_steps_per_s": ens_rate,
-                            "what": "navsim_amd.NavBySceneFamiliarity.step_forward(fake=True): sensor model on the GPU "
-                                    "(2000x2000 landscape resident), scoring, decision, position update; Python caller"}
-        if world == 1 and args.batch_agents > 0 and not args.force_dist:
+        extras = world == 1 and not args.force_dist
+        eng.clear_library()                                      # make room for the secondary blocks
+        if extras and args.secondary:
             try:
-                out["ensemble"] = ensemble_comparisons_per_s(h, w, A, cw, args.seed, args.batch_agents, 100000, 5)
+                out["configs1"] = secondary_scoring(device_index, args.seed, 50000, 64, 64, 16, cw, 200, 20)
+            except Exception as e:                               # noqa: BLE001 - an extra block must not cost the JSON line
+                out["configs1"] = {"error": repr(e)}
+        if extras and args.agent_steps > 0:
+            try:
+                rates, n_lib, ens_rate = agent_steps_per_s(64, 64, 16, cw, 50000, args.seed, args.agent_steps)
+                out["agent"] = {"nav_steps_per_s": rates.get(False), "nav_steps_per_s_fake": rates.get(True),
+                                "view_comparisons_per_s": (rates.get(False) or 0.0) * n_lib * 16, "library_views": n_lib,
+                                "ensemble_of_32_nav_steps_per_s": ens_rate,
+                                "what": "navsim_amd.NavBySceneFamiliarity.step_forward() on the configs[1] shape (64x64, 16 "
+                                        "headings, 50 000-view training path): sensor model on the GPU (2000x2000 landscape "
+                                        "resident), scoring, decision, position update and the error metrics of "
+                                        "NavBySceneFamiliarity.py:252-276; `_fake` = step_forward(fake=True), which skips "
+                                        "the metrics as the reference's own fake flag does; Python caller"}
+            except Exception as e:                               # noqa: BLE001
+                out["agent"] = {"error": repr(e)}
+        if extras and args.batch_agents > 0:
+            try:
+                out["ensemble"] = ensemble_comparisons_per_s(64, 64, 16, cw, args.seed, args.batch_agents, 100000, 5)
             except Exception as e:                               # noqa: BLE001 - an extra block must not cost the JSON line
                 out["ensemble"] = {"error": repr(e)}
         if world == 1 and args.cpu_views > 0:

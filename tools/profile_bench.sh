@@ -15,12 +15,12 @@ OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps $PROFILE_STEPS --warmup 20 --cpu-views 0 --batch-agents 0 $BENCH_ARGS > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps $PROFILE_STEPS --warmup 20 --cpu-views 0 --batch-agents 0 --secondary 0 --agent-steps 0 $BENCH_ARGS > $OUT/bench_under_trace.json 2> $OUT/trace.err
 # the counter passes perturb the timing that picks the workgroup shape: pin the shape the trace pass used
 export DEJAVU_SHAPE=$(python3 -c "import json,sys; print(json.loads(open('$OUT/bench_under_trace.json').read().strip().splitlines()[-1])['config'].get('workgroup_shape', 0))")
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_sq.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_inst -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_inst.err
-rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE --kernel-trace --output-format csv -d $OUT/pmc_sqc -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_sqc.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 --secondary 0 --agent-steps 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 --secondary 0 --agent-steps 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 --secondary 0 --agent-steps 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_inst -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 --secondary 0 --agent-steps 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_inst.err
+rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE --kernel-trace --output-format csv -d $OUT/pmc_sqc -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-views 0 --batch-agents 0 --secondary 0 --agent-steps 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_sqc.err
 cd $ROOT && python3 tools/summarize_profile.py $OUT > $OUT/summary.json && cat $OUT/summary.json
