@@ -80,6 +80,7 @@ struct dv_ctx {
     bool coef_ready = false;                  // d_coef / d_bconst describe the resident patches
     int bits_env = 1;                         // DEJAVU_BITS: 0 never build the bit planes, 1 when they save bytes, 2 whenever possible
     int mfma_tiles_env = 0, mfma_chunk_env = 0;   // DEJAVU_MFMA_TILES / DEJAVU_MFMA_CHUNK (0 = by library size)
+    int mfma_variant_env = 0;                 // DEJAVU_MFMA_VARIANT=1: shorter stages (A/B runs)
     const int* int_hsconst = nullptr;         // constants that go with the partial sums of the last integer scoring pass
     const int* int_vconst = nullptr;
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
@@ -199,6 +200,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_BITS", c->bits_env, 0, 2);
     env_int("DEJAVU_MFMA_TILES", c->mfma_tiles_env, 0, 2);
     env_int("DEJAVU_MFMA_CHUNK", c->mfma_chunk_env, 0, 32);
+    env_int("DEJAVU_MFMA_VARIANT", c->mfma_variant_env, 0, 1);
     env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
@@ -1283,28 +1285,31 @@ static void launch_mfma_variant(dv_ctx* c, int nchunk, int has_hs) {
 // small libraries cut the K-steps into chunks instead so that there are at least as many items as CUs.
 static void launch_mfma(dv_ctx* c, int has_hs) {
     const long long G32 = c->cfg.Fpad / 32;
-    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (G32 >= 16ll * 256 * 4 ? 2 : 1);
+    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (G32 >= 16ll * 256 * 2 ? 2 : 1);     // two, once every CU still gets two items
     const long long GQ = (G32 + 8 * tiles - 1) / (8 * tiles);
     int nchunk = 1;
     if (c->mfma_chunk_env) {
         nchunk = c->mfma_chunk_env;
-    } else if (GQ < 256) {
-        // fewest chunks that fill at least 90 % of the last round of 256 workgroups, else the best filling
-        double best = 0.0;
-        for (int n = 1; n <= c->nchunk_cap && n <= 16; ++n) {
-            const long long items = GQ * n;
-            const double eff = (double)items / (double)(((items + 255) / 256) * 256);
-            if (eff > best + 1e-9) { best = eff; nchunk = n; }
-            if (eff >= 0.9) break;
-        }
+    } else if (GQ < 160) {
+        // Fewer items than ~60 % of the CUs: cut the K-steps so that every CU has one.  (Measured on 50 000 views x 64x64,
+        // 196 items: 1 chunk 59.6 us, 2 chunks 65.3, 3 chunks 74.1, 5 chunks 71.2 -- more chunks mean more partial sums
+        // and more pipeline fills than the idle CUs cost.)
+        nchunk = (int)((256 + GQ - 1) / GQ);
     }
     const int nk_min = c->bcfg.NK[1] > 0 ? (c->bcfg.NK[0] > 0 && c->bcfg.NK[0] < c->bcfg.NK[1] ? c->bcfg.NK[0] : c->bcfg.NK[1]) : c->bcfg.NK[0];
     while (nchunk > 1 && nk_min / nchunk < 4) --nchunk;                  // keep a few K-steps per chunk
     if (nchunk > c->nchunk_cap) nchunk = c->nchunk_cap;
     if (nchunk < 1) nchunk = 1;
     c->nchunk = nchunk;
-    if (tiles == 2) launch_mfma_variant<2, 2>(c, nchunk, has_hs);
-    else launch_mfma_variant<4, 1>(c, nchunk, has_hs);
+    // stage length (K-steps per barrier), measured: two view groups per wave 4 (1.48 ms against 1.58 with 2 at 500 000
+    // views x 128x128), one view group 8 (56.8 us against 59.6 with 4 at 50 000 x 64x64)
+    if (tiles == 2) {
+        if (c->mfma_variant_env == 1) launch_mfma_variant<2, 2>(c, nchunk, has_hs);
+        else launch_mfma_variant<4, 2>(c, nchunk, has_hs);
+    } else {
+        if (c->mfma_variant_env == 1) launch_mfma_variant<4, 1>(c, nchunk, has_hs);
+        else launch_mfma_variant<8, 1>(c, nchunk, has_hs);
+    }
 }
 
 // The integer path of one scoring pass: k_sad_tiles / k_sad_generic, then k_combine.  `after_tiles` (optional) is
