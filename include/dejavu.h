@@ -163,6 +163,23 @@ int dv_sense_step_batch(dv_ctx *ctx, const double *x, const double *y, const dou
 int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,
                               double chem_weight, int64_t first_view, uint8_t *out_views);
 
+/* ---- error / coverage metrics (NavBySceneFamiliarity.py:252-276) -------- */
+/*
+ * update_error of the reference on the device.  dv_set_training_path copies the training points (double[n][2], x then
+ * y; NULL or n < 1 detaches) and clears the coverage marks.  dv_path_error_enqueue computes, for one agent position, the
+ * distance to every training point in the reference's double arithmetic, marks the points within `reach`
+ * (coverage_threshold_factor * step_size, :271) as covered, and leaves the smallest distance for
+ * dv_path_error_wait, which returns the answers in the order they were asked for (at most 8 outstanding).  Nothing
+ * here waits for the GPU except dv_path_error_wait / dv_path_coverage, so the metrics of step t are computed while
+ * step t+1 is scored.  dv_path_coverage copies the marks back (uint8[n], 0/1); dv_path_reset clears them and drops
+ * outstanding answers (reset_error, :195-203).
+ */
+int dv_set_training_path(dv_ctx *ctx, const double *xy, int64_t n);
+int dv_path_error_enqueue(dv_ctx *ctx, double x, double y, double reach);
+int dv_path_error_wait(dv_ctx *ctx, double *nearest);
+int dv_path_coverage(dv_ctx *ctx, uint8_t *out, int64_t n);
+int dv_path_reset(dv_ctx *ctx);
+
 /* ---- scoring ----------------------------------------------------------- */
 /* func(scene, fambuf) of util.pyx:14-20: fambuf[f] for one patch uint8[h,w,3] against every local view. */
 int dv_score(dv_ctx *ctx, const uint8_t *patch, double *fambuf);

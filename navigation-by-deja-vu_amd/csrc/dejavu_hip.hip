@@ -125,6 +125,15 @@ struct dv_ctx {
     bool hsconst_dirty = false;               // k_prep (uploaded patches) wrote constants into d_hsconst
     std::vector<Pose> h_poses;
 
+    // error / coverage metrics of the agent (training path resident; answers collected one step later)
+    double* d_path = nullptr;                 // [n][2]
+    int64_t n_path = 0;
+    unsigned char* d_cover = nullptr;         // [n] coverage marks
+    PathErrState* d_errstate = nullptr;
+    PathErrOut* h_errout = nullptr;           // mapped ring of kErrRing answers
+    PathErrOut* d_errout = nullptr;
+    unsigned long long err_enq = 0, err_deq = 0;   // answers requested / collected
+
     // measurement
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int profile = 0;                          // dv_profile_kernel: bracket every profile-th scoring launch with events
@@ -219,6 +228,10 @@ extern "C" void dv_destroy(dv_ctx* c) {
     if (c->d_poses) (void)hipFree(c->d_poses);
     if (c->d_sense) (void)hipFree(c->d_sense);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_path) (void)hipFree(c->d_path);
+    if (c->d_cover) (void)hipFree(c->d_cover);
+    if (c->d_errstate) (void)hipFree(c->d_errstate);
+    if (c->h_errout) (void)hipHostFree(c->h_errout);
     if (c->h_pub) (void)hipHostFree(c->h_pub);
     if (c->h_mbox) (void)hipHostUnregister(c->h_mbox);
     for (auto e : c->pev) (void)hipEventDestroy(e);
@@ -1702,6 +1715,94 @@ extern "C" int dv_score(dv_ctx* c, const uint8_t* patch, double* fambuf) {
     HIP_TRY(c, hipMemcpyAsync(fambuf, c->d_fam, (size_t)c->cfg.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->step_pending = false;
+    return DV_OK;
+}
+
+// ------------------------------------------------------------------ error / coverage metrics
+constexpr int kErrRing = 8;
+
+extern "C" int dv_set_training_path(dv_ctx* c, const double* xy, int64_t n) {
+    if (!c) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_path) { (void)hipFree(c->d_path); c->d_path = nullptr; }
+    if (c->d_cover) { (void)hipFree(c->d_cover); c->d_cover = nullptr; }
+    c->n_path = 0;
+    c->err_enq = c->err_deq = 0;
+    if (!xy || n < 1) return DV_OK;                              // detach
+    HIP_TRY(c, hipMalloc(&c->d_path, (size_t)n * 2 * sizeof(double)));
+    HIP_TRY(c, hipMalloc(&c->d_cover, (size_t)n));
+    if (!c->d_errstate) {
+        HIP_TRY(c, hipMalloc(&c->d_errstate, sizeof(PathErrState)));
+        HIP_TRY(c, hipHostMalloc(&c->h_errout, kErrRing * sizeof(PathErrOut), hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_errout, c->h_errout, 0));
+    }
+    memset(c->h_errout, 0, kErrRing * sizeof(PathErrOut));
+    const PathErrState init{~0ull, 0u, 0u};
+    HIP_TRY(c, hipMemcpyAsync(c->d_errstate, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_path, xy, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_cover, 0, (size_t)n, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_path = n;
+    return DV_OK;
+}
+
+extern "C" int dv_path_error_enqueue(dv_ctx* c, double x, double y, double reach) {
+    if (!c) return DV_ERR_INVALID;
+    if (c->n_path < 1) return fail(c, DV_ERR_STATE, "no training path set (dv_set_training_path)");
+    if (c->err_enq - c->err_deq >= (unsigned long long)kErrRing)
+        return fail(c, DV_ERR_STATE, "%d path-error answers outstanding: collect them with dv_path_error_wait", kErrRing);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const unsigned long long seq = ++c->err_enq;
+    long long nb = (c->n_path + 255) / 256;
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(k_path_error, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_path, (long long)c->n_path, x, y, reach,
+                       c->d_cover, c->d_errstate, c->d_errout + (seq % kErrRing), seq);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+extern "C" int dv_path_error_wait(dv_ctx* c, double* nearest) {
+    if (!c || !nearest) return DV_ERR_INVALID;
+    if (c->err_deq >= c->err_enq) return fail(c, DV_ERR_STATE, "no path-error answer outstanding");
+    const unsigned long long seq = c->err_deq + 1;
+    volatile const unsigned long long* word = &c->h_errout[seq % kErrRing].seq;
+    bool seen = false;
+    if (c->spin_wait) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (!(seen = (*word == seq))) {
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+    }
+    if (!seen) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (*word != seq) return fail(c, DV_ERR_STATE, "the path-error answer never arrived");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *nearest = c->h_errout[seq % kErrRing].nearest;
+    c->err_deq = seq;
+    return DV_OK;
+}
+
+extern "C" int dv_path_coverage(dv_ctx* c, uint8_t* out, int64_t n) {
+    if (!c || !out) return DV_ERR_INVALID;
+    if (c->n_path < 1 || n != c->n_path) return fail(c, DV_ERR_STATE, "no training path of %lld points set", (long long)n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_cover, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DV_OK;
+}
+
+extern "C" int dv_path_reset(dv_ctx* c) {
+    if (!c) return DV_ERR_INVALID;
+    if (c->n_path < 1) return DV_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->err_deq = c->err_enq;                                     // answers of the run being abandoned are dropped
+    HIP_TRY(c, hipMemsetAsync(c->d_cover, 0, (size_t)c->n_path, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DV_OK;
 }
 

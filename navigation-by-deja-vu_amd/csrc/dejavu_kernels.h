@@ -2099,6 +2099,53 @@ k_sad_mfma(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int
     }
 }
 
+// ------------------------------------------------------------------ error / coverage metrics of the agent
+// update_error of the reference (navsim/NavBySceneFamiliarity.py:252-276) for one position: the distance to every
+// training point in the reference's double arithmetic (delta*delta summed, sqrt; no contraction), its minimum, and
+// the coverage marks `dist <= reach` (the reference ORs them in only when the minimum is within reach, which is the
+// same set: no distance is within reach unless the smallest is).  The last block to arrive hands {nearest, seq} to the
+// host through mapped memory.  Off the step's critical path: the host collects the answer one step later.
+struct PathErrState { unsigned long long minkey; unsigned ticket; unsigned pad; };
+struct PathErrOut { double nearest; unsigned long long seq; };
+
+__global__ void __launch_bounds__(256)
+k_path_error(const double* __restrict__ xy, long long n, double x, double y, double reach, unsigned char* __restrict__ cover,
+             PathErrState* __restrict__ st, PathErrOut* __restrict__ out, unsigned long long seq) {
+    __shared__ unsigned long long wmin[4];
+    unsigned long long key = ~0ull;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double dx = xy[2 * i] - x, dy = xy[2 * i + 1] - y;
+        dx *= dx;
+        dy *= dy;
+        const double dist = sqrt(dx + dy);
+        if (dist <= reach) cover[i] = 1;
+        const unsigned long long k = (unsigned long long)__double_as_longlong(dist);     // dist >= 0: bit order = value order
+        key = k < key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmin[0];
+        for (int i = 1; i < 4; ++i) m = wmin[i] < m ? wmin[i] : m;
+        atomicMin(&st->minkey, m);
+        __threadfence();
+        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const unsigned long long all = __hip_atomic_load(&st->minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->minkey, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out->nearest = __longlong_as_double((long long)all);
+            __threadfence_system();
+            __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.
 __global__ void k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
     const long long stride = (long long)gridDim.x * blockDim.x;

@@ -113,6 +113,11 @@ PROTOTYPES = {
                                            ctypes.POINTER(StepResult)]),
     "dv_set_library_from_poses": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int64, ctypes.c_double,
                                                  ctypes.c_int64, _u8p]),
+    "dv_set_training_path": (ctypes.c_int, [_ctx_p, _f64p, ctypes.c_int64]),
+    "dv_path_error_enqueue": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, ctypes.c_double]),
+    "dv_path_error_wait": (ctypes.c_int, [_ctx_p, _f64p]),
+    "dv_path_coverage": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64]),
+    "dv_path_reset": (ctypes.c_int, [_ctx_p]),
     "dv_score": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
     "dv_step": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
     "dv_step_batch": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,

@@ -235,6 +235,10 @@ class NavBySceneFamiliarity(object):
         self.scene_familiarity = np.zeros(n, dtype=np.float64)
         self._scene_is_inf = False
         self.training_path = points
+        self._metrics_on_device = False
+        if self._engine is not None and hasattr(self._engine, "set_training_path") and points.shape[1] == 2:
+            self._engine.set_training_path(points)
+            self._metrics_on_device = True
         self.reset_error()
         # library hand-off (:140): already resident when the views were sensed on the GPU
         if self._engine is not None:
@@ -249,6 +253,9 @@ class NavBySceneFamiliarity(object):
                 func.engine.clear_library()          # keep the landscape and the sensor configuration
             else:
                 func.engine.close()
+        if getattr(self, "_metrics_on_device", False) and getattr(self, "_engine", None) is not None:
+            self._engine.set_training_path(None)
+        self._metrics_on_device = False
         self.training_path = None
         self.familiar_scenes = None
         self._familiarity_func = None
@@ -288,16 +295,43 @@ class NavBySceneFamiliarity(object):
         self.navigated_for_frames = 0
         self._navigation_error = 0.0
         self._n_navigation_error = 0
+        self._pending_errors = 0
+        self._host_coverage = None
         if self.training_path is not None:
-            self._coverage_array = np.zeros(len(self.training_path), dtype=bool)
+            self._host_coverage = np.zeros(len(self.training_path), dtype=bool)
+            if getattr(self, "_metrics_on_device", False):
+                self._engine.path_reset()
+
+    # The metrics of update_error (:252-276) run on the device when the agent owns its engine: a step asks for them
+    # (dv_path_error_enqueue) and collects the answer one step later, or when a metric is read -- except with a finite
+    # max_distance_to_training_path, where the reference may stop the run inside update_error and the answer is
+    # awaited at once.  Every number is the reference's double arithmetic; only the moment it reaches the host moves.
+    def _collect_errors(self, keep=0):
+        while self._pending_errors > keep:
+            nearest = self._engine.path_error_wait()
+            self._pending_errors -= 1
+            if nearest > self.max_distance_to_training_path:
+                raise TooFarFromTrainingPathException()
+            self._navigation_error += nearest * nearest
+            self._n_navigation_error += 1
+
+    @property
+    def _coverage_array(self):
+        if getattr(self, "_metrics_on_device", False) and self.training_path is not None:
+            self._collect_errors()
+            return self._engine.path_coverage(len(self.training_path))
+        return self._host_coverage
 
     @property
     def navigation_error(self):
+        if getattr(self, "_metrics_on_device", False):
+            self._collect_errors()
         return np.sqrt(self._navigation_error / self._n_navigation_error)
 
     @property
     def percent_recapitulated(self):
-        return np.sum(self._coverage_array) / len(self._coverage_array)
+        cov = self._coverage_array
+        return np.sum(cov) / len(cov)
 
     def _window(self, n_consecutive_scenes):
         return int(n_consecutive_scenes * len(self.training_path))
@@ -306,8 +340,9 @@ class NavBySceneFamiliarity(object):
         """Furthest point i/F of the path such that the `window` scenes before i are all covered (:218-232)."""
         win = self._window(n_consecutive_scenes)
         total = len(self.training_path)
+        cov = self._coverage_array
         for i in range(total, win - 1, -1):
-            if np.all(self._coverage_array[i - win:i]):
+            if np.all(cov[i - win:i]):
                 return i / total
         return 0.
 
@@ -323,6 +358,14 @@ class NavBySceneFamiliarity(object):
 
     def update_error(self):
         self.navigated_for_frames += 1
+        if getattr(self, "_metrics_on_device", False):
+            self._collect_errors()                               # the previous step's answer: ready by now
+            self._engine.path_error_enqueue(self.position[0], self.position[1],
+                                            self.coverage_threshold_factor * self.step_size)
+            self._pending_errors += 1
+            if np.isfinite(self.max_distance_to_training_path):
+                self._collect_errors()                           # may raise TooFarFromTrainingPathException here (:264)
+            return
         delta = self.training_path - self.position
         delta *= delta
         dist = np.sqrt(np.sum(delta, axis=1))
@@ -333,7 +376,7 @@ class NavBySceneFamiliarity(object):
         self._n_navigation_error += 1
         reach = self.coverage_threshold_factor * self.step_size
         if nearest <= reach:
-            self._coverage_array |= (dist <= reach)
+            self._host_coverage |= (dist <= reach)
 
     # ---- the step (:279-329) -------------------------------------------------------------------
     def step_forward(self, fake=False):
@@ -407,6 +450,8 @@ class NavBySceneFamiliarity(object):
         if self._engine is None or self.training_path is None:
             raise ValueError("clone a trained agent whose sensor model runs on the GPU")
         other = copy.copy(self)                                   # shares engine, library views, training path
+        other._metrics_on_device = False                          # the device holds ONE agent's coverage marks: clones keep
+                                                                  # theirs on the host (same arithmetic)
         other.angle_familiarity = np.full_like(self.angle_familiarity, np.nan)
         other.scene_familiarity = None if self.track_scene_familiarity is False else np.zeros_like(self.scene_familiarity)
         other.position, other.angle = None, None

@@ -365,6 +365,32 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_workgroup_shape(self._ctx, int(n_headings), ctypes.byref(v)), "dv_workgroup_shape")
         return int(v.value)
 
+    # -- error / coverage metrics on the device (NavBySceneFamiliarity.py:252-276) ----------------
+    def set_training_path(self, points):
+        """points: float64[n, 2] (x, y), or None to detach.  Clears the coverage marks."""
+        if points is None:
+            self._check(self._lib.dv_set_training_path(self._ctx, None, 0), "dv_set_training_path")
+            return
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        assert pts.ndim == 2 and pts.shape[1] == 2
+        self._check(self._lib.dv_set_training_path(self._ctx, N.f64ptr(pts), pts.shape[0]), "dv_set_training_path")
+
+    def path_error_enqueue(self, x, y, reach):
+        self._check(self._lib.dv_path_error_enqueue(self._ctx, float(x), float(y), float(reach)), "dv_path_error_enqueue")
+
+    def path_error_wait(self):
+        out = ctypes.c_double()
+        self._check(self._lib.dv_path_error_wait(self._ctx, ctypes.byref(out)), "dv_path_error_wait")
+        return out.value
+
+    def path_coverage(self, n):
+        out = np.empty(int(n), dtype=np.uint8)
+        self._check(self._lib.dv_path_coverage(self._ctx, N.u8ptr(out), int(n)), "dv_path_coverage")
+        return out.astype(bool)
+
+    def path_reset(self):
+        self._check(self._lib.dv_path_reset(self._ctx), "dv_path_reset")
+
     def stream_read_gbps(self, n_bytes=1 << 30, iters=10):
         g = ctypes.c_double(0)
         self._check(self._lib.dv_stream_read_gbps(self._ctx, int(n_bytes), int(iters), ctypes.byref(g)),

@@ -663,3 +663,48 @@ def test_ensemble_matches_independent_agents():
     rows = navsim_amd.run_ensemble(ens, frames=0)                  # nothing left to run: just the result rows
     assert [r["stop_status"] for r in rows] == ens.stop_status and all("path_coverage" in r for r in rows)
     ens.engine.close()
+
+
+def test_device_error_metrics_equal_the_host_arithmetic():
+    """update_error on the device (dv_path_error_*, NavBySceneFamiliarity.py:252-276): nearest distances bit-equal to
+    the reference's NumPy expression, the same coverage marks, answers in the order asked, and a finite
+    max_distance_to_training_path stops the run inside the step as the reference does (:264)."""
+    rng = np.random.default_rng(11)
+    path = np.cumsum(rng.uniform(-1.5, 1.5, (70001, 2)), axis=0) + 500.0
+    eng = navsim_amd.FamiliarityEngine(0)
+    try:
+        eng.set_training_path(path)
+        reach = 2.4
+        cov = np.zeros(len(path), dtype=bool)
+        pos = path[rng.integers(0, len(path), 40)] + rng.uniform(-3, 3, (40, 2))
+        want = []
+        for k, (x, y) in enumerate(pos):
+            eng.path_error_enqueue(x, y, reach)
+            delta = path - (x, y)
+            delta *= delta
+            dist = np.sqrt(np.sum(delta, axis=1))
+            want.append(np.min(dist))
+            if want[-1] <= reach:
+                cov |= dist <= reach
+            if k % 5 == 4:                                   # collected late, several at a time, in order
+                for j in range(k - 4, k + 1):
+                    assert eng.path_error_wait() == want[j], j
+        assert np.array_equal(eng.path_coverage(len(path)), cov) and cov.any()
+        with pytest.raises(navsim_amd.EngineError):
+            eng.path_error_wait()                            # nothing outstanding
+        eng.path_reset()
+        assert not eng.path_coverage(len(path)).any()
+    finally:
+        eng.close()
+    # through the agent: too far from the path is raised by the very step that gets there
+    land = synth.synth_landscape(5, 200, 4)
+    line = np.stack([np.linspace(50, 150, 40), np.full(40, 100.0)], axis=1)
+    far = navsim_amd.NavBySceneFamiliarity(land, (8, 8), 2.0, n_test_angles=4, max_distance_to_training_path=1.0,
+                                           familiarity_model=navsim_amd.sads_familiarity())
+    far.train_from_path(line)
+    assert far._metrics_on_device
+    far.position, far.angle = (100.0, 150.0), 0.0
+    with pytest.raises(navsim_amd.TooFarFromTrainingPathException):
+        far.step_forward()
+    assert far.navigated_for_frames == 1
+    far.clear_training()

@@ -2,14 +2,14 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/suite
 timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/suite/pytest.log 2>&1
 rc=$?
-tail -15 gpurun_out/suite/pytest.log
+tail -25 gpurun_out/suite/pytest.log
 if [ $rc -ne 0 ]; then exit $rc; fi
-DEJAVU_VERBOSE=1 timeout -k 10 300 python bench.py --views 500000 --sensor 128 --headings 32 --agent-steps 0 --batch-agents 0 --cpu-views 0 --steps 50 --warmup 5 > gpurun_out/suite/c2.json 2> gpurun_out/suite/c2.err && \
-DEJAVU_VERBOSE=1 timeout -k 10 300 python bench.py --views 50000 --sensor 64 --headings 16 --agent-steps 0 --batch-agents 0 --cpu-views 0 --steps 200 --warmup 20 > gpurun_out/suite/c1.json 2> gpurun_out/suite/c1.err
-grep dejavu gpurun_out/suite/c2.err gpurun_out/suite/c1.err
+timeout -k 10 600 python bench.py --steps 50 --warmup 5 --cpu-views 0 > gpurun_out/suite/full.json 2> gpurun_out/suite/full.err
 python -c "
 import json
-for f in ('c2','c1'):
-    d=json.loads(open('gpurun_out/suite/%s.json'%f).read().strip().splitlines()[-1])
-    print(f, d['value'], d['ms_per_step'], d['config']['workgroup_shape'], d['roofline']['kernel_ms'])
+d=json.loads(open('gpurun_out/suite/full.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])
+print('c1', d['configs1']['value'], d['configs1']['ms_per_step'], d['configs1']['roofline']['kernel_ms'])
+print('agent', d['agent'])
+print('ens', d['ensemble'])
 "
