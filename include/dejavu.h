@@ -46,6 +46,9 @@ enum {
 #define DV_RES_RESOLVED   1u       /* exact tie resolver ran; best_fam / exact_fam are bit-exact */
 #define DV_RES_EXACT_ALL  2u       /* every score of this step is the exact sequential double */
 #define DV_RES_OVERFLOW   4u       /* candidate list overflowed; step was redone in exact mode */
+#define DV_RES_SENSE_ERROR 16u     /* batched calls: THIS agent's sensor footprint reached past the end of the landscape (the
+                                      reference's IndexError for that trial); its other fields are meaningless.  The
+                                      single-agent calls return DV_ERR_INDEX instead. */
 
 /*
  * Result of one step (replaces NavBySceneFamiliarity.py:313-316).
@@ -154,7 +157,8 @@ int dv_sense_step(dv_ctx *ctx, double x, double y, const double *angles, int n_h
 /*
  * Ensemble form: n_agents agents (positions x[i], y[i]; headings angles[i][0..A)) sensed and scored against the one
  * resident library, 64/A agents per library pass -- the trial farm of scripts/run_experiment.py:326-347 as agents
- * batched on one GPU.  results[n_agents].  DV_ERR_INDEX if any footprint leaves the landscape.
+ * batched on one GPU.  results[n_agents].  An agent whose footprint leaves the landscape gets DV_RES_SENSE_ERROR in
+ * its result's flags; the other agents' results are unaffected (the reference's trials are independent).
  */
 int dv_sense_step_batch(dv_ctx *ctx, const double *x, const double *y, const double *angles, int n_agents, int n_headings,
                         uint32_t flags, dv_step_result *results);
@@ -224,7 +228,8 @@ int dv_step_wait(dv_ctx *ctx, dv_step_result *result, double *scene_fam);
 /*
  * Device address of the packed record of the last enqueued step, for a device-side exchange between ranks
  * (stream-ordered after dv_step_enqueue on the context's stream; no host synchronisation):
- *   double[3 + 4A] = approx_max, n_candidates, state (0 integer scores, 1 candidates exact, 2 all exact),
+ *   double[3 + 4A] = approx_max, n_candidates, state (0 integer scores, 1 candidates exact, 2 all exact; + 4 when the
+ *                    patches were sensed past the end of the landscape: dv_merge_records then returns DV_ERR_INDEX),
  *                    angle_fam[A], angle_view[A], exact_fam[A], exact_view[A]
  */
 int dv_step_record(dv_ctx *ctx, void **device_ptr, int *n_doubles);

@@ -28,6 +28,7 @@ using namespace dv;
 static_assert(sizeof(StepResultDev) == sizeof(dv_step_result) + sizeof(unsigned long long) &&
               offsetof(StepResultDev, check) == sizeof(dv_step_result), "device record = host record + check word");
 static_assert(kMaxHeadings == DV_MAX_HEADINGS && kMaxHues == DV_MAX_HUE_PLANES, "header constants differ");
+static_assert(kResSenseError == DV_RES_SENSE_ERROR, "header constants differ");
 
 static thread_local std::string g_create_error;
 
@@ -120,7 +121,7 @@ struct dv_ctx {
     size_t poses_cap = 0;
     unsigned char* d_sense = nullptr;         // [n][sh][sw][3] scratch for dv_sense
     size_t sense_cap = 0;
-    int* d_err = nullptr;                     // [3]: [0],[1] alternate with d_hsconst_pair, [2] is k_sense's
+    unsigned long long* d_err = nullptr;      // [3]: [0],[1] alternate with d_hsconst_pair (one bit per agent of the pass), [2] is k_sense's
     int sense_parity = 0;
     bool hsconst_dirty = false;               // k_prep (uploaded patches) wrote constants into d_hsconst
     std::vector<Pose> h_poses;
@@ -361,6 +362,9 @@ extern "C" int dv_publish_wait(dv_ctx* c, double* dst, int64_t n) {
 extern "C" int dv_merge_records(const double* rec, int world, int A, int64_t stride, double delta, dv_merge_out* out) {
     if (!rec || !out || world < 1 || world > 64 || A < 1 || A > kMaxHeadings || stride < 3 + 4 * (int64_t)A) return DV_ERR_INVALID;
     memset(out, 0, sizeof(*out));
+    // state word: 0..2, + 4 when that rank's patches were sensed past the end of the landscape
+    for (int r = 0; r < world; ++r)
+        if (rec[(int64_t)r * stride + 2] >= 4.0) return DV_ERR_INDEX;
     auto R = [&](int r, int64_t i) { return rec[(int64_t)r * stride + i]; };
     double gmax = R(0, 0);
     for (int r = 1; r < world; ++r) if (R(r, 0) > gmax) gmax = R(r, 0);
@@ -796,8 +800,8 @@ extern "C" int dv_configure_sensor(dv_ctx* c, int sw, int sh, int pw, int ph, co
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->d_lut) HIP_TRY(c, hipMalloc(&c->d_lut, 768));
     if (!c->d_err) {
-        HIP_TRY(c, hipMalloc(&c->d_err, 3 * sizeof(int)));
-        HIP_TRY(c, hipMemsetAsync(c->d_err, 0, 3 * sizeof(int), c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_err, 3 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->d_err, 0, 3 * sizeof(unsigned long long), c->stream));
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_lut, lut, 768, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -821,18 +825,18 @@ static int enqueue_sense(dv_ctx* c, const double* x, const double* y, const doub
         const double rot = -(0.5 * M_PI - angle[i]);
         c->h_poses[(size_t)i] = Pose{x[i], y[i], std::cos(rot), std::sin(rot)};
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_err + 2, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_err + 2, 0, sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), (size_t)n * sizeof(Pose), hipMemcpyHostToDevice, c->stream));
     const long long total = n * c->sensor.sh * c->sensor.sw;
     hipLaunchKernelGGL(k_sense, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, c->d_poses, (int)n,
-                       c->sensor, c->d_lut, d_out, c->d_err + 2);
+                       c->sensor, c->d_lut, d_out, reinterpret_cast<int*>(c->d_err + 2));
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
 
 static int check_sense_error(dv_ctx* c) {
     int err = 0;
-    HIP_TRY(c, hipMemcpyAsync(&err, c->d_err + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&err, c->d_err + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // k_sense's flag: low word
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (err) return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)");
     return DV_OK;
@@ -880,7 +884,7 @@ static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int 
     const long long total = (long long)A * c->cfg.Q * 4;
     hipLaunchKernelGGL(k_sense_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, poses, A,
                        c->sensor, c->d_lut, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, c->APAD, c->d_err + cur,
-                       c->d_hsconst_pair + nxt * kMaxHeadings, c->d_err + nxt);
+                       c->d_hsconst_pair + nxt * kMaxHeadings, c->d_err + nxt, A_agent);
     HIP_TRY(c, hipGetLastError());
     c->patches_sensed = true;      // no host synchronisation here: the step's result record carries the error flag
     return enqueue_bit_prep(c);
@@ -941,8 +945,8 @@ static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_res
         std::vector<Pass> again;
         for (const Pass& p : passes) {
             unsigned bad = 0;
-            for (int ag = 0; ag < p.n; ++ag) bad |= c->h_result[p.slot + ag].flags & (kResNeedsResolve | DV_RES_OVERFLOW | kResSenseError);
-            if (bad) { again.push_back(p); continue; }
+            for (int ag = 0; ag < p.n; ++ag) bad |= c->h_result[p.slot + ag].flags & (kResNeedsResolve | DV_RES_OVERFLOW);
+            if (bad) { again.push_back(p); continue; }            // (an agent sensed past the landscape just carries its flag)
             for (int ag = 0; ag < p.n; ++ag) {
                 memcpy(&results[p.first + ag], &c->h_result[p.slot + ag], sizeof(dv_step_result));
                 for (int a = A; a < kMaxHeadings; ++a) {
@@ -958,9 +962,6 @@ static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_res
             if (rc) return rc;
             rc = finish_pass(c);
             if (rc) return rc;
-            if (c->h_result[0].flags & kResSenseError)
-                return fail(c, DV_ERR_INDEX, "a sensor footprint of agents %d..%d reaches past the end of the landscape "
-                            "(index out of bounds)", p.first, p.first + p.n - 1);
             for (int ag = 0; ag < p.n; ++ag) copy_result(c, ag, &results[p.first + ag]);
         }
     }
@@ -1531,7 +1532,8 @@ static int enqueue_resolve(dv_ctx* c, int agent = 0) {
                        c->d_cand_exact + co, c->cfg);
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state + agent, c->d_cand + co, c->d_cand_exact + co,
-                       c->d_result + agent, c->d_record + (size_t)agent * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta);
+                       c->d_result + agent, c->d_record + (size_t)agent * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta,
+                       c->patches_sensed ? c->d_err + c->sense_parity : nullptr, agent);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }

@@ -888,12 +888,14 @@ __device__ __forceinline__ void decide_block(const unsigned long long* amax, con
 
 // Packed per-rank record for the sharded exchange (navsim_amd/sharded.py:pack_record):
 //   [approx_max, n_candidates, state, angle_fam[A], angle_view[A], exact_fam[A], exact_view[A]]   (doubles)
-// state: 0 integer-sum scores only, 1 candidates re-scored exactly, 2 every score exact.
+// state: 0 integer-sum scores only, 1 candidates re-scored exactly, 2 every score exact; + 4 when the patches were
+// sensed past the end of the landscape (the reference's IndexError, util.pyx:137-168).
 __device__ __forceinline__ void emit_record(const StepResultDev* r, double* __restrict__ rec, int A, int tid, int nthreads) {
     if (tid == 0) {
         rec[0] = r->approx_max;
         rec[1] = (double)r->n_candidates;
-        rec[2] = (r->flags & 2u) ? 2.0 : ((r->flags & 1u) ? 1.0 : 0.0);
+        // + 4: the patches were sensed past the end of the landscape (every rank raises IndexError on seeing it)
+        rec[2] = ((r->flags & 2u) ? 2.0 : ((r->flags & 1u) ? 1.0 : 0.0)) + ((r->flags & kResSenseError) ? 4.0 : 0.0);
     }
     for (int i = tid; i < A; i += nthreads) {
         rec[3 + i] = r->angle_fam[i];
@@ -917,7 +919,7 @@ __global__ void __launch_bounds__(256)
 k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
        StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
        StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene,
-       int exact_all, int force, int seq, const int* __restrict__ sense_err, double delta_rel) {
+       int exact_all, int force, int seq, const unsigned long long* __restrict__ sense_err, double delta_rel) {
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ int s_last;
     const int agent = blockIdx.y;
@@ -1008,7 +1010,7 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     }
     // the other two things the decision needs, fetched by other waves in the same round trip
     if (threadIdx.x == 64) s_ncand = __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 128) s_serr = sense_err ? *sense_err : 0;
+    if (threadIdx.x == 128) s_serr = sense_err ? (int)((*sense_err >> agent) & 1ull) : 0;   // bit = agent of the pass
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long n_all = s_ncand;
@@ -1058,7 +1060,7 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
          int APAD, int has_hs_sum, int has_v_sum, StepState* __restrict__ st, unsigned long long* __restrict__ bsum,
          unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand, double* __restrict__ scene,
          StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene, int force,
-         int seq, const int* __restrict__ sense_err) {
+         int seq, const unsigned long long* __restrict__ sense_err) {
     __shared__ unsigned long long s_bmax[kMaxHeadings];
     __shared__ unsigned long long s_bview[kMaxHeadings];
     __shared__ unsigned long long s_keys[16 * 16 * 17];          // 34 KB: key transposes of phase 2
@@ -1179,7 +1181,7 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
     if (tid < kMaxHeadings) { s_amax[tid] = 0; s_aview[tid] = ~0ull; }
     if (tid == 0) s_ncount = 0;
     if (tid == 64) s_ntmp = __hip_atomic_load(&st->ntmp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 128) s_serr = sense_err ? *sense_err : 0;
+    if (tid == 128) s_serr = sense_err ? (int)((*sense_err >> agent) & 1ull) : 0;          // bit = agent of the pass
     __syncthreads();
     const int G = blockDim.x / A;                       // thread groups; thread (a, r) walks blocks r, r+G, ...
     const int a = tid % A, r = tid / A;
@@ -1362,7 +1364,8 @@ k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw
 // Resolve path only: single wave; folds the exact candidate values into per-heading maxima, then decides.
 __global__ void k_decide(const StepState* __restrict__ st, const unsigned long long* __restrict__ cand,
                          const double* __restrict__ cand_exact, StepResultDev* __restrict__ out,
-                         double* __restrict__ rec, LibCfg c, int A, double delta) {
+                         double* __restrict__ rec, LibCfg c, int A, double delta,
+                         const unsigned long long* __restrict__ sense_err, int agent) {
     __shared__ unsigned long long ekey[kMaxHeadings];
     __shared__ unsigned long long eview[kMaxHeadings];
     __shared__ StepResultDev s_res;
@@ -1378,7 +1381,10 @@ __global__ void k_decide(const StepState* __restrict__ st, const unsigned long l
         if (ordered_key(cand_exact[i]) == ekey[a]) atomicMax(&eview[a], ~(cand[i] & 0xffffffffffull));
     }
     __syncthreads();
-    if (lane == 0) decide_core(st->amax, st->aview, n_all, n > 0, ekey, eview, &s_res, c, A, delta, 0);
+    if (lane == 0) {
+        decide_core(st->amax, st->aview, n_all, n > 0, ekey, eview, &s_res, c, A, delta, 0);
+        if (sense_err && ((*sense_err >> agent) & 1ull)) s_res.flags |= kResSenseError;
+    }
     __syncthreads();
     emit_record(&s_res, rec, A, lane, blockDim.x);
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
@@ -1702,14 +1708,14 @@ __device__ __forceinline__ bool sense_pixel(const unsigned char* __restrict__ la
 // The headings' poses travel as a kernel argument (64 x 32 bytes): no host-to-device copy on the step's path.
 struct PoseSet { Pose p[kMaxHeadings]; };
 
-// hsconst / err are this step's accumulators (added into with atomics, so they must start at zero); next_hsconst /
-// next_err are the OTHER buffers of their pairs, which nothing uses during this step: block 0 clears them for the
+// hsconst / err are this step's accumulators (added into with atomics, so they must start at zero; err is a mask with one
+// bit per agent of the pass, A_agent headings each); next_hsconst / next_err are the OTHER buffers of their pairs, which nothing uses during this step: block 0 clears them for the
 // next sensed step, so that no memset sits on a step's path.
 __global__ void __launch_bounds__(256)
 k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A, SensorCfg g,
              const unsigned char* __restrict__ lut, unsigned char* __restrict__ raw, unsigned* __restrict__ prep,
-             int* __restrict__ hsconst, LibCfg c, int APAD, int* __restrict__ err, int* __restrict__ next_hsconst,
-             int* __restrict__ next_err) {
+             int* __restrict__ hsconst, LibCfg c, int APAD, unsigned long long* __restrict__ err, int* __restrict__ next_hsconst,
+             unsigned long long* __restrict__ next_err, int A_agent) {
     if (blockIdx.x == 0) {
         if (threadIdx.x < kMaxHeadings) next_hsconst[threadIdx.x] = 0;
         if (threadIdx.x == 0) *next_err = 0;
@@ -1744,7 +1750,7 @@ k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
             const int px = grp * 4 + i;
             if (px >= c.P) break;
             unsigned H = Hs[i], S = Ss[i], V = Vs[i];
-            if (!okp[i]) { atomicOr(err, 1); H = S = V = 0; }
+            if (!okp[i]) { atomicOr(err, 1ull << (a / A_agent)); H = S = V = 0; }     // bit = agent of the pass
             rawb[3 * i] = (unsigned char)H; rawb[3 * i + 1] = (unsigned char)S; rawb[3 * i + 2] = (unsigned char)V;
             for (int pl = 0; pl < c.npl; ++pl) w[pl] |= plane_byte(c, pl, H, S, V) << (8 * i);
             if (!c.generic && c.cw > 0.0) {

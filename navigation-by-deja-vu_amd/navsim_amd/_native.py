@@ -18,6 +18,7 @@ DV_STEP_WANT_SCENE = 2
 DV_RES_RESOLVED = 1
 DV_RES_EXACT_ALL = 2
 DV_RES_OVERFLOW = 4
+DV_RES_SENSE_ERROR = 16
 
 ERROR_NAMES = {-1: "DV_ERR_INVALID", -2: "DV_ERR_HIP", -3: "DV_ERR_STATE", -4: "DV_ERR_OOM", -5: "DV_ERR_INDEX"}
 

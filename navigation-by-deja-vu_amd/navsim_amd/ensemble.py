@@ -39,8 +39,10 @@ class NavEnsemble(object):
     def active(self):
         return [i for i, s in enumerate(self.stop_status) if s == 0 and self.agents[i].stopped_with_exception is None]
 
+    SENSE_ERROR_STATUS = -3      # not one of the reference's codes: its trial would have died of an IndexError
+
     def _stop(self, i, exc):
-        self.stop_status[i] = exc.get_code()
+        self.stop_status[i] = exc.get_code() if hasattr(exc, "get_code") else self.SENSE_ERROR_STATUS
         self.agents[i].stopped_with_exception = exc
 
     def step_forward(self, fake=False):
@@ -56,6 +58,11 @@ class NavEnsemble(object):
         if idx:
             results = self.engine.sense_step_batch(xs, ys, np.stack(angs))
             for i, res in zip(idx, results):
+                if res["flags"] & 16:                             # DV_RES_SENSE_ERROR: this agent's footprint left the
+                    # landscape (a corner reaches r*sqrt(2) > r past the bounds test); the reference's trial ends in an
+                    # IndexError, the other trials go on
+                    self._stop(i, IndexError("sensor footprint reaches past the end of the landscape (index out of bounds)"))
+                    continue
                 try:
                     self.agents[i].apply_step_result(res, fake)
                 except StopNavigationException as e:

@@ -48,8 +48,19 @@ def pack_record(res):
     return rec
 
 
+SENSE_ERROR_MESSAGE = "sensor footprint reaches past the end of the landscape (index out of bounds)"
+
+
+def check_sense_error(records):
+    """A rank whose patches were sensed past the end of the landscape says so in its record's state word (+ 4): every
+    rank raises the reference's IndexError (util.pyx:137-168) instead of deciding on zeroed pixels."""
+    if np.any(records[:, 2] >= 4.0):
+        raise IndexError(SENSE_ERROR_MESSAGE)
+
+
 def contending(records, delta):
     """Indices of the ranks whose local maximum is within delta of the global maximum."""
+    check_sense_error(records)
     gmax = np.max(records[:, 0])
     return [r for r in range(records.shape[0]) if records[r, 0] >= gmax - delta], gmax
 
@@ -109,6 +120,8 @@ def merge_records_native(records, delta, n_headings):
     world, stride = records.shape
     out = N.MergeOut()
     rc = lib.dv_merge_records(N.f64ptr(records), world, int(n_headings), stride, float(delta), out)
+    if rc == -5:                                         # DV_ERR_INDEX: some rank sensed past the end of the landscape
+        raise IndexError(SENSE_ERROR_MESSAGE)
     if rc != 0:
         raise N.EngineError("dv_merge_records failed (%d)" % rc)
     mask = out.contending_mask

@@ -141,6 +141,19 @@ def test_device_sharded_agent_with_gpu_sensor_single_rank():
             np.testing.assert_allclose(fam, z[name + "_fam"], rtol=1e-12, atol=0)
             assert hashlib.sha256(np.ascontiguousarray(nsf.familiar_scenes).tobytes()).digest() == bytes(z[name + "_scenes_sha"])
             nsf._engine.close()
+        # the sensor running off the landscape inside a sharded step: the record carries it, every rank raises the
+        # reference's IndexError (the single-GPU agent does: test_gpu_sensor_index_errors_like_the_reference)
+        land = synth.synth_landscape(3, 120, 4)
+        model = sharded.device_sharded_sads_familiarity(0.25, 0, 1, "cuda:0")
+        nsf = navsim_amd.NavBySceneFamiliarity(land, (40, 40), 1.0, n_test_angles=4, familiarity_model=model,
+                                               track_scene_familiarity=False)
+        nsf.train_from_path(np.stack([np.linspace(40, 80, 30), np.full(30, 60.0)], axis=1))
+        nsf.position, nsf.angle = (99.4, 99.4), 0.8 - nsf.angle_offsets[0]
+        with pytest.raises(IndexError):
+            nsf.step_forward(fake=True)
+        nsf.position, nsf.angle = (60.0, 60.0), 0.0
+        nsf.step_forward(fake=True)                      # and the exchange is usable afterwards
+        nsf._engine.close()
     finally:
         dist.destroy_process_group()
 

@@ -708,3 +708,110 @@ def test_device_error_metrics_equal_the_host_arithmetic():
         far.step_forward()
     assert far.navigated_for_frames == 1
     far.clear_training()
+
+
+def test_golden_trajectories_as_ensemble_members(manifest, golden):
+    """The reference's golden trajectories (tests/golden/t4_trajectory.npz) with the agent stepping as a member of a
+    NavEnsemble: member 0 (the trained agent) and member 1 (a clone at the same pose) must both reproduce the
+    reference's headings, positions and angles bit for bit while other members wander elsewhere on the same library --
+    sensing and scoring of all of them share the batched passes (dv_sense_step_batch)."""
+    z = golden("t4_trajectory.npz")
+    for case in manifest["t4_trajectory"]:
+        land = synth.synth_landscape(case["landscape"]["seed"], case["landscape"]["size"], case["landscape"]["grain"])
+        size = case["landscape"]["size"]
+        path = synth.sin_training_path(0.5, 0.2 * size, 0.6 * size, arclen=1.0)[:case["n_views"]]
+        nsf = navsim_amd.NavBySceneFamiliarity(
+            land, case["sensor_dimensions"], case["step_size"], n_test_angles=case["n_test_angles"],
+            sensor_pixel_dimensions=case["sensor_pixel_dimensions"], n_sensor_levels=case["n_sensor_levels"],
+            mask_middle_n=case["mask_middle_n"], saccade_degrees=case["saccade_degrees"],
+            max_distance_to_training_path=450, familiarity_model=navsim_amd.sads_familiarity(case["chem_weight"]),
+            track_scene_familiarity=False)
+        nsf.train_from_path(path)
+        d = path[2] - path[1]
+        a0 = float(np.arctan2(d[1], d[0]) % (2 * np.pi)) + np.deg2rad(case["start_angle_offset_deg"])
+        p0 = path[1] + np.array(case["start_offset"])
+        others = [(path[k] + np.array([0.5, 0.25 * j]), a0 + 0.1 * j) for j, k in enumerate((30, 90, 150, 200, 250))]
+        ens = navsim_amd.NavEnsemble.from_agent(nsf, [(p0, a0), (p0, a0)] + others)
+        n = min(case["steps_recorded"], 300)
+        name = case["name"]
+        for t in range(n):
+            ens.step_forward()
+            for m in (0, 1):
+                ag = ens.agents[m]
+                assert ag.last_best_idex == z[name + "_best"][t], (name, m, t)
+                assert np.array([ag.position[0], ag.position[1]]).tobytes() == z[name + "_pos"][t].tobytes(), (name, m, t)
+                assert np.float64(ag.angle).tobytes() == z[name + "_angle"][t].tobytes(), (name, m, t)
+                np.testing.assert_allclose(ag.step_familiarity, z[name + "_fam"][t], rtol=RTOL)
+        # the member with the device-side metrics and the clone with the host's: the same numbers
+        assert float(ens.agents[0].navigation_error) == float(ens.agents[1].navigation_error)
+        assert np.array_equal(ens.agents[0]._coverage_array, ens.agents[1]._coverage_array)
+        nsf._engine.close()
+
+
+def test_one_agent_off_the_landscape_does_not_stop_the_ensemble():
+    """The reference's trials are independent: an IndexError in one (its rotated sensor reaches past the landscape,
+    util.pyx:137-168) leaves the others running.  In a batched pass the offending agent alone carries
+    DV_RES_SENSE_ERROR; NavEnsemble stops it and steps the rest, whose decisions equal the same agents stepped alone."""
+    land = synth.synth_landscape(3, 120, 4)
+    path = np.stack([np.linspace(40, 80, 30), np.full(30, 60.0)], axis=1)
+
+    def trained():
+        a = navsim_amd.NavBySceneFamiliarity(land, (40, 40), 1.0, n_test_angles=4, track_scene_familiarity=False,
+                                             familiarity_model=navsim_amd.sads_familiarity(0.25))
+        a.train_from_path(path)
+        return a
+
+    poses = [((60.0, 60.0), 0.0), ((99.4, 99.4), 0.8 + np.pi / 2), ((50.0, 61.0), 0.2), ((70.0, 58.0), 6.0)]
+    alone = []
+    for pos, ang in poses:
+        a = trained()
+        a.position, a.angle = pos, ang
+        try:
+            a.step_forward(fake=True)
+            alone.append((a.last_best_idex, a.position, a.angle))
+        except IndexError:
+            alone.append("IndexError")
+        a._engine.close()
+    assert alone[1] == "IndexError" and all(x != "IndexError" for i, x in enumerate(alone) if i != 1)
+    ens = navsim_amd.NavEnsemble.from_agent(trained(), poses)
+    running = ens.step_forward(fake=True)
+    assert running == [0, 2, 3] and ens.stop_status[1] == navsim_amd.NavEnsemble.SENSE_ERROR_STATUS
+    assert isinstance(ens.agents[1].stopped_with_exception, IndexError)
+    for i in (0, 2, 3):
+        ag = ens.agents[i]
+        assert (ag.last_best_idex, ag.position, ag.angle) == alone[i], i
+    assert ens.step_forward(fake=True) == [0, 2, 3]                   # and the next pass runs without it
+    ens.engine.close()
+
+
+def test_ensemble_share_of_config_five_at_size():
+    """One GPU's share of BASELINE.json configs[4]: 32 agents x 16 headings against 100 000 views of 64x64 through
+    dv_step_batch (8 library passes of 64 headings).  Planted answers for six agents in different passes, every
+    agent's per-heading maxima checked against the oracle on a sample of views that contains its best ones."""
+    F, h, w, A, n_agents, seed, cw = 100000, 64, 64, 16, 32, 20261004, 0.25
+    eng = navsim_amd.FamiliarityEngine(0)
+    try:
+        eng.generate_library(seed, F, h, w, cw)
+        patches = synth.synth_patches(seed + 5, n_agents * A, h, w).reshape(n_agents, A, h, w, 3)
+        planted = {0: (3, 77), 5: (15, 99999), 11: (0, 50000), 17: (8, 31337), 24: (9, 64), 31: (7, 12345)}
+        for ag, (a, f) in planted.items():
+            v = synth.synth_views(seed, 1, h, w, first_view=f)[0]
+            patches[ag, a] = v if ag % 2 else synth.near_match_patch(v, ag + 1, fraction=0.01)
+        res = eng.step_batch(patches)
+        assert len(res) == n_agents
+        for ag, (a, f) in planted.items():
+            assert (res[ag]["best_idex"], res[ag]["best_view"]) == (a, f), ag
+            if ag % 2:
+                assert res[ag]["step_familiarity"] == float(h * w)
+        # sampled views: the reported best view of every (agent, heading) plus a fixed spread; on that sample the
+        # oracle's per-heading maximum must be the reported one (it contains the maximiser) and no sampled view may beat it
+        spread = np.arange(0, F, 4999)
+        for ag in range(n_agents):
+            views = np.unique(np.concatenate([spread, np.asarray(res[ag]["angle_view"], dtype=np.int64)]))
+            lib = np.stack([synth.synth_views(seed, 1, h, w, first_view=int(f))[0] for f in views])
+            want = oracle.step(lib, patches[ag], cw)
+            np.testing.assert_allclose(res[ag]["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+            assert res[ag]["best_idex"] == want["best_idex"], ag
+            assert res[ag]["best_view"] == int(views[want["best_view"]]), ag
+    finally:
+        eng.close()
