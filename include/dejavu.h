@@ -233,6 +233,19 @@ int dv_step_wait(dv_ctx *ctx, dv_step_result *result, double *scene_fam);
  *                    angle_fam[A], angle_view[A], exact_fam[A], exact_view[A]
  */
 int dv_step_record(dv_ctx *ctx, void **device_ptr, int *n_doubles);
+/*
+ * The sharded step's fast exchange: packed keys of the last enqueued step for ONE all-reduce(max) of uint64 words
+ * (north star: one all-reduce per navigation step).  dv_step_keys enqueues, behind the step, the kernel that builds
+ *   keys[a], a < A              ordered image of this rank's max over its views of heading a's score
+ *   keys[A + 4r .. A + 4r + 3]  rank r's slot (zero on the other ranks): ordered image of its best score; candidate
+ *                               count | state << 32 | 1 << 48; its first-maximum heading + 1; that heading's view + 1
+ * and returns their device address (n_words = A + 4 * world).  signed_order != 0 flips every word's top bit, so that a
+ * signed 64-bit maximum orders them correctly.  dv_merge_keys (host arithmetic only, no context) takes the reduced
+ * words: when a single (heading, view) pair lies within delta of the global maximum it fills the decision, else it
+ * sets needs_resolve and the full records are exchanged (dv_step_record / dv_merge_records).  DV_ERR_INDEX when a rank
+ * reports patches sensed past the end of the landscape.
+ */
+int dv_step_keys(dv_ctx *ctx, int rank, int world, int signed_order, void **device_ptr, int *n_words);
 /* Enqueue the exact resolver on the last step's candidates (updates the record); no host synchronisation. */
 int dv_resolve_enqueue(dv_ctx *ctx);
 /*
@@ -276,6 +289,7 @@ typedef struct dv_merge_out {
     double angle_fam[DV_MAX_HEADINGS];
 } dv_merge_out;
 int dv_merge_records(const double *records, int world, int n_headings, int64_t stride, double delta, dv_merge_out *out);
+int dv_merge_keys(const uint64_t *keys, int world, int n_headings, double delta, int signed_order, dv_merge_out *out);
 int dv_synchronize(dv_ctx *ctx);
 
 /* ---- measurement ------------------------------------------------------- */

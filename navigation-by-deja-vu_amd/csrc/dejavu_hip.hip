@@ -95,6 +95,7 @@ struct dv_ctx {
     StepResultDev* h_result = nullptr;        // pinned, mapped: the kernels write the result record into it
     StepResultDev* d_result = nullptr;        // device-side address of h_result
     double* d_record = nullptr;               // [3 + 4*64] packed record of the last step, for device-side exchange
+    unsigned long long* d_keys = nullptr;     // [64 + 4*64] packed keys of the last step (all-reduce(max) exchange)
     double* h_scene = nullptr;                // pinned staging for scene_fam
     int A = 0, APAD = 0;                      // resident patches (all agents of the pass)
     int n_agents = 1, A_agent = 0;            // agents in the resident pass and headings per agent
@@ -164,7 +165,7 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
-    F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_bsum); F(c->d_ctmp);
+    F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
     F(c->d_btiles); F(c->d_coef); F(c->d_bconst);
     c->bits_ok = false; c->coef_ready = false; c->btile_bytes = 0;
@@ -614,6 +615,7 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_cand, (size_t)kMaxHeadings * kCandCap * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand_exact, (size_t)kMaxHeadings * kCandCap * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_record, (size_t)kMaxHeadings * (3 + 4 * kMaxHeadings) * sizeof(double)));
+    HIP_TRY(c, hipMalloc(&c->d_keys, (size_t)(kMaxHeadings + kKeyWordsPerRank * 64) * sizeof(unsigned long long)));
     HIP_TRY(c, hipHostMalloc(&c->h_result, kMaxHeadings * sizeof(StepResultDev), hipHostMallocMapped));
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_result, c->h_result, 0));
     memset(c->h_result, 0, kMaxHeadings * sizeof(StepResultDev));
@@ -1684,6 +1686,58 @@ extern "C" int dv_step_record(dv_ctx* c, void** device_ptr, int* n_doubles) {
     if (!c->have_lib || c->A < 1) return fail(c, DV_ERR_STATE, "no library or no resident patches");
     *device_ptr = c->d_record;
     *n_doubles = 3 + 4 * c->A;
+    return DV_OK;
+}
+
+extern "C" int dv_step_keys(dv_ctx* c, int rank, int world, int signed_order, void** device_ptr, int* n_words) {
+    if (!c || !device_ptr || !n_words) return DV_ERR_INVALID;
+    if (!c->have_lib || c->A < 1) return fail(c, DV_ERR_STATE, "no library or no resident patches");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(c, DV_ERR_INVALID, "dv_step_keys: rank %d of %d", rank, world);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_make_keys, dim3(1), dim3(64), 0, c->stream, c->d_record, c->d_keys, c->A, rank, world, signed_order ? 1 : 0);
+    HIP_TRY(c, hipGetLastError());
+    *device_ptr = c->d_keys;
+    *n_words = c->A + kKeyWordsPerRank * world;
+    return DV_OK;
+}
+
+// Host arithmetic of the key exchange; mirrors navsim_amd/sharded.py:merge_keys (the CPU tests compare the two).
+extern "C" int dv_merge_keys(const uint64_t* keys, int world, int A, double delta, int signed_order, dv_merge_out* out) {
+    if (!keys || !out || world < 1 || world > 64 || A < 1 || A > kMaxHeadings) return DV_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    const uint64_t top = signed_order ? 0x8000000000000000ull : 0ull;
+    auto K = [&](int i) { return keys[i] ^ top; };
+    auto to_double = [](uint64_t k) {
+        const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        double d;
+        memcpy(&d, &b, sizeof d);
+        return d;
+    };
+    double approx[64];
+    double gmax = 0.0;
+    int winner = -1;
+    for (int r = 0; r < world; ++r) {
+        const uint64_t w1 = K(A + kKeyWordsPerRank * r + 1);
+        if (!(w1 >> 48)) return fail(nullptr, DV_ERR_STATE, "dv_merge_keys: rank %d contributed no slot", r);
+        if (((w1 >> 32) & 0xff) >= 4) return DV_ERR_INDEX;               // that rank sensed past the end of the landscape
+        approx[r] = to_double(K(A + kKeyWordsPerRank * r));
+        if (winner < 0 || approx[r] > gmax) { gmax = approx[r]; winner = r; }
+    }
+    long long total = 0;
+    for (int r = 0; r < world; ++r) {
+        if (approx[r] >= gmax - delta) {
+            out->contending_mask |= 1ull << r;
+            out->n_contending++;
+            total += (long long)(K(A + kKeyWordsPerRank * r + 1) & 0xffffffffull);
+        }
+    }
+    for (int a = 0; a < A; ++a) out->angle_fam[a] = to_double(K(a));
+    if (total > 1) { out->needs_resolve = 1; return DV_OK; }            // near-ties: the full records decide
+    const int best = (int)K(A + kKeyWordsPerRank * winner + 2) - 1;
+    if (best < 0 || best >= A) return fail(nullptr, DV_ERR_STATE, "dv_merge_keys: heading %d out of range", best);
+    out->best_heading = best;
+    out->best_view = (int64_t)K(A + kKeyWordsPerRank * winner + 3) - 1;
+    out->best_fam = out->angle_fam[best];
     return DV_OK;
 }
 

@@ -672,6 +672,53 @@ k_publish(const double* __restrict__ src, double* __restrict__ dst, unsigned lon
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------ packed keys for the all-reduce(max) exchange
+// The sharded step's fast path (navsim_amd/sharded.py:pack_keys): ONE all-reduce(max) of uint64 words per step,
+//   keys[a], a < A                 ordered key of this rank's max_f fam[a][f]  -> the reduction is angle_familiarity
+//   keys[A + 4r .. A + 4r + 3]     rank r's own slot, zero on every other rank (so the maximum is rank r's words):
+//                                  ordered key of its best score; candidate count | state << 32 | 1 << 48;
+//                                  its first-maximum heading + 1; that heading's first view (global index) + 1.
+// Every rank can then tell whether a single (heading, view) pair lies within delta of the global maximum -- the usual
+// case -- and if so which; otherwise the full records are exchanged as before.  `flip` = 1 flips the top bit of every
+// word so that a SIGNED 64-bit maximum (torch's int64 all_reduce) orders them like the unsigned one.
+constexpr int kKeyWordsPerRank = 4;
+__global__ void __launch_bounds__(64)
+k_make_keys(const double* __restrict__ rec, unsigned long long* __restrict__ keys, int A, int rank, int world, int flip) {
+    const int lane = threadIdx.x;
+    const unsigned long long top = flip ? 0x8000000000000000ull : 0ull;
+    const int n = A + kKeyWordsPerRank * world;
+    for (int i = lane; i < n; i += 64) {
+        unsigned long long w = 0;
+        if (i < A) w = ordered_key(rec[3 + i]);
+        keys[i] = w ^ top;
+    }
+    // this rank's first-maximum heading over the per-heading maxima of its record
+    unsigned long long k = lane < A ? ordered_key(rec[3 + lane]) : 0ull;
+    unsigned long long m = k;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(m, o);
+        m = other > m ? other : m;
+    }
+    int idx = (lane < A && k == m) ? lane : 64;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(idx, o);
+        idx = other < idx ? other : idx;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        if (idx > 63) idx = 0;
+        unsigned long long cnt = (unsigned long long)rec[1];
+        if (cnt > 0x7fffffffull) cnt = 0x7fffffffull;
+        unsigned long long* slot = keys + A + kKeyWordsPerRank * rank;
+        slot[0] = ordered_key(rec[0]) ^ top;
+        slot[1] = (cnt | ((unsigned long long)rec[2] << 32) | (1ull << 48)) ^ top;
+        slot[2] = (unsigned long long)(idx + 1) ^ top;
+        slot[3] = ((unsigned long long)(long long)rec[3 + A + idx] + 1ull) ^ top;
+    }
+}
+
 // ------------------------------------------------------------------ mailbox exchange (one node, host-shared memory)
 // One entry per (slot, rank) of a host segment that every rank's process has mapped and registered with its GPU:
 //   entry = kMboxEntry doubles: [0] sequence number, [1] check word (bits), [2 .. 2+n) the rank's packed record.

@@ -135,6 +135,10 @@ PROTOTYPES = {
     "dv_step_wait": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult), _f64p]),
     "dv_step_record": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
     "dv_resolve_enqueue": (ctypes.c_int, [_ctx_p]),
+    "dv_step_keys": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                    ctypes.POINTER(ctypes.c_int)]),
+    "dv_merge_keys": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                     ctypes.c_int, ctypes.POINTER(MergeOut)]),
     "dv_publish": (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int64]),
     "dv_publish_wait": (ctypes.c_int, [_ctx_p, _f64p, ctypes.c_int64]),
     "dv_set_mailbox": (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),

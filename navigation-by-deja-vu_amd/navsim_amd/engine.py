@@ -318,6 +318,14 @@ class FamiliarityEngine(object):
     def resolve_enqueue(self):
         self._check(self._lib.dv_resolve_enqueue(self._ctx), "dv_resolve_enqueue")
 
+    def step_keys(self, rank, world, signed_order=False):
+        """Enqueue the packing of the last step's keys for the all-reduce(max) exchange; (device pointer, n_words)."""
+        ptr = ctypes.c_void_p()
+        n = ctypes.c_int(0)
+        self._check(self._lib.dv_step_keys(self._ctx, int(rank), int(world), 1 if signed_order else 0, ctypes.byref(ptr),
+                                           ctypes.byref(n)), "dv_step_keys")
+        return int(ptr.value), int(n.value)
+
     # -- measurement ----------------------------------------------------------------------------
     def timer_start(self):
         self._check(self._lib.dv_timer_start(self._ctx), "dv_timer_start")

@@ -108,6 +108,81 @@ def merge_records(records, delta, n_headings):
                 angle_familiarity=out_fam, resolved=True)
 
 
+# ---- the fast exchange: ONE all-reduce(max) of packed uint64 keys per step ---------------------------------------
+# (the north star's collective; include/dejavu.h:dv_step_keys describes the words).  It decides the step whenever a
+# single (heading, view) pair lies within delta of the global maximum -- the usual case; near-ties fall back to the
+# exchange of full records above.  pack_keys / merge_keys are the readable statement of k_make_keys / dv_merge_keys.
+KEY_WORDS_PER_RANK = 4
+_TOP = np.uint64(1 << 63)
+
+
+def ordered_key(x):
+    """uint64 image of float64 whose unsigned order is the numeric order (csrc/dejavu_kernels.h:ordered_key)."""
+    b = np.ascontiguousarray(x, dtype=np.float64).view(np.uint64)
+    return np.where(b >> np.uint64(63), ~b, b | _TOP)
+
+
+def key_to_double(k):
+    k = np.ascontiguousarray(k, dtype=np.uint64)
+    b = np.where(k >> np.uint64(63), k & ~_TOP, ~k)
+    return b.view(np.float64)
+
+
+def pack_keys(rec, rank, world):
+    """This rank's words of the key exchange from its packed record (pack_record): uint64[A + 4 * world]."""
+    A = (len(rec) - 3) // 4
+    keys = np.zeros(A + KEY_WORDS_PER_RANK * world, dtype=np.uint64)
+    ang = np.asarray(rec[3:3 + A], dtype=np.float64)
+    keys[:A] = ordered_key(ang)
+    best = int(np.argmax(ang))                                           # first maximum
+    base = A + KEY_WORDS_PER_RANK * rank
+    keys[base] = ordered_key(np.array([rec[0]]))[0]
+    keys[base + 1] = np.uint64(min(int(rec[1]), 0x7fffffff) | (int(rec[2]) << 32) | (1 << 48))
+    keys[base + 2] = np.uint64(best + 1)
+    keys[base + 3] = np.uint64(int(rec[3 + A + best]) + 1)
+    return keys
+
+
+def merge_keys(keys, world, n_headings, delta):
+    """Decision from the max-reduced keys, or None when near-ties need the exchange of full records."""
+    A = n_headings
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    slots = keys[A:A + KEY_WORDS_PER_RANK * world].reshape(world, KEY_WORDS_PER_RANK)
+    if np.any((slots[:, 1] >> np.uint64(48)) == 0):
+        raise RuntimeError("a rank contributed no slot to the key exchange")
+    if np.any(((slots[:, 1] >> np.uint64(32)) & np.uint64(0xff)) >= 4):
+        raise IndexError(SENSE_ERROR_MESSAGE)
+    approx = key_to_double(slots[:, 0])
+    gmax = approx.max()
+    total = int(np.sum((slots[:, 1] & np.uint64(0xffffffff))[approx >= gmax - delta]))
+    if total > 1:
+        return None
+    winner = int(np.argmax(approx))
+    angle_fam = key_to_double(keys[:A]).copy()
+    best = int(slots[winner, 2]) - 1
+    return dict(best_idex=best, best_view=int(slots[winner, 3]) - 1, step_familiarity=float(angle_fam[best]),
+                angle_familiarity=angle_fam, resolved=False)
+
+
+def merge_keys_native(keys, world, n_headings, delta, signed_order=False):
+    """merge_keys through the library (dv_merge_keys, host arithmetic only)."""
+    from . import _native as N
+    lib = N.load()
+    keys = np.ascontiguousarray(keys).view(np.uint64)
+    out = N.MergeOut()
+    rc = lib.dv_merge_keys(keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), int(world), int(n_headings), float(delta),
+                           1 if signed_order else 0, out)
+    if rc == -5:
+        raise IndexError(SENSE_ERROR_MESSAGE)
+    if rc != 0:
+        raise N.EngineError("dv_merge_keys failed (%d)" % rc)
+    if out.needs_resolve:
+        return None
+    fam = np.frombuffer(out, dtype=np.float64, count=int(n_headings), offset=N.MergeOut.angle_fam.offset)
+    return dict(best_idex=out.best_heading, best_view=out.best_view, step_familiarity=out.best_fam,
+                angle_familiarity=fam, resolved=False)
+
+
 def merge_records_native(records, delta, n_headings):
     """needs_resolve + merge_records in one call into the library (dv_merge_records, host arithmetic only).
 
@@ -141,12 +216,14 @@ class ShardedFamiliarity(object):
                 in production, see `torch_gather`; tests inject a gloo one)
     """
 
-    def __init__(self, engine, gather, rank, world_size):
+    def __init__(self, engine, gather, rank, world_size, reduce_max=None):
         self.engine = engine
         self.gather = gather
+        self.reduce_max = reduce_max          # callable(uint64[k]) -> elementwise maximum over the ranks, or None
         self.rank = rank
         self.world_size = world_size
         self.exchanges = 0
+        self.key_decisions = 0                # steps decided by the all-reduce(max) of packed keys alone
 
     def set_library(self, scenes, chem_weight=0.0):
         """Every rank passes the FULL library (or only its own block via set_library_block)."""
@@ -158,6 +235,16 @@ class ShardedFamiliarity(object):
         res = self.engine.step(patches, want_scene=want_scene)
         A = len(res["angle_familiarity"])
         delta = res["delta"]
+        if self.reduce_max is not None:
+            # one all-reduce(max) of A + 4*world words decides unless there are near-ties
+            keys = self.reduce_max(pack_keys(pack_record(res), self.rank, self.world_size))
+            self.exchanges += 1
+            out = merge_keys(keys, self.world_size, A, delta)
+            if out is not None:
+                self.key_decisions += 1
+                out["scene_familiarity_local"] = res.get("scene_familiarity")
+                out["scene_familiarity"] = None
+                return out
         records = self.gather(pack_record(res))
         self.exchanges += 1
         again, ranks = needs_resolve(records, delta)
@@ -173,7 +260,7 @@ class ShardedFamiliarity(object):
         return out
 
 
-def sharded_sads_familiarity(chem_weight, gather, rank, world_size, engine_factory=None):
+def sharded_sads_familiarity(chem_weight, gather, rank, world_size, engine_factory=None, reduce_max=None):
     """The reference's plug-in shape (navsim/util.pyx:10-25) over a library sharded across ranks.
 
     model(scenes) gives this rank's engine its block of `scenes` and returns `func` whose `.engine` is a
@@ -189,7 +276,7 @@ def sharded_sads_familiarity(chem_weight, gather, rank, world_size, engine_facto
         else:
             from .engine import FamiliarityEngine
             engine = FamiliarityEngine()
-        sh = ShardedFamiliarity(engine, gather, rank, world_size)
+        sh = ShardedFamiliarity(engine, gather, rank, world_size, reduce_max=reduce_max)
         sh.set_library(scenes, chem_weight)
 
         def func(scene, fambuf):
@@ -266,6 +353,24 @@ def torch_gather(device=None):
     return gather
 
 
+def torch_reduce_max(device=None):
+    """reduce_max for ShardedFamiliarity over an initialised torch.distributed group: elementwise maximum of uint64
+    words over the ranks.  torch reduces int64, so the words travel with their top bit flipped (signed order = unsigned
+    order)."""
+    import torch
+    import torch.distributed as dist
+
+    def reduce_max(keys):
+        flipped = (np.ascontiguousarray(keys, dtype=np.uint64) ^ _TOP).view(np.int64)
+        t = torch.from_numpy(flipped.copy())
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy().view(np.uint64) ^ _TOP
+
+    return reduce_max
+
+
 class _NcclUniqueId(ctypes.Structure):
     _fields_ = [("internal", ctypes.c_char * 128)]
 
@@ -280,6 +385,8 @@ class DirectRccl(object):
     """
 
     NCCL_FLOAT64 = 8
+    NCCL_UINT64 = 5
+    NCCL_MAX = 2
 
     def __init__(self, rank, world_size):
         import torch
@@ -289,6 +396,8 @@ class DirectRccl(object):
         self.lib.ncclGetErrorString.restype = ctypes.c_char_p
         self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
         self.lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_void_p]
         uid = _NcclUniqueId()
         if rank == 0:
@@ -308,6 +417,10 @@ class DirectRccl(object):
         self._ok(self.lib.ncclAllGather(ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr), count, self.NCCL_FLOAT64,
                                         self.comm, ctypes.c_void_p(stream)), "ncclAllGather")
 
+    def all_reduce_max_u64(self, send_ptr, recv_ptr, count, stream):
+        self._ok(self.lib.ncclAllReduce(ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr), count, self.NCCL_UINT64,
+                                        self.NCCL_MAX, self.comm, ctypes.c_void_p(stream)), "ncclAllReduce")
+
     def close(self):
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)
@@ -317,8 +430,8 @@ class DirectRccl(object):
 class _DeviceArray(object):
     """Minimal __cuda_array_interface__ carrier so that torch can wrap a raw device pointer without copying."""
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(ptr, False), version=2)
 
 
 class DeviceExchange(object):
@@ -350,6 +463,12 @@ class DeviceExchange(object):
         self.gathered = torch.empty(world_size * n, dtype=torch.float64, device=self.device)
         self.host = np.empty((world_size, n), dtype=np.float64)
         self.exchanges = 0
+        # the fast exchange: one all-reduce(max) of A + 4*world packed keys (DEJAVU_KEY_EXCHANGE=0: always full records)
+        self.use_keys = os.environ.get("DEJAVU_KEY_EXCHANGE", "1") != "0"
+        self.n_keys = self.A + KEY_WORDS_PER_RANK * world_size
+        self.keys_red = torch.zeros(self.n_keys, dtype=torch.int64, device=self.device)
+        self.keys_host = np.empty(self.n_keys, dtype=np.float64)      # raw words; dv_publish moves 8-byte units
+        self.key_decisions = 0
         # RCCL on the engine's own stream when it can be set up on every rank (DEJAVU_DIRECT_RCCL=0: torch's path)
         self.direct = None
         if os.environ.get("DEJAVU_DIRECT_RCCL", "1") != "0":
@@ -403,8 +522,31 @@ class DeviceExchange(object):
         self.exchanges += 1
         return self.host
 
+    def _reduce_keys(self):
+        """One all-reduce(max) of this step's packed keys behind the step's kernels, handed to the host like the
+        records; returns the decision or None (near-ties: the full records decide)."""
+        direct = self.direct is not None
+        ptr, n = self.engine.step_keys(self.rank, self.world, signed_order=not direct)
+        assert n == self.n_keys
+        if direct:
+            self.direct.all_reduce_max_u64(ptr, self.keys_red.data_ptr(), n, self.stream.cuda_stream)
+        else:
+            with self._torch.cuda.stream(self.stream):
+                src = self._torch.as_tensor(_DeviceArray(ptr, n, "<i8"), device=self.device)
+                self.keys_red.copy_(src)
+                self._dist.all_reduce(self.keys_red, op=self._dist.ReduceOp.MAX)
+        self.engine.publish(self.keys_red.data_ptr(), n)
+        self.engine.publish_wait(self.keys_host)
+        self.exchanges += 1
+        return merge_keys_native(self.keys_host, self.world, self.A, self.delta, signed_order=not direct)
+
     def step(self):
         self.engine.step_enqueue(want_scene=False)
+        if self.use_keys:
+            out = self._reduce_keys()
+            if out is not None:
+                self.key_decisions += 1
+                return out
         records = self._gather()
         again, ranks, out = merge_records_native(records, self.delta, self.A)
         if again:

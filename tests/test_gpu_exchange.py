@@ -74,8 +74,32 @@ def test_device_exchange_single_rank_matches_plain_step(eng):
                 np.testing.assert_allclose(out["angle_familiarity"], want["angle_familiarity"], rtol=1e-12)
                 assert ex.exchanges >= 3
                 ex.close()
+        # the fast exchange: without near-ties ONE all-reduce(max) of packed keys decides the step (k_make_keys,
+        # ncclAllReduce(uint64, max) on the engine's stream or torch's int64 maximum with the sign bit flipped),
+        # with the same decision as the full records (DEJAVU_KEY_EXCHANGE=0)
+        lib = synth.synth_views(78, 1500, 12, 12)
+        pats = synth.synth_patches(78, 7, 12, 12)
+        pats[2] = synth.near_match_patch(lib[700], 3)
+        want = oracle.step(lib, pats, 0.3)
+        eng.set_library(lib, 0.3)
+        eng.upload_patches(pats)
+        for direct in ("1", "0"):
+            os.environ["DEJAVU_DIRECT_RCCL"] = direct
+            seen = {}
+            for keys in ("1", "0"):
+                os.environ["DEJAVU_KEY_EXCHANGE"] = keys
+                ex = sharded.DeviceExchange(eng, 0, 1, torch.device("cuda", 0))
+                for _ in range(4):
+                    out = ex.step()
+                seen[keys] = (out["best_idex"], out["best_view"], float(out["step_familiarity"]),
+                              np.asarray(out["angle_familiarity"]).tolist())
+                assert (ex.key_decisions, ex.exchanges) == ((4, 4) if keys == "1" else (0, 4)), (direct, keys)
+                ex.close()
+            assert seen["1"] == seen["0"]
+            assert seen["1"][:2] == (want["best_idex"], want["best_view"]) == (2, 700)
     finally:
         os.environ.pop("DEJAVU_DIRECT_RCCL", None)
+        os.environ.pop("DEJAVU_KEY_EXCHANGE", None)
         eng.set_stream(None)
         dist.destroy_process_group()
 

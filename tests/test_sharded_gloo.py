@@ -46,6 +46,7 @@ def worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     gather = sharded.torch_gather(device=None)
+    reduce_max = sharded.torch_reduce_max(device=None)
     results = []
     for name, lib, pat, cw in cases():
         sh = sharded.ShardedFamiliarity(OracleBackedEngine(), gather, rank, world)
@@ -55,6 +56,12 @@ def worker(rank, world, port, q):
         r = sh.step(pat)
         results.append((name, r["best_idex"], r["best_view"], r["step_familiarity"],
                         r["angle_familiarity"].tolist(), sh.exchanges))
+        # the same step with the fast exchange first: one all-reduce(max) of packed keys, full records only on near-ties
+        shk = sharded.ShardedFamiliarity(OracleBackedEngine(), gather, rank, world, reduce_max=reduce_max)
+        shk.set_library(lib, cw)
+        rk = shk.step(pat)
+        results.append((name + "+keys", rk["best_idex"], rk["best_view"], rk["step_familiarity"],
+                        rk["angle_familiarity"].tolist(), (shk.exchanges, shk.key_decisions)))
     q.put((rank, results))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,6 +88,8 @@ def test_sharded_matches_unsharded_reference(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     expected = {name: oracle.step(lib, pat, cw) for name, lib, pat, cw in cases()}
+    for name in list(expected):
+        expected[name + "+keys"] = expected[name]
     exchanged = {}
     for rank in range(world):
         for name, best, view, fam, angle, exchanges in got[rank]:
@@ -93,6 +102,57 @@ def test_sharded_matches_unsharded_reference(world):
     # one exchange when the integer scores decide, a second one only for cross-rank ties
     assert exchanged["plain"] == 1 and exchanged["plain_cw"] == 1
     assert exchanged["dups_across_ranks"] >= 1
+    # the key exchange alone decides the plain cases (1 collective of A + 4*world words); ties go on to the records
+    assert exchanged["plain+keys"] == (1, 1) and exchanged["plain_cw+keys"] == (1, 1)
+    for name in ("dups_across_ranks", "all_same"):               # (ties_4x4's near-ties need not involve the maximum)
+        n_ex, n_key = exchanged[name + "+keys"]
+        assert n_key == 0 and n_ex >= 2, name
+
+
+def test_key_merge_rules_native_equals_python():
+    """dv_merge_keys (host C in the library) against sharded.merge_keys on random reduced keys, incl. the signed-order
+    transport and the sense-error word."""
+    rng = np.random.default_rng(3)
+    delta = 1e-9
+    n_decided = 0
+    for it in range(300):
+        world, A = int(rng.integers(1, 9)), int(rng.integers(1, 65))
+        recs = []
+        for r in range(world):
+            ang = rng.choice([10.0, 10.0 + 1e-12, 9.5, 3.25, 7.0, -1.5], A) + (0.0 if it % 3 else rng.uniform(0, 1e-3, A))
+            rec = np.empty(3 + 4 * A)
+            rec[0] = ang.max()
+            rec[1] = float(rng.integers(1, 4) if it % 2 else 1)
+            rec[2] = float(rng.integers(0, 3))
+            rec[3:3 + A] = ang
+            rec[3 + A:3 + 2 * A] = rng.integers(0, 1 << 33, A)
+            rec[3 + 2 * A:] = 0.0
+            recs.append(rec)
+        keys = np.zeros(A + 4 * world, dtype=np.uint64)
+        for r in range(world):
+            keys = np.maximum(keys, sharded.pack_keys(recs[r], r, world))
+        want = sharded.merge_keys(keys, world, A, delta)
+        for signed in (False, True):
+            wire = keys ^ np.uint64(1 << 63) if signed else keys
+            got = sharded.merge_keys_native(wire, world, A, delta, signed_order=signed)
+            assert (got is None) == (want is None), it
+            if want is not None:
+                n_decided += 1
+                assert (got["best_idex"], got["best_view"], got["step_familiarity"]) == (
+                    want["best_idex"], want["best_view"], want["step_familiarity"]), it
+                assert np.array_equal(got["angle_familiarity"], want["angle_familiarity"])
+                # and it is what the full records would have decided
+                full = sharded.merge_records(np.stack(recs), delta, A)
+                assert (full["best_idex"], full["best_view"], full["step_familiarity"]) == (
+                    want["best_idex"], want["best_view"], want["step_familiarity"]), it
+    assert n_decided > 100
+    rec = recs[0].copy()
+    rec[2] += 4.0                                           # sensed past the end of the landscape
+    keys = sharded.pack_keys(rec, 0, 1)
+    with pytest.raises(IndexError):
+        sharded.merge_keys(keys, 1, A, delta)
+    with pytest.raises(IndexError):
+        sharded.merge_keys_native(keys, 1, A, delta)
 
 
 def ensemble_case():
