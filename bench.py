@@ -173,6 +173,44 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     return rates, n_lib, ens_rate
 
 
+def ssd_f32_block(device_index, F, h, w, A, steps):
+    """The north star's literal "fp32 SSD" on the configs[1] shape: float32 single-channel views (819 MB), the metric the
+    reference defines as `ssds` (util.pyx:171-184).  Patches are uploaded every step (262 KB): the PCIe-inclusive step."""
+    import navsim_amd
+    rng = np.random.default_rng(1)
+    lib = rng.random((F, h, w), dtype=np.float32)
+    patches = rng.random((A, h, w), dtype=np.float32)
+    patches[A // 2] = lib[31337 % F] + np.float32(0.01)
+    eng = navsim_amd.FamiliarityEngine(device_index)
+    try:
+        eng.set_library_f32(lib)
+        for _ in range(5):
+            r = eng.step_f32(patches)
+        if (r["best_idex"], r["best_view"]) != (A // 2, 31337 % F):
+            raise RuntimeError("ssd_f32: planted view not found")
+        eng.profile_kernel(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step_f32(patches)
+        dt = (time.perf_counter() - t0) / steps
+        kms, kn = eng.profile_read()
+        eng.profile_kernel(False)
+    finally:
+        eng.close()
+    passes = (A + 15) // 16
+    kern_ms = kms / max(kn, 1)
+    streamed = float(F) * h * w * 4 * passes
+    algo = float(F) * h * w * 4
+    return {"workload": "%dx%d sensor, %d stored float32 views, %d headings, ssd_f32" % (w, h, F, A), "dtype": "f32",
+            "value": F * A / dt, "unit": "view-comparisons/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "roofline": {"bound": "hbm", "kernel": "k_ssd_tiles", "kernel_ms": kern_ms, "launches_timed": kn,
+                         "library_passes": passes, "achieved": streamed / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": streamed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "bytes_basis": "streamed library bytes (4 B/px x passes of 16 headings)",
+                         "algorithmic_bytes_per_launch": algo,
+                         "frac_algorithmic": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+
+
 def workload_name(w, h, F, A, cw, world):
     named = ""
     if w == h:
@@ -455,6 +493,11 @@ def main():
                                         "the metrics as the reference's own fake flag does; Python caller"}
             except Exception as e:                               # noqa: BLE001
                 out["agent"] = {"error": repr(e)}
+        if extras and args.secondary:
+            try:
+                out["ssd_f32"] = ssd_f32_block(device_index, 50000, 64, 64, 16, 50)
+            except Exception as e:                               # noqa: BLE001
+                out["ssd_f32"] = {"error": repr(e)}
         if extras and args.batch_agents > 0:
             try:
                 out["ensemble"] = ensemble_comparisons_per_s(64, 64, 16, cw, args.seed, args.batch_agents, 100000, 5)

@@ -208,7 +208,7 @@ int dv_resolve(dv_ctx *ctx, dv_step_result *result);
  * views: float32[F,h,w] single channel.  Scores are sums of squared differences (smaller = more familiar):
  * fp32 fma over 16 pixels folded into a double, within ~1e-6 relative of ssds() on the upcast data; the chosen
  * heading / view are those of the exact double sums (near-ties within 3e-6 relative are re-scored exactly).
- * At most 16 headings per step.  In the result, angle_fam[a] = min over views of the SSD of heading a,
+ * Up to DV_MAX_HEADINGS headings per step, scored 16 per pass over the library.  In the result, angle_fam[a] = min over views of the SSD of heading a,
  * best_heading = first heading attaining the overall minimum; scene_ssd[f] = max over headings.
  */
 int dv_set_library_f32(dv_ctx *ctx, const float *views, int64_t n_views, int h, int w, int64_t first_view);

@@ -1465,6 +1465,7 @@ __global__ void k_retile_f32(const float* __restrict__ raw, float4* __restrict__
     ftiles[(r / c.Q) * c.gstride + (long long)q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// fprep[q][j][a] = patch pixel 4q + j of heading a: wave-uniform, read with scalar loads into SGPRs.
 __global__ void k_prep_f32(const float* __restrict__ raw, float* __restrict__ fprep, LibCfg c, int A, int APAD) {
     const long long total = (long long)c.Q * 4 * APAD;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1474,58 +1475,88 @@ __global__ void k_prep_f32(const float* __restrict__ raw, float* __restrict__ fp
     fprep[t] = (a < A && px < c.P) ? raw[(long long)a * c.P + px] : 0.f;
 }
 
-template <int APAD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))
-k_ssd_tiles(const float4* __restrict__ ftiles, const float* __restrict__ fprep, double* __restrict__ part, LibCfg c, int nchunk) {
+// Scoring kernel of the ssd_f32 metric.  Item = (pixel chunk, view group of 64), scored by a workgroup of NW waves that
+// take the item's 16-pixel blocks round-robin; lane <-> view, APAD headings per pass (a_off selects the slice of the
+// apad_total resident ones: 32 or 64 headings are further passes over the library).
+//   * arithmetic: d = l - p, run = fma(d, d, run) in fp32 over one 16-pixel block, then added into a double per heading
+//     (~1e-7 relative; near-ties are re-scored exactly by k_resolve_f32).  Two VALU instructions per pixel and heading
+//     are the floor of this form -- packed fp32 is not faster on gfx950 (measured: 283 us against 213) -- so the kernel
+//     is co-limited by VALU issue and HBM: the next block's tiles are loaded before the current one is scored;
+//   * the NW waves add their doubles up in LDS in a fixed order (wave 0 + 1 + 2 + 3: reproducible) and share the
+//     stores, so a quarter of the partial sums cross HBM.
+template <int APAD, int NW, bool PF>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(96))) __attribute__((amdgpu_waves_per_eu(APAD == 16 ? 4 : 6)))
+k_ssd_tiles(const float4* __restrict__ ftiles, const float* __restrict__ fprep, double* __restrict__ part, LibCfg c, int nchunk,
+            int apad_total, int a_off) {
+    extern __shared__ double red_f[];            // [NW][APAD][64] when NW > 1
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
+    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Q = c.Q;
     const long long G = c.Fpad / 64;
     const long long n_items = G * nchunk;
-    const long long stride = (long long)gridDim.x * nw;
-    for (long long item = (long long)blockIdx.x * nw + wave; item < n_items; item += stride) {
+    const int Q4 = (Q + 3) / 4;                  // 16-pixel blocks
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / G);
         const long long g = item - (long long)ch * G;
-        // chunk boundaries on multiples of 4 q-steps (16 pixels): the fp32 -> double fold happens every 4 steps
-        const int Q4 = (Q + 3) / 4;
-        const int q0 = (int)(((long long)ch * Q4) / nchunk) * 4;
-        int q1 = (int)(((long long)(ch + 1) * Q4) / nchunk) * 4;
-        if (q1 > Q) q1 = Q;
+        const int b0 = (int)(((long long)ch * Q4) / nchunk), b1 = (int)(((long long)(ch + 1) * Q4) / nchunk);
         const float4* base = ftiles + g * c.gstride + lane;
         double acc[APAD];
-        float run[APAD];
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) { acc[a] = 0.0; run[a] = 0.f; }
-        for (int qb = q0; qb < q1; qb += 4) {
-            float4 L[4];
+        for (int a = 0; a < APAD; ++a) acc[a] = 0.0;
+        auto load_block = [&](int blk, v4u_t (&dst)[4]) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int q = (qb + s < q1) ? qb + s : q1 - 1;
-                const v4u_t t = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(&base[(long long)q * 64]));
-                L[s] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+                const int q = (blk * 4 + s < Q) ? blk * 4 + s : Q - 1;
+                dst[s] = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(&base[(long long)q * 64]));
             }
+        };
+        v4u_t cur[4], nxt[4];
+        if (PF && b0 + wave < b1) load_block(b0 + wave, cur);
+        for (int blk = b0 + wave; blk < b1; blk += NW) {
+            const int qb = blk * 4;
+            if (PF) load_block(blk + NW < b1 ? blk + NW : blk, nxt);  // the next block's tiles, in flight while this one is scored
+            else load_block(blk, cur);
+            float run[APAD];
+#pragma unroll
+            for (int a = 0; a < APAD; ++a) run[a] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                if (qb + s < q1) {
-                    const float* pp = fprep + ((long long)(qb + s) * 4) * APAD;          // wave-uniform -> s_load
-                    const float lw[4] = {L[s].x, L[s].y, L[s].z, L[s].w};
+                if (qb + s < Q) {
+                    const float* pp = fprep + ((long long)(qb + s) * 4) * apad_total + a_off;          // wave-uniform -> s_load
+                    const float lw[4] = {__uint_as_float(cur[s].x), __uint_as_float(cur[s].y), __uint_as_float(cur[s].z), __uint_as_float(cur[s].w)};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
 #pragma unroll
                         for (int a = 0; a < APAD; ++a) {
-                            const float d = lw[j] - pp[j * APAD + a];
+                            const float d = lw[j] - pp[j * apad_total + a];
                             run[a] = __builtin_fmaf(d, d, run[a]);
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int a = 0; a < APAD; ++a) { acc[a] += (double)run[a]; run[a] = 0.f; }
-        }
-        double* dst = part + ((long long)ch * APAD) * c.Fpad + g * 64 + lane;
+            for (int a = 0; a < APAD; ++a) acc[a] += (double)run[a];
+            if (PF) {
 #pragma unroll
-        for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc[a];
+                for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
+            }
+        }
+        double* dst = part + ((long long)ch * apad_total + a_off) * c.Fpad + g * 64 + lane;
+        if (NW == 1) {
+#pragma unroll
+            for (int a = 0; a < APAD; ++a) dst[(long long)a * c.Fpad] = acc[a];
+            continue;
+        }
+#pragma unroll
+        for (int a = 0; a < APAD; ++a) red_f[(wave * APAD + a) * 64 + lane] = acc[a];
+        __syncthreads();
+        for (int a = wave; a < APAD; a += NW) {
+            double t = red_f[a * 64 + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) t += red_f[(w2 * APAD + a) * 64 + lane];
+            dst[(long long)a * c.Fpad] = t;
+        }
+        __syncthreads();
     }
 }
 

@@ -462,7 +462,8 @@ def _ssd_reference(lib, patches):
     return out
 
 
-@pytest.mark.parametrize("F,h,w,A", [(1, 1, 1, 1), (130, 5, 7, 3), (300, 16, 16, 16), (64, 9, 31, 8), (257, 32, 32, 10)])
+@pytest.mark.parametrize("F,h,w,A", [(1, 1, 1, 1), (130, 5, 7, 3), (300, 16, 16, 16), (64, 9, 31, 8), (257, 32, 32, 10),
+                                     (200, 12, 12, 32), (150, 10, 14, 64), (90, 7, 9, 37)])
 def test_ssd_f32_metric_against_reference_ssds(eng, F, h, w, A):
     rng = np.random.default_rng(F * 7 + A)
     lib = rng.uniform(-3, 3, (F, h, w)).astype(np.float32)
@@ -815,3 +816,41 @@ def test_ensemble_share_of_config_five_at_size():
             assert res[ag]["best_view"] == int(views[want["best_view"]]), ag
     finally:
         eng.close()
+
+
+def test_ssd_f32_full_size_properties():
+    """ssd_f32 on BASELINE configs[1]'s shape (64x64, 50 000 views; 16 and 32 headings = one and two passes): planted
+    near-copies win at their headings, the planted pairs' SSDs equal the reference's `ssds` on the upcast data to 1e-6,
+    scaling every input by 2 scales every SSD by exactly 4, and both workgroup shapes agree on the decision."""
+    import os
+    F, h, w = 50000, 64, 64
+    rng = np.random.default_rng(2)
+    lib = rng.random((F, h, w), dtype=np.float32)
+    for A in (16, 32):
+        patches = rng.random((A, h, w), dtype=np.float32)
+        patches[A - 3] = lib[31337] + np.float32(0.01)
+        patches[2] = lib[49999] + rng.normal(0, 0.02, (h, w)).astype(np.float32)
+        seen = {}
+        for shape in ("0", "2"):                    # default (single wave, prefetch) and four waves + LDS fold
+            os.environ["DEJAVU_SHAPE"] = shape
+            try:
+                eng = navsim_amd.FamiliarityEngine(0)
+            finally:
+                os.environ.pop("DEJAVU_SHAPE", None)
+            try:
+                eng.set_library_f32(lib)
+                r = eng.step_f32(patches)
+                assert (r["best_idex"], r["best_view"]) == (A - 3, 31337)
+                assert int(r["angle_view"][2]) == 49999
+                for a, f in ((A - 3, 31337), (2, 49999)):
+                    want = oracle.ssds(patches[a].astype(np.float64), lib[f].astype(np.float64))
+                    np.testing.assert_allclose(r["angle_ssd"][a], want, rtol=1e-6)
+                seen[shape] = np.array(r["angle_ssd"])
+                if shape == "0" and A == 16:
+                    eng.set_library_f32(lib * np.float32(2))
+                    r2 = eng.step_f32(patches * np.float32(2))
+                    assert (r2["best_idex"], r2["best_view"]) == (A - 3, 31337)
+                    assert np.array_equal(np.array(r2["angle_ssd"]), 4.0 * seen["0"])      # powers of two: exact
+            finally:
+                eng.close()
+        np.testing.assert_allclose(seen["0"], seen["2"], rtol=1e-6)
