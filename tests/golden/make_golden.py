@@ -307,14 +307,91 @@ def ssds_vectors(navsim, out):
     return dict(ssd=val)
 
 
+def import_run_experiment(ref_root):
+    """scripts/run_experiment.py imported as a module (its __main__ block does not run).  It needs, at import time only,
+    mpi4py and skimage.measure / skimage.filters.rank, which this container lacks: empty stand-in MODULES are registered
+    for the import statements (nothing of them is ever called by the functions recorded here -- sin_training_path,
+    chop_path_to_len, run_experiment and the two format tables are plain Python/NumPy), and the NumPy-2-removed
+    aliases its navsim.generate_landscapes import touches are already in place (import_reference)."""
+    import importlib.util
+    for m in ("mpi4py", "skimage.measure", "skimage.filters", "skimage.filters.rank"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["mpi4py"].MPI = types.SimpleNamespace()
+    sys.modules["skimage"].measure = sys.modules["skimage.measure"]
+    sys.modules["skimage"].filters = sys.modules["skimage.filters"]
+    sys.modules["skimage.filters"].rank = sys.modules["skimage.filters.rank"]
+    spec = importlib.util.spec_from_file_location("ref_run_experiment", os.path.join(ref_root, "scripts", "run_experiment.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def experiment_vectors(navsim, ref_root, out):
+    """T7: the experiment helpers of scripts/run_experiment.py -- sin_training_path (:95-105), chop_path_to_len
+    (:107-124), run_experiment (:235-258) and the CSV row of the farm (:44-71, :339-343)."""
+    rx = import_run_experiment(ref_root)
+    arrays = {}
+    paths = []
+    for k, (curve, start, length, arclen) in enumerate(((0.5, 180.0, 540.0, 1.0), (0.0, 40.0, 120.0, 0.35),
+                                                        (1.0, 400.0, 1200.0, 2.0), (0.25, 10.5, 77.25, 0.1))):
+        arrays["sin_%d" % k] = rx.sin_training_path(curve, start, length, arclen=arclen)
+        paths.append(dict(key="sin_%d" % k, curve=curve, start_x=start, l=length, arclen=arclen))
+    chops = []
+    for k, (src, frac) in enumerate((("sin_0", 0.5), ("sin_1", 0.999), ("sin_2", 0.123), ("sin_3", 1.0))):
+        p = arrays[src]
+        total = float(np.sum(np.linalg.norm(p[1:] - p[:-1], axis=1)))
+        arrays["chop_%d" % k] = rx.chop_path_to_len(p, frac * total)
+        chops.append(dict(key="chop_%d" % k, path=src, length=frac * total))
+    # one trial of the farm on the T4 landscape: the agent of traj_px, run by the reference's run_experiment
+    L, grain, lseed = 900, 4, 424242
+    land = synth.synth_landscape(lseed, L, grain)
+    tp = synth.sin_training_path(0.5, 0.2 * L, 0.6 * L, arclen=1.0)[:300]
+    rows = []
+    for name, cw, frames in (("row_default_frames", 0.25, None), ("row_40_frames", 0.0, 40)):
+        nsf = navsim.NavBySceneFamiliarity(land, (16, 8), 1.0, n_test_angles=10, sensor_pixel_dimensions=[2, 4],
+                                           n_sensor_levels=4, mask_middle_n=1, saccade_degrees=90.0,
+                                           max_distance_to_training_path=450,
+                                           familiarity_model=navsim.util.sads_familiarity(cw))
+        nsf.train_from_path(tp)
+        d = tp[2] - tp[1]
+        nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi)) + np.deg2rad(7.0)
+        nsf.position = tp[1] + np.array([1.5, -1.0])
+        res = rx.run_experiment(nsf, frames=frames)
+        trial = dict(landscape_class="synthetic", landscape_name="land_%d.png" % lseed, training_path_curve=0.5,
+                     landscape_noise_factor=0.0, n_chemicals=2, min_chem_grain_diameter=2.0, chem_weight=cw,
+                     sensor_dimensions=[16, 8, 2, 4], mask_middle_n=1, n_sensor_levels=4, step_size=1.0,
+                     saccade_degrees=90.0, n_test_angles=10, start_offset=[0.25, 7.0], landscape_flip_vertical=0,
+                     landscape_flip_horizontal=1)
+        variables = sorted(trial)
+        result_vars = sorted(rx.result_variables)
+        header = ", ".join(variables + result_vars)
+        line = ", ".join([rx.variable_formats[v].format(trial[v]) for v in variables]) + ", " + \
+               ", ".join([rx.result_variables[v].format(res[v]) for v in result_vars])
+        rows.append(dict(name=name, chem_weight=cw, frames=frames, trial=trial, header=header, line=line,
+                         result={k: (int(v) if isinstance(v, (int, np.integer)) else float(v)) for k, v in res.items()}))
+    np.savez_compressed(os.path.join(out, "t7_experiment.npz"), **arrays)
+    return dict(paths=paths, chops=chops, rows=rows, frame_factor=float(rx.FRAME_FACTOR),
+                n_consecutive_scenes=float(rx.N_CONSECUTIVE_SCENES),
+                landscape=dict(seed=lseed, size=L, grain=grain, sha=sha(land)), n_views=300)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=HERE)
+    ap.add_argument("--only", default=None, help="regenerate one fixture group only (e.g. t7_experiment) into the existing manifest")
     args = ap.parse_args()
     work = build_reference(args.reference)
     try:
         navsim = import_reference(work)
+        if args.only == "t7_experiment":
+            with open(os.path.join(args.out, "manifest.json")) as f:
+                manifest = json.load(f)
+            manifest["t7_experiment"] = experiment_vectors(navsim, args.reference, args.out)
+            with open(os.path.join(args.out, "manifest.json"), "w") as f:
+                json.dump(manifest, f, indent=1, sort_keys=True)
+            print("t7_experiment written to", args.out)
+            return
         manifest = dict(
             generator="tests/golden/make_golden.py",
             numpy=np.__version__,
@@ -325,6 +402,7 @@ def main():
             t4_trajectory=trajectory(navsim, args.out),
             t5_sensor=sensor_vectors(navsim, args.out),
             t6_ssds=ssds_vectors(navsim, args.out),
+            t7_experiment=experiment_vectors(navsim, args.reference, args.out),
         )
         with open(os.path.join(args.out, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)

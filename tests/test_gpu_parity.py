@@ -854,3 +854,31 @@ def test_ssd_f32_full_size_properties():
             finally:
                 eng.close()
         np.testing.assert_allclose(seen["0"], seen["2"], rtol=1e-6)
+
+
+def test_experiment_rows_match_the_reference_on_gpu(manifest, golden, tmp_path):
+    """One trial of the reference's farm through the product agent (everything on the GPU): the result row and the CSV
+    text the reference's run_experiment + row formatting produced (tests/golden manifest "t7_experiment")."""
+    from navsim_amd import experiment
+    t7 = manifest["t7_experiment"]
+    land = synth.synth_landscape(t7["landscape"]["seed"], t7["landscape"]["size"], t7["landscape"]["grain"])
+    size = t7["landscape"]["size"]
+    tp = synth.sin_training_path(0.5, 0.2 * size, 0.6 * size, arclen=1.0)[:t7["n_views"]]
+    done = []
+    for row in t7["rows"]:
+        nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 8), 1.0, n_test_angles=10, sensor_pixel_dimensions=[2, 4],
+                                               n_sensor_levels=4, mask_middle_n=1, saccade_degrees=90.0,
+                                               max_distance_to_training_path=450,
+                                               familiarity_model=navsim_amd.sads_familiarity(row["chem_weight"]))
+        nsf.train_from_path(tp)
+        d = tp[2] - tp[1]
+        nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi)) + np.deg2rad(7.0)
+        nsf.position = tp[1] + np.array([1.5, -1.0])
+        res = experiment.run_experiment(nsf, frames=row["frames"])
+        assert experiment.csv_row(row["trial"], res) == row["line"], row["name"]
+        assert res["stop_status"] == row["result"]["stop_status"] and float(res["rmsd_error"]) == row["result"]["rmsd_error"]
+        done.append((row["trial"], res))
+        nsf._engine.close()
+    out = tmp_path / "task-0.csv"
+    experiment.write_task_csv(str(out), done)
+    assert out.read_text().splitlines() == [t7["rows"][0]["header"]] + [r["line"] for r in t7["rows"]]

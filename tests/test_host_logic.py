@@ -237,3 +237,36 @@ def test_bit_plane_decomposition_is_exact():
     # too many planes for the cap: refused, the byte-plane kernels keep such a library
     presence = (ctypes.c_uint32 * 8)(*([0xffffffff] * 8))
     assert lib.dv_bitplane_plan(presence, 16, lo, w, ctypes.byref(lmin), ctypes.byref(lmax)) == -1
+
+
+def test_experiment_helpers_match_the_reference(manifest, golden):
+    """scripts/run_experiment.py's helpers, pinned by the reference's own outputs (tests/golden/make_golden.py imports
+    the script; t7_experiment.npz): training-path generator and path chopping bit for bit, the result row of
+    run_experiment, and the CSV header / row text of the farm's task files."""
+    from navsim_amd import experiment
+    z = golden("t7_experiment.npz")
+    t7 = manifest["t7_experiment"]
+    assert (experiment.FRAME_FACTOR, experiment.N_CONSECUTIVE_SCENES) == (t7["frame_factor"], t7["n_consecutive_scenes"])
+    for c in t7["paths"]:
+        got = experiment.sin_training_path(c["curve"], c["start_x"], c["l"], arclen=c["arclen"])
+        assert got.tobytes() == z[c["key"]].tobytes() and got.shape == z[c["key"]].shape, c["key"]
+    for c in t7["chops"]:
+        got = experiment.chop_path_to_len(z[c["path"]], c["length"])
+        assert got.tobytes() == z[c["key"]].tobytes() and got.shape == z[c["key"]].shape, c["key"]
+    land = synth.synth_landscape(t7["landscape"]["seed"], t7["landscape"]["size"], t7["landscape"]["grain"])
+    assert sha(land) == t7["landscape"]["sha"]
+    size = t7["landscape"]["size"]
+    tp = synth.sin_training_path(0.5, 0.2 * size, 0.6 * size, arclen=1.0)[:t7["n_views"]]
+    for row in t7["rows"]:
+        nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 8), 1.0, n_test_angles=10, sensor_pixel_dimensions=[2, 4],
+                                               n_sensor_levels=4, mask_middle_n=1, saccade_degrees=90.0,
+                                               max_distance_to_training_path=450,
+                                               familiarity_model=oracle.sads_familiarity(row["chem_weight"]))
+        nsf.train_from_path(tp)
+        d = tp[2] - tp[1]
+        nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi)) + np.deg2rad(7.0)
+        nsf.position = tp[1] + np.array([1.5, -1.0])
+        res = experiment.run_experiment(nsf, frames=row["frames"])
+        assert {k: (int(v) if isinstance(v, (int, np.integer)) else float(v)) for k, v in res.items()} == row["result"], row["name"]
+        assert experiment.csv_header(row["trial"]) == row["header"]
+        assert experiment.csv_row(row["trial"], res) == row["line"], row["name"]
