@@ -120,6 +120,13 @@ int dv_set_exact(dv_ctx *ctx, int exact);
  */
 int dv_set_library(dv_ctx *ctx, const uint8_t *views, int64_t n_views, int h, int w,
                    int channels, double chem_weight, int64_t first_view);
+/*
+ * Append n more views (uint8[n,h,w,3], same shape and chem_weight) to the resident library: a further training path
+ * (scripts/run_experiment.py:23-26 anticipates several per library).  Existing views keep their device tiles, only the
+ * new view groups are re-tiled; kernel forms timed on the library stay chosen.  The device layout was fixed by the
+ * first ingest's hue set and saturation range: views outside it are refused with DV_ERR_STATE (re-ingest everything).
+ */
+int dv_append_library(dv_ctx *ctx, const uint8_t *views, int64_t n_views, int channels);
 /* Same library as navsim_amd.synth.synth_views(seed, n_views, h, w, first_view), generated on the GPU. */
 int dv_generate_library(dv_ctx *ctx, uint64_t seed, int64_t n_views, int h, int w,
                         double chem_weight, int64_t first_view);
@@ -166,6 +173,10 @@ int dv_sense_step_batch(dv_ctx *ctx, const double *x, const double *y, const dou
  * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */
 int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,
                               double chem_weight, int64_t first_view, uint8_t *out_views);
+
+/* dv_append_library with the views sensed on the device at n more poses (out_views may be NULL). */
+int dv_append_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,
+                                 uint8_t *out_views);
 
 /* ---- error / coverage metrics (NavBySceneFamiliarity.py:252-276) -------- */
 /*

@@ -669,6 +669,109 @@ static int ingest_raw(dv_ctx* c, const unsigned char* d_raw, int64_t F, int h, i
     return DV_OK;
 }
 
+static int enqueue_sense(dv_ctx* c, const double* x, const double* y, const double* angle, long long n, unsigned char* d_out);
+static int check_sense_error(dv_ctx* c);
+static int ensure_sense_buffer(dv_ctx* c, size_t bytes);
+
+// Appends n raw views (device buffer uint8[n][h*w][3]) to the resident library: the byte tiles of the existing views
+// are copied as they are, only the new view groups are re-tiled; the per-step buffers are re-sized; the workgroup
+// shapes timed on the old library are kept.  The device layout was chosen from the first ingest's hue set and
+// saturation range: views that do not fit it cannot be appended (DV_ERR_STATE; re-ingest the whole library).
+static int append_raw(dv_ctx* c, const unsigned char* d_raw, int64_t n) {
+    const LibCfg old = c->cfg;
+    if (old.cw > 0.0 && !old.generic) {
+        unsigned bitmap[9] = {0};
+        unsigned* d_bitmap = nullptr;
+        hipError_t e = hipMalloc(&d_bitmap, sizeof bitmap);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bitmap, 0, sizeof bitmap, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_hue_scan, dim3(256), dim3(256), 0, c->stream, d_raw, (long long)n * old.P, d_bitmap);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(bitmap, d_bitmap, sizeof bitmap, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (d_bitmap) (void)hipFree(d_bitmap);
+        if (e != hipSuccess) return fail(c, DV_ERR_HIP, "hue scan: %s", hipGetErrorString(e));
+        const int nk = old.signed_s ? 2 : old.nhs;
+        for (int v = 0; v < 256; ++v) {
+            if (!(bitmap[v >> 5] & (1u << (v & 31)))) continue;
+            bool known = false;
+            for (int k = 0; k < nk; ++k) known |= (old.hues[k] == v);
+            if (!known) return fail(c, DV_ERR_STATE, "appended views contain hue %d, which the resident layout has no plane for: "
+                                    "re-ingest the whole library", v);
+        }
+        if (old.signed_s && bitmap[8] > 127)
+            return fail(c, DV_ERR_STATE, "appended views contain saturation %u > 127, which the resident signed-saturation plane "
+                        "cannot hold: re-ingest the whole library", bitmap[8]);
+    }
+    uint4* old_tiles = c->d_tiles;
+    const size_t old_bytes = (size_t)(old.Fpad / 64) * old.gstride * sizeof(uint4);
+    c->d_tiles = nullptr;                                  // survives the re-allocation below
+    int tuned[4];
+    for (int i = 0; i < 4; ++i) tuned[i] = c->tuned_shape[i];
+    const int nk = old.signed_s ? 2 : old.nhs;
+    int rc = alloc_library(c, old.F + n, c->h, c->w, old.cw, old.first, (old.cw > 0.0 && !old.generic) ? nk : 0, old.hues,
+                           old.generic, old.signed_s ? 127 : 255);
+    if (rc) { (void)hipFree(old_tiles); free_library(c); return rc; }
+    for (int i = 0; i < 4; ++i) c->tuned_shape[i] = tuned[i];
+    const LibCfg& g = c->cfg;
+    if (g.npl != old.npl || g.gstride != old.gstride || g.signed_s != old.signed_s || g.nhs != old.nhs) {
+        (void)hipFree(old_tiles);
+        free_library(c);
+        return fail(c, DV_ERR_STATE, "internal: the grown library chose another layout");
+    }
+    hipError_t e = hipMemcpyAsync(c->d_tiles, old_tiles, old_bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) {
+        const long long total = (g.Fpad / 64 - old.F / 64) * (long long)g.npl * g.Q * 64;
+        hipLaunchKernelGGL(k_retile_append, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_tiles, c->cfg,
+                           (long long)old.F);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(old_tiles);
+    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "append: %s", hipGetErrorString(e)); }
+    rc = build_bit_planes(c);
+    if (rc) { free_library(c); return rc; }
+    return DV_OK;
+}
+
+extern "C" int dv_append_library(dv_ctx* c, const uint8_t* views, int64_t n, int channels) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib || c->metric != 0) return fail(c, DV_ERR_STATE, "no sads_hsv library to append to (call dv_set_library first)");
+    if (!views || n < 1) return fail(c, DV_ERR_INVALID, "dv_append_library: views is NULL or n < 1");
+    if (channels != 3) return fail(c, DV_ERR_INVALID, "views must have 3 channels (H,S,V), got %d", channels);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t raw_bytes = (size_t)n * c->cfg.P * 3;
+    unsigned char* d_raw = nullptr;
+    HIP_TRY(c, hipMalloc(&d_raw, raw_bytes));
+    int rc = DV_OK;
+    if (hipMemcpyAsync(d_raw, views, raw_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(c, DV_ERR_HIP, "upload: %s", hipGetErrorString(hipGetLastError()));
+    if (rc == DV_OK) rc = append_raw(c, d_raw, n);
+    (void)hipFree(d_raw);
+    return rc;
+}
+
+extern "C" int dv_append_library_from_poses(dv_ctx* c, const double* x, const double* y, const double* angle, int64_t n,
+                                            uint8_t* out_views) {
+    if (!c || !x || !y || !angle || n < 1) return DV_ERR_INVALID;
+    if (!c->have_lib || c->metric != 0) return fail(c, DV_ERR_STATE, "no sads_hsv library to append to");
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    if (c->sensor.sw != c->w || c->sensor.sh != c->h) return fail(c, DV_ERR_STATE, "sensor and library shapes differ");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = (size_t)n * c->sensor.sh * c->sensor.sw * 3;
+    int rc = ensure_sense_buffer(c, bytes);
+    if (rc) return rc;
+    rc = enqueue_sense(c, x, y, angle, n, c->d_sense);
+    if (rc) return rc;
+    if (out_views) HIP_TRY(c, hipMemcpyAsync(out_views, c->d_sense, bytes, hipMemcpyDeviceToHost, c->stream));
+    rc = check_sense_error(c);
+    if (rc) return rc;
+    return append_raw(c, c->d_sense, n);
+}
+
 extern "C" int dv_set_library(dv_ctx* c, const uint8_t* views, int64_t F, int h, int w, int channels,
                               double cw, int64_t first) {
     int rc = check_lib_args(c, F, h, w, cw);

@@ -186,6 +186,34 @@ __global__ void k_retile(const unsigned char* __restrict__ raw, uint4* __restric
     tiles[g * c.gstride + ((long long)pl * c.Q + q) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Appended views: raw uint8[n][P][3] holds local views [f0, f0 + n) of the grown library.  One thread per 16-byte chunk
+// of the view groups from f0 / 64 on; entries of views below f0 (already in place) are left alone.
+__global__ void k_retile_append(const unsigned char* __restrict__ raw, uint4* __restrict__ tiles, LibCfg c, long long f0) {
+    const long long g0 = f0 / 64;
+    const long long total = (c.Fpad / 64 - g0) * (long long)c.npl * c.Q * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    long long r = t >> 6;
+    const int q = (int)(r % c.Q); r /= c.Q;
+    const int pl = (int)(r % c.npl);
+    const long long g = g0 + r / c.npl;
+    const long long f = g * 64 + lane;
+    if (f < f0) return;
+    unsigned w[4] = {0, 0, 0, 0};
+    if (f < c.F) {
+        const unsigned char* v = raw + (f - f0) * (long long)c.P * 3;
+        for (int i = 0; i < 16; ++i) {
+            const int px = q * 16 + i;
+            if (px < c.P) {
+                const unsigned b = plane_byte(c, pl, v[px * 3 + 0], v[px * 3 + 1], v[px * 3 + 2]);
+                w[i >> 2] |= b << (8 * (i & 3));
+            }
+        }
+    }
+    tiles[g * c.gstride + ((long long)pl * c.Q + q) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // Synthetic library straight into tiles: view f, pixel p <- splitmix64((first+f)*P + p + seed*GOLDEN).
 __global__ void k_generate_tiles(uint4* __restrict__ tiles, LibCfg c, unsigned long long seed) {
     const long long total = (c.Fpad / 64) * (long long)c.npl * c.Q * 64;

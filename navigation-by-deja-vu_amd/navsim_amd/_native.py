@@ -98,6 +98,8 @@ PROTOTYPES = {
                                       ctypes.c_double, ctypes.c_int64]),
     "dv_generate_library": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_int64]),
+    "dv_append_library": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64, ctypes.c_int]),
+    "dv_append_library_from_poses": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int64, _u8p]),
     "dv_clear_library": (ctypes.c_int, [_ctx_p]),
     "dv_get_library_info": (ctypes.c_int, [_ctx_p, ctypes.POINTER(LibInfo)]),
     "dv_read_planes": (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, _u8p]),

@@ -246,6 +246,39 @@ class NavBySceneFamiliarity(object):
         else:
             self._familiarity_func = self.familiarity_model(self.familiar_scenes)
 
+    def train_additional_path(self, points):
+        """A further training path behind the first (the reference's experiment script anticipates several per
+        library, scripts/run_experiment.py:23-26, but its class has no call for it): the new points' views are appended
+        to the library -- on the device only the new view groups are re-tiled -- and the path, its length and the
+        coverage marks grow with them.  Views are taken as in train_from_path (:124-132): each point looks towards the
+        next one of ITS path, the last reuses the last heading."""
+        if self.training_path is None:
+            raise ValueError("train_from_path first")
+        points = np.asarray(points, dtype=np.float64)
+        n = len(points)
+        steps = points[1:] - points[:-1]
+        headings = np.arctan2(steps[:, 1], steps[:, 0])
+        view_headings = headings[np.minimum(np.arange(n), n - 2)]
+        engine = getattr(self._familiarity_func, "engine", None)
+        if self._engine is not None and engine is self._engine:
+            for pt in points:
+                self._check_bounds(pt)
+            new_views = self._engine.append_library_from_poses(points[:, 0], points[:, 1], view_headings)
+        else:
+            new_views = np.stack([self.get_sensor_mat(points[i], view_headings[i]) for i in range(n)])
+            if engine is not None and hasattr(engine, "append_library"):
+                engine.append_library(new_views)
+        self.familiar_scenes = np.concatenate([self.familiar_scenes, new_views])
+        if engine is None or not hasattr(engine, "append_library"):
+            self._familiarity_func = self.familiarity_model(self.familiar_scenes)     # any other plug-in: hand it all views again
+        self.training_path_length = self.training_path_length + np.sum(np.linalg.norm(steps, axis=1))
+        self.training_path = np.concatenate([self.training_path, points])
+        self.scene_familiarity = np.zeros(len(self.training_path), dtype=np.float64)
+        self._scene_is_inf = False
+        if self._metrics_on_device:
+            self._engine.set_training_path(self.training_path)
+        self.reset_error()
+
     def clear_training(self):
         func = getattr(self, "_familiarity_func", None)
         if func is not None and hasattr(func, "engine"):

@@ -74,6 +74,25 @@ class FamiliarityEngine(object):
                                                   float(chem_weight), int(first_view)), "dv_generate_library")
         self.n_views, self.shape = int(n_views), (int(h), int(w))
 
+    def append_library(self, scenes):
+        """More views (uint8[n,h,w,3]) behind the resident ones; only the new view groups are re-tiled.  Raises
+        EngineError (DV_ERR_STATE) when they do not fit the resident layout (a new hue, S > 127 on a signed plane)."""
+        scenes = N.as_u8(scenes, "familiar_scenes")
+        if scenes.ndim != 4 or scenes.shape[1:3] != tuple(self.shape):
+            raise ValueError("appended views must be uint8[n,%d,%d,3], got shape %r" % (self.shape + (scenes.shape,)))
+        self._check(self._lib.dv_append_library(self._ctx, N.u8ptr(scenes), scenes.shape[0], scenes.shape[3]), "dv_append_library")
+        self.n_views += scenes.shape[0]
+
+    def append_library_from_poses(self, x, y, angle, want_views=True):
+        """dv_append_library with the views sensed on the device; returns them (uint8[n,h,w,3]) when want_views."""
+        x, y, angle = self._pose_arrays(x, y, angle)
+        h, w = self.sensor_shape
+        out = np.empty((len(x), h, w, 3), dtype=np.uint8) if want_views else None
+        self._check_sense(self._lib.dv_append_library_from_poses(self._ctx, N.f64ptr(x), N.f64ptr(y), N.f64ptr(angle), len(x),
+                                                                 N.u8ptr(out) if want_views else None), "dv_append_library_from_poses")
+        self.n_views += len(x)
+        return out
+
     def clear_library(self):
         self._check(self._lib.dv_clear_library(self._ctx), "dv_clear_library")
         self.n_views, self.shape = 0, None

@@ -882,3 +882,63 @@ def test_experiment_rows_match_the_reference_on_gpu(manifest, golden, tmp_path):
     out = tmp_path / "task-0.csv"
     experiment.write_task_csv(str(out), done)
     assert out.read_text().splitlines() == [t7["rows"][0]["header"]] + [r["line"] for r in t7["rows"]]
+
+
+@pytest.mark.parametrize("cw", [0.0, 0.25])
+def test_appended_library_equals_one_ingest(eng, cw):
+    """dv_append_library: views appended behind a resident library (only the new view groups are re-tiled, also when
+    the old library ends inside a group) give the stored planes and the decisions of one ingest of all of them; views
+    the resident layout cannot hold are refused."""
+    F0, F1, h, w, A = 700, 1011, 12, 10, 9
+    lib = synth.synth_views(41, F1, h, w)
+    pats = synth.synth_patches(41, A, h, w)
+    pats[4] = synth.near_match_patch(lib[903], 2)             # best view among the appended ones
+    eng.set_library(lib, cw)
+    want_planes = eng.read_planes(0, F1)
+    want = eng.step(pats, want_scene=True)
+    eng.set_library(lib[:F0], cw)
+    eng.step(pats, want_scene=False)                          # (times the kernel forms on the old library)
+    eng.append_library(lib[F0:900])
+    eng.append_library(lib[900:])
+    info = eng.library_info()
+    assert info["n_views"] == F1
+    assert np.array_equal(eng.read_planes(0, F1), want_planes)
+    got = eng.step(pats, want_scene=True)
+    assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]) == (4, 903)
+    assert np.array_equal(got["angle_familiarity"], want["angle_familiarity"])
+    assert np.array_equal(got["scene_familiarity"], want["scene_familiarity"])
+    ref = oracle.step(lib, pats, cw)
+    assert (got["best_idex"], got["best_view"]) == (ref["best_idex"], ref["best_view"])
+    if cw > 0:
+        odd = lib[:3].copy()
+        odd[..., 0] = 33                                       # a hue the resident layout has no plane for
+        odd[..., 1] = 50
+        with pytest.raises(navsim_amd.EngineError):
+            eng.append_library(odd)
+        assert eng.library_info()["n_views"] == F1             # refused before anything changed
+
+
+def test_agent_trains_on_a_second_path():
+    """train_additional_path: the library, the path and the metrics grow; the agent with everything on the GPU (views
+    of the second path sensed and appended on the device) walks exactly like the host agent over the oracle, and covers
+    points of the second path."""
+    land = synth.synth_landscape(11, 420, 4)
+    p1 = synth.sin_training_path(0.5, 0.2 * 420, 0.6 * 420, arclen=1.0)[:150]
+    p2 = np.stack([np.linspace(120, 300, 181), np.full(181, 90.0)], axis=1)
+    host = navsim_amd.NavBySceneFamiliarity(land, (16, 12), 1.0, n_test_angles=7, use_gpu_sensor=False,
+                                            familiarity_model=oracle.sads_familiarity(0.25))
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 12), 1.0, n_test_angles=7, track_scene_familiarity=False,
+                                           familiarity_model=navsim_amd.sads_familiarity(0.25))
+    for a in (host, nsf):
+        a.train_from_path(p1)
+        a.train_additional_path(p2)
+        a.position, a.angle = (p2[5][0] + 0.5, p2[5][1] - 0.5), 0.05
+    assert np.array_equal(nsf.familiar_scenes, host.familiar_scenes) and len(nsf.training_path) == 331
+    assert nsf.training_path_length == host.training_path_length
+    for _ in range(60):
+        host.step_forward()
+        nsf.step_forward()
+        assert nsf.last_best_idex == host.last_best_idex and nsf.position == host.position
+    assert float(nsf.navigation_error) == float(host.navigation_error)
+    assert np.array_equal(nsf._coverage_array, host._coverage_array) and nsf._coverage_array[150:].any()
+    nsf._engine.close()
