@@ -319,6 +319,14 @@ int dv_workgroup_shape(dv_ctx *ctx, int n_headings, int *shape);
 /* Streaming-read microbenchmark over n_bytes of device memory (achievable HBM ceiling). */
 int dv_stream_read_gbps(dv_ctx *ctx, int64_t n_bytes, int iters, double *gbps);
 
+/*
+ * roctx ranges (rocprofv3 --marker-trace): with DEJAVU_ROCTX=1 in the environment the library brackets the phases of a
+ * step ("dv:sense", "dv:score", "dv:finish", "dv:wait") and callers can add their own (navsim_amd/sharded.py wraps the
+ * per-step exchange in "dv:exchange").  No-ops otherwise; libroctx64.so is looked up at run time.
+ */
+int dv_range_push(const char *name);
+int dv_range_pop(void);
+
 const char *dv_version(void);
 
 #ifdef __cplusplus

@@ -30,6 +30,52 @@ static_assert(sizeof(StepResultDev) == sizeof(dv_step_result) + sizeof(unsigned 
 static_assert(kMaxHeadings == DV_MAX_HEADINGS && kMaxHues == DV_MAX_HUE_PLANES, "header constants differ");
 static_assert(kResSenseError == DV_RES_SENSE_ERROR, "header constants differ");
 
+#include "dejavu_host.inl"      // dv_merge_records, dv_merge_keys, dv_bitplane_plan: host arithmetic, no HIP
+
+#include <dlfcn.h>
+
+// roctx ranges around the phases of a step (sense / score / finish / wait; the Python exchange brackets its collective
+// through dv_range_push / dv_range_pop), visible in rocprofv3 --marker-trace.  libroctx64.so is looked up at run time and
+// only when DEJAVU_ROCTX=1 (librocprofiler-sdk-roctx.so, else libroctx64.so): no link-time dependency on the tracer and the ranges cost one predictable
+// branch otherwise.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("DEJAVU_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        // rocprofv3 (rocprofiler-sdk) records the ranges of its own roctx library; the older roctracer one is the fallback
+        void* h = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so",
+                                 "/opt/rocm/lib/libroctx64.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+};
+}  // namespace
+
+extern "C" int dv_range_push(const char* name) {
+    if (!name) return DV_ERR_INVALID;
+    if (roctx().push) roctx().push(name);
+    return DV_OK;
+}
+extern "C" int dv_range_pop(void) {
+    if (roctx().pop) roctx().pop();
+    return DV_OK;
+}
+
 static thread_local std::string g_create_error;
 
 struct dv_ctx {
@@ -59,6 +105,7 @@ struct dv_ctx {
     unsigned long long* d_bsum = nullptr;     // k_finish: per-block, per-heading (maximum, first view) [blocks][2][headings]
     unsigned long long* d_ctmp = nullptr;     // k_finish: shared extra-candidate list [agents][kTmpCap][2]
     int int_has_hs = 0, int_has_v = 0;        // which sums the last integer scoring pass produced
+    int fenced_env = -1;                      // DEJAVU_FENCED: 1 release/acquire around the arrival ticket always, 0 never; default by path
     int finish_fused = 1;                     // DEJAVU_FINISH: integer-path steps end in k_finish where it pays (0: never, 2: whenever possible)
     unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
     unsigned long long* d_pmax = nullptr;     // [64][max(G, Fpad/256)] partial maxima
@@ -213,6 +260,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_MFMA_CHUNK", c->mfma_chunk_env, 0, 32);
     env_int("DEJAVU_MFMA_VARIANT", c->mfma_variant_env, 0, 1);
     env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
+    env_int("DEJAVU_FENCED", c->fenced_env, 0, 1);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -358,80 +406,6 @@ extern "C" int dv_publish_wait(dv_ctx* c, double* dst, int64_t n) {
     return DV_OK;
 }
 
-// Host arithmetic of the sharded decision; mirrors navsim_amd/sharded.py (needs_resolve + merge_records), which the
-// CPU tests compare it with on random records.
-extern "C" int dv_merge_records(const double* rec, int world, int A, int64_t stride, double delta, dv_merge_out* out) {
-    if (!rec || !out || world < 1 || world > 64 || A < 1 || A > kMaxHeadings || stride < 3 + 4 * (int64_t)A) return DV_ERR_INVALID;
-    memset(out, 0, sizeof(*out));
-    // state word: 0..2, + 4 when that rank's patches were sensed past the end of the landscape
-    for (int r = 0; r < world; ++r)
-        if (rec[(int64_t)r * stride + 2] >= 4.0) return DV_ERR_INDEX;
-    auto R = [&](int r, int64_t i) { return rec[(int64_t)r * stride + i]; };
-    double gmax = R(0, 0);
-    for (int r = 1; r < world; ++r) if (R(r, 0) > gmax) gmax = R(r, 0);
-    long long total = 0;
-    bool unresolved = false;
-    for (int r = 0; r < world; ++r) {
-        if (R(r, 0) >= gmax - delta) {
-            out->contending_mask |= 1ull << r;
-            out->n_contending++;
-            total += (long long)R(r, 1);
-            if (R(r, 2) == 0.0) unresolved = true;
-        }
-    }
-    // per-heading maxima of the integer-sum scores over ALL ranks, first rank on ties
-    int owner[kMaxHeadings];
-    for (int a = 0; a < A; ++a) {
-        double m = R(0, 3 + a);
-        int o = 0;
-        for (int r = 1; r < world; ++r) if (R(r, 3 + a) > m) { m = R(r, 3 + a); o = r; }
-        out->angle_fam[a] = m;
-        owner[a] = o;
-    }
-    if (total > 1 && unresolved) {
-        out->needs_resolve = 1;
-        return DV_OK;
-    }
-    if (total <= 1) {
-        int best = 0;
-        for (int a = 1; a < A; ++a) if (out->angle_fam[a] > out->angle_fam[best]) best = a;     // first maximum
-        out->best_heading = best;
-        out->best_view = (int64_t)R(owner[best], 3 + A + best);
-        out->best_fam = out->angle_fam[best];
-        return DV_OK;
-    }
-    const double ninf = -std::numeric_limits<double>::infinity();
-    double ex_a[kMaxHeadings];
-    for (int a = 0; a < A; ++a) {
-        double m = ninf;
-        for (int r = 0; r < world; ++r) {
-            if (!((out->contending_mask >> r) & 1)) continue;
-            const double v = (R(r, 2) == 2.0) ? R(r, 3 + a) : R(r, 3 + 2 * A + a);
-            if (v > m) m = v;
-        }
-        ex_a[a] = m;
-    }
-    int best = 0;
-    for (int a = 1; a < A; ++a) if (ex_a[a] > ex_a[best]) best = a;                               // first maximum
-    int64_t best_view = -1;
-    bool have = false;
-    for (int r = 0; r < world; ++r) {
-        if (!((out->contending_mask >> r) & 1)) continue;
-        const bool all_exact = R(r, 2) == 2.0;
-        const double v = all_exact ? R(r, 3 + best) : R(r, 3 + 2 * A + best);
-        if (v == ex_a[best]) {
-            const int64_t f = (int64_t)(all_exact ? R(r, 3 + A + best) : R(r, 3 + 3 * A + best));
-            if (!have || f < best_view) { best_view = f; have = true; }
-        }
-    }
-    for (int a = 0; a < A; ++a) if (std::isfinite(ex_a[a])) out->angle_fam[a] = ex_a[a];
-    out->best_heading = best;
-    out->best_view = best_view;
-    out->best_fam = ex_a[best];
-    out->resolved = 1;
-    return DV_OK;
-}
-
 extern "C" int dv_synchronize(dv_ctx* c) {
     if (!c) return DV_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -448,37 +422,6 @@ static long long group_stride(const dv_ctx* c, long long kb) {
 }
 
 // ------------------------------------------------------------------ bit planes (MFMA scoring path)
-// Thermometer planes of one byte plane from the 256-bit presence map of its values: one plane per gap between
-// consecutive levels, gaps wider than 127 split so that every coefficient w - 2*alpha fits an int8.
-// Returns the number of planes (0 for a single level), or -1 when there are more than `cap`.
-static int plan_byte_plane(const uint32_t presence[8], int cap, uint8_t* lo, uint8_t* w, int* lmin, int* lmax) {
-    int levels[256], n = 0;
-    for (int v = 0; v < 256; ++v)
-        if (presence[v >> 5] & (1u << (v & 31))) levels[n++] = v;
-    if (n == 0) { levels[n++] = 0; }                    // nothing stored (cannot happen with F >= 1): one level, 0
-    *lmin = levels[0];
-    *lmax = levels[n - 1];
-    int t = 0;
-    for (int i = 0; i + 1 < n; ++i) {
-        int a = levels[i];
-        const int b = levels[i + 1];
-        while (a < b) {
-            const int step = (b - a) > 127 ? 127 : (b - a);
-            if (t >= cap) return -1;
-            lo[t] = (uint8_t)a;
-            w[t] = (uint8_t)step;
-            ++t;
-            a += step;
-        }
-    }
-    return t;
-}
-
-extern "C" int dv_bitplane_plan(const uint32_t* presence, int cap, uint8_t* lo, uint8_t* w, int* lmin, int* lmax) {
-    if (!presence || !lo || !w || !lmin || !lmax || cap < 0 || cap > 255) return DV_ERR_INVALID;
-    return plan_byte_plane(presence, cap, lo, w, lmin, lmax);
-}
-
 // Builds the bit-plane copy of the resident byte tiles when the library's values allow it.  Never fails the ingest:
 // a library that does not qualify simply keeps the byte path.
 static int build_bit_planes(dv_ctx* c) {
@@ -974,6 +917,7 @@ extern "C" int dv_sense(dv_ctx* c, const double* x, const double* y, const doubl
 // Senses the patches of A_total headings (poses by value) straight into the scoring kernel's operand layout: ONE
 // kernel, no copy and no memset on the way (see k_sense_prep).  n_agents agents of A_agent headings each.
 static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int A_agent) {
+    Range range("dv:sense");
     const int A = n_agents * A_agent;
     c->A = A; c->n_agents = n_agents; c->A_agent = A_agent;
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
@@ -1516,6 +1460,7 @@ static int tune_workgroup_shape(dv_ctx* c) {
 
 // Scoring: integer-sum kernel + combine (or the exact fp64 kernel), then amax[a] without atomics.
 static int launch_scoring(dv_ctx* c, bool with_combine = true) {
+    Range range("dv:score");
     const LibCfg& g = c->cfg;
     int rc = DV_OK;
     if (c->metric == 0 && !c->exact && !g.generic && c->shape_env == 0 && c->tuned_shape[apad_class(c->APAD)] == 0) {
@@ -1594,6 +1539,13 @@ static int launch_scoring(dv_ctx* c, bool with_combine = true) {
     return DV_OK;
 }
 
+// The arrival ticket of k_finish / k_tail without fences saves ~1.5 us of a ~100 us single-agent step; everywhere else
+// (exact scores, ssd_f32, batched passes) the release / acquire pair of the memory model is kept.
+static int step_fenced(const dv_ctx* c) {
+    if (c->fenced_env >= 0) return c->fenced_env;
+    return (c->exact || c->metric == 1 || c->n_agents > 1) ? 1 : 0;
+}
+
 // One step on the resident patches: scoring (2 launches) + k_tail.  The result record lands in mapped host memory.
 template <int NT>
 static void launch_finish(dv_ctx* c, int want_scene, int force) {
@@ -1602,7 +1554,7 @@ static void launch_finish(dv_ctx* c, int want_scene, int force) {
                        c->d_part, c->int_hsconst, c->int_vconst, c->nchunk, c->APAD, c->int_has_hs, c->int_has_v, c->d_state, c->d_bsum, c->d_ctmp,
                        c->d_cand, c->d_scene, c->d_result + c->result_slot,
                        c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta, want_scene, force,
-                       ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr);
+                       ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr, step_fenced(c));
 }
 
 static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
@@ -1618,6 +1570,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
                        (c->finish_fused == 2 || (c->finish_fused == 1 && c->A_agent <= 16 && g.F >= 32768));
     int rc = launch_scoring(c, !fused);
     if (rc) return rc;
+    Range range("dv:finish");
     if (fused) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
         else launch_finish<2>(c, scene_on, force);
@@ -1626,7 +1579,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
                            c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result + c->result_slot,
                            c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,
                            c->A_agent, c->delta, scene_on, c->exact, force, ++c->seq,
-                           c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->metric == 1 ? 3e-6 : 0.0);
+                           c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->metric == 1 ? 3e-6 : 0.0, step_fenced(c));
     }
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
@@ -1695,6 +1648,7 @@ static bool spin_for_records(dv_ctx* c, int slot, int n, int A, int seq) {
 static bool spin_for_results(dv_ctx* c) { return spin_for_records(c, 0, c->n_agents, c->A_agent, c->seq); }
 
 static int finish_pass(dv_ctx* c) {
+    Range range("dv:wait");
     if (!c->step_pending) return fail(c, DV_ERR_STATE, "no step enqueued");
     if (!(c->spin_wait && !c->last_want_scene && spin_for_results(c)))
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1813,46 +1767,6 @@ extern "C" int dv_step_keys(dv_ctx* c, int rank, int world, int signed_order, vo
     HIP_TRY(c, hipGetLastError());
     *device_ptr = c->d_keys;
     *n_words = c->A + kKeyWordsPerRank * world;
-    return DV_OK;
-}
-
-// Host arithmetic of the key exchange; mirrors navsim_amd/sharded.py:merge_keys (the CPU tests compare the two).
-extern "C" int dv_merge_keys(const uint64_t* keys, int world, int A, double delta, int signed_order, dv_merge_out* out) {
-    if (!keys || !out || world < 1 || world > 64 || A < 1 || A > kMaxHeadings) return DV_ERR_INVALID;
-    memset(out, 0, sizeof(*out));
-    const uint64_t top = signed_order ? 0x8000000000000000ull : 0ull;
-    auto K = [&](int i) { return keys[i] ^ top; };
-    auto to_double = [](uint64_t k) {
-        const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-        double d;
-        memcpy(&d, &b, sizeof d);
-        return d;
-    };
-    double approx[64];
-    double gmax = 0.0;
-    int winner = -1;
-    for (int r = 0; r < world; ++r) {
-        const uint64_t w1 = K(A + kKeyWordsPerRank * r + 1);
-        if (!(w1 >> 48)) return fail(nullptr, DV_ERR_STATE, "dv_merge_keys: rank %d contributed no slot", r);
-        if (((w1 >> 32) & 0xff) >= 4) return DV_ERR_INDEX;               // that rank sensed past the end of the landscape
-        approx[r] = to_double(K(A + kKeyWordsPerRank * r));
-        if (winner < 0 || approx[r] > gmax) { gmax = approx[r]; winner = r; }
-    }
-    long long total = 0;
-    for (int r = 0; r < world; ++r) {
-        if (approx[r] >= gmax - delta) {
-            out->contending_mask |= 1ull << r;
-            out->n_contending++;
-            total += (long long)(K(A + kKeyWordsPerRank * r + 1) & 0xffffffffull);
-        }
-    }
-    for (int a = 0; a < A; ++a) out->angle_fam[a] = to_double(K(a));
-    if (total > 1) { out->needs_resolve = 1; return DV_OK; }            // near-ties: the full records decide
-    const int best = (int)K(A + kKeyWordsPerRank * winner + 2) - 1;
-    if (best < 0 || best >= A) return fail(nullptr, DV_ERR_STATE, "dv_merge_keys: heading %d out of range", best);
-    out->best_heading = best;
-    out->best_view = (int64_t)K(A + kKeyWordsPerRank * winner + 3) - 1;
-    out->best_fam = out->angle_fam[best];
     return DV_OK;
 }
 

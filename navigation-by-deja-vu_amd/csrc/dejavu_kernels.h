@@ -994,7 +994,7 @@ __global__ void __launch_bounds__(256)
 k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial,
        StepState* __restrict__ st, unsigned long long* __restrict__ cand, double* __restrict__ scene,
        StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene,
-       int exact_all, int force, int seq, const unsigned long long* __restrict__ sense_err, double delta_rel) {
+       int exact_all, int force, int seq, const unsigned long long* __restrict__ sense_err, double delta_rel, int fenced) {
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ int s_last;
     const int agent = blockIdx.y;
@@ -1067,9 +1067,16 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     // the kernel boundary.  So no release fence here and no acquire in the last block: on this multi-XCD part they
     // are an L2 write-back / invalidate each (-1.5 us per step; tools/stress_tail.py has checked the decisions of
     // 2.5 million steps x 196 blocks against known answers).
+    // `fenced` puts the release / acquire pair of the HIP memory model back (an L2 write-back and an L1 invalidate on this
+    // part, ~1.5 us): the engine asks for it wherever that time does not matter (exact mode, ssd_f32, batched passes,
+    // DEJAVU_FENCED=1) and the GPU suite checks that both forms decide alike.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = (atomicAdd(&st->done, 1u) == gridDim.x - 1) ? 1 : 0;
+        if (fenced && s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
     if (!s_last) return;
 
@@ -1080,7 +1087,7 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     __shared__ unsigned long long s_ncand;
     __shared__ int s_serr;
     if (threadIdx.x < A) {
-        st->amax[threadIdx.x] = s_amax[threadIdx.x];                            // for k_decide on the resolve path
+        __hip_atomic_store(&st->amax[threadIdx.x], s_amax[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for k_decide on the resolve path
         s_aview[threadIdx.x] = __hip_atomic_load(&st->aview[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the other two things the decision needs, fetched by other waves in the same round trip
@@ -1098,7 +1105,7 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
         if (s_serr) s_res.flags |= kResSenseError;     // patches came from k_sense and it ran off the landscape
         s_res.reserved = seq;                           // the host may poll this instead of waiting for the stream
         s_res.check = record_check(reinterpret_cast<const unsigned long long*>(&s_res), A);
-        st->done = 0;                                   // k_finish, which may run the next step, expects it clear
+        __hip_atomic_store(&st->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // k_finish, which may run the next step, expects it clear
     }
     __syncthreads();
     emit_record(&s_res, rec, A, threadIdx.x, blockDim.x);
@@ -1135,7 +1142,7 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
          int APAD, int has_hs_sum, int has_v_sum, StepState* __restrict__ st, unsigned long long* __restrict__ bsum,
          unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand, double* __restrict__ scene,
          StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene, int force,
-         int seq, const unsigned long long* __restrict__ sense_err) {
+         int seq, const unsigned long long* __restrict__ sense_err, int fenced) {
     __shared__ unsigned long long s_bmax[kMaxHeadings];
     __shared__ unsigned long long s_bview[kMaxHeadings];
     __shared__ unsigned long long s_keys[16 * 16 * 17];          // 34 KB: key transposes of phase 2
@@ -1242,7 +1249,11 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
     // ---- arrival ticket (see k_tail)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&st->done, 1u) == (unsigned)(nb - 1)) ? 1 : 0;
+    if (tid == 0) {
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = (atomicAdd(&st->done, 1u) == (unsigned)(nb - 1)) ? 1 : 0;
+        if (fenced && s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
     if (!s_last) return;
 
@@ -1352,17 +1363,18 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
     __syncthreads();
     if (tid < A) {
         s_aview[tid] = ~s_aview[tid];                                          // decide_core / k_decide expect ~f (0 = none)
-        st->amax[tid] = s_amax[tid];
-        st->aview[tid] = s_aview[tid];
+        __hip_atomic_store(&st->amax[tid], s_amax[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->aview[tid], s_aview[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     // the shared list overflowing means candidates were lost: report more than the resolver can take
     const unsigned long long n_all = (s_ntmp > (unsigned)kTmpCap) ? (unsigned long long)kCandCap + 1 : (unsigned long long)s_ncount;
     const bool needs = n_all <= (unsigned long long)kCandCap && (n_all >= 2 || (force && n_all >= 1));
-    if (tid == 0) {
-        st->ncand = n_all;
-        st->done = 0;                                                          // counters clear for the next step
-        st->ntmp = 0;
+    if (tid == 0) {                                                            // counters clear for the next step; every
+        // location other blocks touch atomically is also reset atomically (agent scope)
+        __hip_atomic_store(&st->ncand, n_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->ntmp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __shared__ unsigned long long s_check;
     decide_block(s_amax, s_aview, n_all, &s_res, &s_check, c, A, delta, (needs ? kResNeedsResolve : 0u) | (s_serr ? kResSenseError : 0u), seq);

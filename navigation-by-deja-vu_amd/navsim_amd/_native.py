@@ -155,6 +155,8 @@ PROTOTYPES = {
     "dv_profile_read": (ctypes.c_int, [_ctx_p, _f64p, _i64p]),
     "dv_workgroup_shape": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "dv_stream_read_gbps": (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int, _f64p]),
+    "dv_range_push": (ctypes.c_int, [ctypes.c_char_p]),
+    "dv_range_pop": (ctypes.c_int, []),
     "dv_version": (ctypes.c_char_p, []),
 }
 

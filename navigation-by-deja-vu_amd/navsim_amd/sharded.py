@@ -542,6 +542,14 @@ class DeviceExchange(object):
 
     def step(self):
         self.engine.step_enqueue(want_scene=False)
+        lib = self.engine._lib
+        lib.dv_range_push(b"dv:exchange")                # roctx range (no-op unless DEJAVU_ROCTX=1)
+        try:
+            return self._exchange()
+        finally:
+            lib.dv_range_pop()
+
+    def _exchange(self):
         if self.use_keys:
             out = self._reduce_keys()
             if out is not None:

@@ -58,7 +58,7 @@ _MODE_ENV = {
     "mfma": {"DEJAVU_FINISH": "2", "DEJAVU_SHAPE": "6", "DEJAVU_BITS": "2"},
     "default": {},
 }
-_MODE_KEYS = ("DEJAVU_FINISH", "DEJAVU_SHAPE", "DEJAVU_BITS")
+_MODE_KEYS = ("DEJAVU_FINISH", "DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FENCED")
 
 
 class engine_mode(object):

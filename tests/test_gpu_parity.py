@@ -942,3 +942,40 @@ def test_agent_trains_on_a_second_path():
     assert float(nsf.navigation_error) == float(host.navigation_error)
     assert np.array_equal(nsf._coverage_array, host._coverage_array) and nsf._coverage_array[150:].any()
     nsf._engine.close()
+
+
+@pytest.mark.parametrize("finish", ["2", "0"])
+def test_fenced_and_unfenced_arrival_tickets_decide_alike(finish):
+    """k_finish / k_tail hand their per-block results to the last block through agent-scope atomics; the release /
+    acquire pair of the memory model around the arrival ticket is optional on the single-agent integer path
+    (DEJAVU_FENCED, csrc/dejavu_hip.hip:step_fenced).  Both forms must give the reference's decision, per-heading maxima
+    and per-view minima on a library whose best view is duplicated in far-apart blocks and seen by several headings."""
+    import os
+    F, h, w, A, cw = 90000, 4, 4, 16, 0.25
+    lib = synth.synth_views(23, F, h, w)
+    star = lib[41000].copy()
+    star[0, 0] = (77, 200, 13)
+    for f in (5, 30000, 41000, 89999):
+        lib[f] = star
+    pats = synth.synth_patches(23, A, h, w)
+    pats[3] = pats[9] = pats[15] = star
+    want = oracle.step(lib, pats, cw)
+    seen = {}
+    for fenced in ("0", "1"):
+        os.environ["DEJAVU_FENCED"], os.environ["DEJAVU_FINISH"] = fenced, finish
+        try:
+            e = navsim_amd.FamiliarityEngine(0)
+        finally:
+            os.environ.pop("DEJAVU_FENCED", None)
+            os.environ.pop("DEJAVU_FINISH", None)
+        try:
+            e.set_library(lib, cw)
+            for _ in range(20):
+                r = e.step(pats, want_scene=True)
+                assert (r["best_idex"], r["best_view"]) == (want["best_idex"], want["best_view"]) == (3, 5), fenced
+            seen[fenced] = (np.array(r["angle_familiarity"]), np.array(r["scene_familiarity"]), r["n_candidates"])
+        finally:
+            e.close()
+    assert np.array_equal(seen["0"][0], seen["1"][0]) and np.array_equal(seen["0"][1], seen["1"][1])
+    assert seen["0"][2] == seen["1"][2] >= 12
+    np.testing.assert_allclose(seen["0"][0], want["angle_familiarity"], rtol=RTOL)

@@ -270,3 +270,17 @@ def test_experiment_helpers_match_the_reference(manifest, golden):
         assert {k: (int(v) if isinstance(v, (int, np.integer)) else float(v)) for k, v in res.items()} == row["result"], row["name"]
         assert experiment.csv_header(row["trial"]) == row["header"]
         assert experiment.csv_row(row["trial"], res) == row["line"], row["name"]
+
+
+def test_sanitizer_build_of_the_host_side_runs_clean():
+    """AddressSanitizer + UndefinedBehaviorSanitizer on the C code that needs no GPU (tools/sanitize): the host-arithmetic
+    entry points of the C ABI (csrc/dejavu_host.inl) and the oracle's C restatement, on exact-size buffers and ragged
+    shapes.  (GPU sanitizers are not available on the pool.)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host C++ toolchain")
+    d = os.path.join(REPO, "tools", "sanitize")
+    r = subprocess.run(["make", "-C", d, "check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "asan_driver: ok" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
