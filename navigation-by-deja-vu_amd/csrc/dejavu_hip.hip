@@ -128,7 +128,7 @@ struct dv_ctx {
     bool coef_ready = false;                  // d_coef / d_bconst describe the resident patches
     int bits_env = 1;                         // DEJAVU_BITS: 0 never build the bit planes, 1 when they save bytes, 2 whenever possible
     int mfma_tiles_env = 0, mfma_chunk_env = 0;   // DEJAVU_MFMA_TILES / DEJAVU_MFMA_CHUNK (0 = by library size)
-    int mfma_variant_env = 0;                 // DEJAVU_MFMA_VARIANT=1: shorter stages (A/B runs)
+    int mfma_variant_env = 0;                 // DEJAVU_MFMA_VARIANT: other forms of the matrix-core kernel (A/B runs), see launch_mfma
     const int* int_hsconst = nullptr;         // constants that go with the partial sums of the last integer scoring pass
     const int* int_vconst = nullptr;
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
@@ -258,7 +258,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_BITS", c->bits_env, 0, 2);
     env_int("DEJAVU_MFMA_TILES", c->mfma_tiles_env, 0, 2);
     env_int("DEJAVU_MFMA_CHUNK", c->mfma_chunk_env, 0, 32);
-    env_int("DEJAVU_MFMA_VARIANT", c->mfma_variant_env, 0, 1);
+    env_int("DEJAVU_MFMA_VARIANT", c->mfma_variant_env, 0, 4);
     env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
     env_int("DEJAVU_FENCED", c->fenced_env, 0, 1);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
@@ -1343,6 +1343,24 @@ static void launch_mfma_variant(dv_ctx* c, int nchunk, int has_hs) {
                            c->APAD, a_off, has_hs);
 }
 
+template <int SK, int TILES, int RD>
+static void launch_mfma_ring(dv_ctx* c, int nchunk, int has_hs) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)RD * (SK * 8 + 8 * SK * TILES) * 1024;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma_ring<SK, TILES, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long long G32 = c->cfg.Fpad / 32;
+    const long long items = ((G32 + 8 * TILES - 1) / (8 * TILES)) * nchunk;
+    const unsigned grid = (unsigned)(items < 256 ? items : 256);
+    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
+    for (int a_off = 0; a_off < c->APAD; a_off += 32)
+        hipLaunchKernelGGL((k_sad_mfma_ring<SK, TILES, RD>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+                           c->d_coef + (size_t)(a_off / 32) * nkt * 512, reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk,
+                           c->APAD, a_off, has_hs);
+}
+
 // Work items of k_sad_mfma = (chunk of K-steps, 8*TILES view groups of 32).  Two view groups per wave halve the
 // coefficient traffic (every A operand serves both) once the library is large enough to keep every CU busy that way;
 // small libraries cut the K-steps into chunks instead so that there are at least as many items as CUs.
@@ -1364,14 +1382,28 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     if (nchunk > c->nchunk_cap) nchunk = c->nchunk_cap;
     if (nchunk < 1) nchunk = 1;
     c->nchunk = nchunk;
-    // stage length (K-steps per barrier), measured: two view groups per wave 4 (1.48 ms against 1.58 with 2 at 500 000
-    // views x 128x128), one view group 8 (56.8 us against 59.6 with 4 at 50 000 x 64x64)
+    // Forms of the kernel (DEJAVU_MFMA_VARIANT, A/B runs).  Default: both operands through LDS rings by LDS-DMA with
+    // counted waits (k_sad_mfma_ring).  Measured, 500 000 views x 128x128 x 32 headings, two view groups per wave:
+    // register-staged library bits, stage of 4 K-steps 1.48-1.51 ms; rings <SK,TILES,RD> = <2,2,3> 1.38, <2,2,2> 1.37,
+    // <1,2,3..6> 1.29 ms.  50 000 views x 64x64 x 16 headings, one view group per wave: register-staged, stage of 8
+    // K-steps 56.7 us; rings <2,1,4> 50.2, <4,1,2> 46.7, <1,1,6> 50.9 us.
+    const int var = c->mfma_variant_env;
     if (tiles == 2) {
-        if (c->mfma_variant_env == 1) launch_mfma_variant<2, 2>(c, nchunk, has_hs);
-        else launch_mfma_variant<4, 2>(c, nchunk, has_hs);
+        switch (var) {
+            case 1: launch_mfma_variant<2, 2>(c, nchunk, has_hs); break;
+            case 2: launch_mfma_variant<4, 2>(c, nchunk, has_hs); break;
+            case 3: launch_mfma_ring<2, 2, 3>(c, nchunk, has_hs); break;
+            case 4: launch_mfma_ring<1, 2, 5>(c, nchunk, has_hs); break;
+            default: launch_mfma_ring<1, 2, 3>(c, nchunk, has_hs);
+        }
     } else {
-        if (c->mfma_variant_env == 1) launch_mfma_variant<4, 1>(c, nchunk, has_hs);
-        else launch_mfma_variant<8, 1>(c, nchunk, has_hs);
+        switch (var) {
+            case 1: launch_mfma_variant<4, 1>(c, nchunk, has_hs); break;
+            case 2: launch_mfma_variant<8, 1>(c, nchunk, has_hs); break;
+            case 3: launch_mfma_ring<2, 1, 4>(c, nchunk, has_hs); break;
+            case 4: launch_mfma_ring<1, 1, 6>(c, nchunk, has_hs); break;
+            default: launch_mfma_ring<4, 1, 2>(c, nchunk, has_hs);
+        }
     }
 }
 

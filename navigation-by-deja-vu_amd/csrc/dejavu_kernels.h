@@ -2270,6 +2270,171 @@ k_path_error(const double* __restrict__ xy, long long n, double x, double y, dou
     }
 }
 
+// The same scoring with BOTH operands streamed through LDS rings by LDS-DMA (global_load_lds, no destination
+// registers) RD stages deep, and every vector-memory wait counted by hand:
+//   stage = SK K-steps; per stage a wave fetches its share of the coefficient rows (SK*8 rows of 1 KB over the 8 waves)
+//   and its own library rows (SK*TILES rows) -- NDMA instructions, all issued in one place at the top of a stage, for
+//   stage st + RD - 1, into the ring slot the workgroup finished reading one barrier ago;
+//   vmcnt retires in order, so "stage st + 1 has landed" = "at most the NDMA * (RD - 2) younger instructions are
+//   still outstanding": one counted s_waitcnt per stage, then a raw s_barrier (every wave's rows are in, every wave is done
+//   with the slot about to be refilled).  Nothing ever drains to vmcnt(0) inside a segment, so HBM loads stay RD - 1
+//   stages (microseconds) ahead of their use and the accumulators are the only large register block.
+// The LDS-DMA instructions are inline assembly: hipcc would wait for vmcnt(0) before every ds_read while one of ITS
+// global_load_lds is in flight (it cannot tell the ring slots apart).  Inline assembly is invisible to its waitcnt
+// bookkeeping, which is exactly what is wanted here: every wait in the loop is written out below.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_dma_16(const uint4* gsrc, unsigned lds_byte_addr) {     // 64 lanes x 16 B -> 1 KB of LDS
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void lds_dma_16_nt(const uint4* gsrc, unsigned lds_byte_addr) {  // library rows: used once per step
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int SK, int TILES, int RD>
+__global__ void __launch_bounds__(512, 2)
+k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, LibCfg c, BitCfg b,
+                int nchunk, int apad_total, int a_off, int has_hs_sum) {
+    extern __shared__ uint4 lds_ring[];           // [RD][ coefficient rows SK*8 | library rows 8 waves * SK * TILES ][64]
+    constexpr int NW = 8;
+    constexpr int VW = NW * TILES;
+    constexpr int COEF_ROWS = SK * 8;             // per stage
+    constexpr int LIB_ROWS = NW * SK * TILES;
+    constexpr int SLOT16 = (COEF_ROWS + LIB_ROWS) * 64;      // uint4 per ring slot
+    constexpr int CPW = COEF_ROWS / NW;           // coefficient rows each wave fetches per stage
+    constexpr int NDMA = CPW + SK * TILES;        // LDS-DMA instructions per wave and stage
+    static_assert(COEF_ROWS % NW == 0 && RD >= 2 && NDMA * (RD - 1) < 64, "ring shape");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long G32 = c.Fpad / 32;
+    const long long GQ = (G32 + VW - 1) / VW;
+    const long long n_items = GQ * nchunk;
+    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ch = (int)(item / GQ);
+        const long long gq = item - (long long)ch * GQ;
+        const uint4* lib[TILES];
+        long long gidx[TILES];
+        bool live[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            long long g = gq * VW + wave * TILES + t;
+            live[t] = g < G32;
+            if (!live[t]) g = G32 - 1;
+            gidx[t] = g;
+            lib[t] = btiles + (g * b.GS) * 64 + lane;
+        }
+#pragma unroll 1
+        for (int seg = 0; seg < 2; ++seg) {
+            if (seg == 0 && !has_hs_sum) continue;
+            if (seg == 1 && !c.hasv) continue;
+            const int kbase = seg ? b.NK[0] : 0;
+            const int k0 = kbase + (int)(((long long)ch * b.NK[seg]) / nchunk);
+            const int k1 = kbase + (int)(((long long)(ch + 1) * b.NK[seg]) / nchunk);
+            const int nst = (k1 - k0 + SK - 1) / SK;
+            v16i_t acc[TILES][4];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][s][r] = 0;
+            if (nst > 0) {
+                auto kclamp = [&](int k) { return k < k1 ? k : k1 - 1; };
+                // all of a stage's LDS-DMA of this wave: CPW coefficient rows, then its SK*TILES library rows
+                auto issue_stage = [&](int st) {
+                    const int kb = k0 + st * SK;
+                    const unsigned slot = lds_base + (unsigned)((st % RD) * SLOT16) * 16u;
+#pragma unroll
+                    for (int i = 0; i < CPW; ++i) {
+                        const int row = wave * CPW + i;                       // (K-step, slice) row of the stage
+                        long long src = ((long long)kb * 8 + row) * 64 + lane;
+                        const long long lim = (long long)k1 * 512;
+                        if (src >= lim) src = lim - 64 + lane;                // past the chunk: any valid row (masked below)
+                        lds_dma_16(coef + src, __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u));
+                    }
+#pragma unroll
+                    for (int k = 0; k < SK; ++k)
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const int row = COEF_ROWS + (wave * SK + k) * TILES + t;
+                            lds_dma_16_nt(lib[t] + (long long)kclamp(kb + k) * 64, __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u));
+                        }
+                };
+#pragma unroll
+                for (int r = 0; r < RD - 1; ++r) issue_stage(r);              // stages 0 .. RD-2 (clamped rows past the end)
+                for (int st = 0; st < nst; ++st) {
+                    // stage st has landed once at most the (RD - 2) younger stages' instructions are outstanding
+                    wait_vmcnt_le<NDMA * (RD - 2)>();
+                    __builtin_amdgcn_s_barrier();
+                    issue_stage(st + RD - 1);                                  // into the slot everybody finished with a barrier ago
+                    const int kb = k0 + st * SK;
+                    const uint4* cbuf = lds_ring + (st % RD) * SLOT16 + lane;
+                    const uint4* lbuf = cbuf + (COEF_ROWS + wave * SK * TILES) * 64;
+                    v4i_t a[2][4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { const uint4 w = cbuf[s * 64]; a[0][s] = v4i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
+                    uint4 xl[2][TILES];                                        // library bits of the current / next K-step
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) xl[0][t] = lbuf[t * 64];
+#pragma unroll
+                    for (int hs = 0; hs < 2 * SK; ++hs) {
+                        const int k = hs >> 1;
+                        if (hs + 1 < 2 * SK) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const uint4 w = cbuf[((hs + 1) * 4 + s) * 64];
+                                a[(hs + 1) & 1][s] = v4i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+                            }
+                            if ((hs & 1) == 0 && k + 1 < SK) {
+#pragma unroll
+                                for (int t = 0; t < TILES; ++t) xl[(k + 1) & 1][t] = lbuf[((k + 1) * TILES + t) * 64];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const bool on = kb + k < k1;
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const uint4 x = xl[k & 1][t];
+                            const uint4 src = (hs & 1) ? make_uint4(x.x >> 4, x.y >> 4, x.z >> 4, x.w >> 4) : x;
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const unsigned m = on ? (0x01010101u << s) : 0u;
+                                const v4i_t bo = v4i_t{(int)(src.x & m), (int)(src.y & m), (int)(src.z & m), (int)(src.w & m)};
+                                acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[hs & 1][s], bo, acc[t][s], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                wait_vmcnt_le<0>();               // the clamped fetches past the end of the chunk
+                __builtin_amdgcn_s_barrier();     // nobody still reads a slot the next segment / item refills
+            }
+            const int type_row = seg ? has_hs_sum : 0;
+            const int nsum = has_hs_sum + c.hasv;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                if (live[t]) {
+                    int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int tot = acc[t][0][r] + (acc[t][1][r] >> 1) + (acc[t][2][r] >> 2) + (acc[t][3][r] >> 3);
+                        if (m < rows) dst[(long long)m * c.Fpad] = tot;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.
 __global__ void k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
     const long long stride = (long long)gridDim.x * blockDim.x;

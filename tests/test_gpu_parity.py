@@ -979,3 +979,35 @@ def test_fenced_and_unfenced_arrival_tickets_decide_alike(finish):
     assert np.array_equal(seen["0"][0], seen["1"][0]) and np.array_equal(seen["0"][1], seen["1"][1])
     assert seen["0"][2] == seen["1"][2] >= 12
     np.testing.assert_allclose(seen["0"][0], want["angle_familiarity"], rtol=RTOL)
+
+
+@pytest.mark.parametrize("variant", ["0", "2", "3"])
+def test_matrix_core_kernel_forms_under_repetition(variant):
+    """k_sad_mfma_ring streams both operands through LDS rings with hand-counted waits; k_sad_mfma stages the library
+    bits in registers.  A race in either would show as an occasional wrong sum: 150 steps with changing patches on a
+    library with several view groups per wave and a ragged tail, every decision, per-heading maximum and per-view minimum
+    against the oracle (the integer sums are exact, so the scores must agree to the last bit from step to step)."""
+    import os
+    F, h, w, A, cw = 9000 + 37, 20, 12, 13, 0.25
+    lib = synth.synth_views(61, F, h, w)
+    os.environ.update(DEJAVU_SHAPE="6", DEJAVU_BITS="2", DEJAVU_MFMA_VARIANT=variant)
+    try:
+        e = navsim_amd.FamiliarityEngine(0)
+    finally:
+        for k in ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_MFMA_VARIANT"):
+            os.environ.pop(k, None)
+    try:
+        e.set_library(lib, cw)
+        assert e.library_info()["has_bit_planes"]
+        for it in range(150):
+            pats = synth.synth_patches(1000 + it % 5, A, h, w)
+            pats[it % A] = synth.near_match_patch(lib[(it * 997) % F], it, fraction=0.02)
+            got = e.step(pats, want_scene=True)
+            if it < 15:
+                want = oracle.step(lib, pats, cw)
+                assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]), it
+                np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+                np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=RTOL)
+            assert got["best_view"] == (it * 997) % F and got["best_idex"] == it % A, it
+    finally:
+        e.close()
