@@ -134,19 +134,25 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi))
     nsf.position = path[1] + np.array([1.0, -1.0])
     rates = {}
+    outliers = {}
     for fake in (True, False):
         nsf.position = path[1] + np.array([1.0, -1.0])
         nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi))
         nsf.reset_error()
         done = 0
+        durs = []
         try:
             for _ in range(10):
                 nsf.step_forward(fake=fake)
             t0 = time.perf_counter()
             for _ in range(n_steps):
+                t1 = time.perf_counter()
                 nsf.step_forward(fake=fake)
+                durs.append(time.perf_counter() - t1)
                 done += 1
             rates[fake] = done / (time.perf_counter() - t0)
+            outliers[fake] = dict(median_step_us=float(np.median(durs)) * 1e6,
+                                  steps=[(i, int(x * 1e6)) for i, x in enumerate(durs) if x > 4 * float(np.median(durs))][:8])
         except navsim_amd.StopNavigationException:              # left the path before n_steps: rate over what ran
             rates[fake] = done / max(time.perf_counter() - t0, 1e-9) if done else None
     n_lib = len(path)
@@ -170,7 +176,7 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     except Exception:                                            # noqa: BLE001 - an extra figure only
         ens_rate = None
     nsf.clear_training()
-    return rates, n_lib, ens_rate
+    return rates, n_lib, ens_rate, outliers
 
 
 def ssd_f32_block(device_index, F, h, w, A, steps):
@@ -482,10 +488,11 @@ def main():
                 out["configs1"] = {"error": repr(e)}
         if extras and args.agent_steps > 0:
             try:
-                rates, n_lib, ens_rate = agent_steps_per_s(64, 64, 16, cw, 50000, args.seed, args.agent_steps)
+                rates, n_lib, ens_rate, outliers = agent_steps_per_s(64, 64, 16, cw, 50000, args.seed, args.agent_steps)
                 out["agent"] = {"nav_steps_per_s": rates.get(False), "nav_steps_per_s_fake": rates.get(True),
                                 "view_comparisons_per_s": (rates.get(False) or 0.0) * n_lib * 16, "library_views": n_lib,
                                 "ensemble_of_32_nav_steps_per_s": ens_rate,
+                                "median_step_us_and_steps_over_4x_median": {"fake": outliers.get(True), "not_fake": outliers.get(False)},
                                 "what": "navsim_amd.NavBySceneFamiliarity.step_forward() on the configs[1] shape (64x64, 16 "
                                         "headings, 50 000-view training path): sensor model on the GPU (2000x2000 landscape "
                                         "resident), scoring, decision, position update and the error metrics of "

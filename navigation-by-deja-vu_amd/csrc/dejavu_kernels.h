@@ -2230,7 +2230,7 @@ k_sad_mfma(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int
 // same set: no distance is within reach unless the smallest is).  The last block to arrive hands {nearest, seq} to the
 // host through mapped memory.  Off the step's critical path: the host collects the answer one step later.
 struct PathErrState { unsigned long long minkey; unsigned ticket; unsigned pad; };
-struct PathErrOut { double nearest; unsigned long long seq; };
+struct alignas(16) PathErrOut { double nearest; unsigned long long seq; };
 
 __global__ void __launch_bounds__(256)
 k_path_error(const double* __restrict__ xy, long long n, double x, double y, double reach, unsigned char* __restrict__ cover,
@@ -2263,9 +2263,12 @@ k_path_error(const double* __restrict__ xy, long long n, double x, double y, dou
             const unsigned long long all = __hip_atomic_load(&st->minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&st->minkey, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out->nearest = __longlong_as_double((long long)all);
-            __threadfence_system();
-            __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // answer and sequence number leave in ONE 16-byte store to the mapped host record (one PCIe write: the host,
+            // which polls the sequence word and then reads the answer, can never pair a new number with an old answer),
+            // so no system-scope fence sits between them
+            v4u_t rec;
+            rec.x = (unsigned)all; rec.y = (unsigned)(all >> 32); rec.z = (unsigned)seq; rec.w = (unsigned)(seq >> 32);
+            *reinterpret_cast<v4u_t*>(out) = rec;
         }
     }
 }
