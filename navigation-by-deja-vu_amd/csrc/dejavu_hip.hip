@@ -105,6 +105,7 @@ struct dv_ctx {
     unsigned long long* d_bsum = nullptr;     // k_finish: per-block, per-heading (maximum, first view) [blocks][2][headings]
     unsigned long long* d_ctmp = nullptr;     // k_finish: shared extra-candidate list [agents][kTmpCap][2]
     int int_has_hs = 0, int_has_v = 0;        // which sums the last integer scoring pass produced
+    int finish_vb_env = 0;                    // DEJAVU_FINISH_VB: view sets of 256 per k_finish block
     int fenced_env = -1;                      // DEJAVU_FENCED: 1 release/acquire around the arrival ticket always, 0 never; default by path
     int finish_fused = 1;                     // DEJAVU_FINISH: integer-path steps end in k_finish where it pays (0: never, 2: whenever possible)
     unsigned* d_part = nullptr;               // [nchunk][nsum][APAD][Fpad] raw integer sums of one pass
@@ -261,6 +262,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_MFMA_VARIANT", c->mfma_variant_env, 0, 4);
     env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
     env_int("DEJAVU_FENCED", c->fenced_env, 0, 1);
+    env_int("DEJAVU_FINISH_VB", c->finish_vb_env, 0, 16);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -1582,11 +1584,24 @@ static int step_fenced(const dv_ctx* c) {
 template <int NT>
 static void launch_finish(dv_ctx* c, int want_scene, int force) {
     const LibCfg& g = c->cfg;
-    hipLaunchKernelGGL(k_finish<NT>, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream,
+    // Large libraries (more than 256 blocks of 256 views): the blocks only leave their summaries and k_fold, a 1024-thread
+    // kernel behind them, folds and decides -- the serial walk of thousands of summaries by one 256-thread last block cost
+    // 60 us at 500 000 views.  DEJAVU_FINISH_VB: view sets of 256 per block (fewer, longer blocks; default 1).
+    long long vb = c->finish_vb_env > 0 ? c->finish_vb_env : 1;
+    const long long per_block = 256 * vb;
+    const unsigned nb = (unsigned)((g.F + per_block - 1) / per_block);
+    const int separate = nb > 256 ? 1 : 0;
+    const unsigned long long* serr = c->patches_sensed ? c->d_err + c->sense_parity : nullptr;
+    StepResultDev* outp = c->d_result + c->result_slot;
+    double* recp = c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings);
+    ++c->seq;
+    hipLaunchKernelGGL(k_finish<NT>, dim3(nb, (unsigned)c->n_agents), dim3(256), 0, c->stream,
                        c->d_part, c->int_hsconst, c->int_vconst, c->nchunk, c->APAD, c->int_has_hs, c->int_has_v, c->d_state, c->d_bsum, c->d_ctmp,
-                       c->d_cand, c->d_scene, c->d_result + c->result_slot,
-                       c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta, want_scene, force,
-                       ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr, step_fenced(c));
+                       c->d_cand, c->d_scene, outp, recp, c->cfg, c->A_agent, c->delta, want_scene, force,
+                       c->seq, serr, step_fenced(c), (int)vb, separate);
+    if (separate)
+        hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3(1024), 0, c->stream, c->d_bsum, c->d_ctmp, c->d_cand, c->d_state,
+                           outp, recp, c->cfg, c->A_agent, c->delta, force, c->seq, serr, (int)nb);
 }
 
 static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
@@ -1599,7 +1614,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     // 32 headings per agent: equal at 200 000 views, 5 us slower at 20 000; 64 (64 scores per thread in registers,
     // one wave per SIMD): 1103 vs 1029 us at 200 000 views; 8-16 headings on 20 000 views: 1-2 us slower.
     const bool fused = c->metric == 0 && !c->exact && c->A_agent <= 32 &&
-                       (c->finish_fused == 2 || (c->finish_fused == 1 && c->A_agent <= 16 && g.F >= 32768));
+                       (c->finish_fused == 2 || (c->finish_fused == 1 && g.F >= 32768 && (c->A_agent <= 16 || g.F >= 131072)));
     int rc = launch_scoring(c, !fused);
     if (rc) return rc;
     Range range("dv:finish");

@@ -1136,127 +1136,17 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
 // Cross-block data travels through device-scope atomic stores/loads (no fences, see k_tail).
 constexpr int kTmpCap = 4096;       // entries of the shared extra-candidate list per agent
 
-template <int NT>                   // headings per agent <= 16 * NT, scores held in registers
-__global__ void __launch_bounds__(256)
-k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, const int* __restrict__ vconst, int nchunk,
-         int APAD, int has_hs_sum, int has_v_sum, StepState* __restrict__ st, unsigned long long* __restrict__ bsum,
-         unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand, double* __restrict__ scene,
-         StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene, int force,
-         int seq, const unsigned long long* __restrict__ sense_err, int fenced) {
-    __shared__ unsigned long long s_bmax[kMaxHeadings];
-    __shared__ unsigned long long s_bview[kMaxHeadings];
-    __shared__ unsigned long long s_keys[16 * 16 * 17];          // 34 KB: key transposes of phase 2
-    __shared__ int s_last;
-    const int agent = blockIdx.y;
-    const int a_base = agent * A;
-    const int nb = gridDim.x;
+// The part of k_finish after every block has left its summary: fold the summaries into per-heading maxima and first
+// views, derive the threshold, build the candidate list from the representatives and the shared list, decide, write the
+// result record.  Run by the last block to arrive (small libraries) or by k_fold, a kernel of its own with 1024 threads
+// behind k_finish (large libraries: the kernel boundary replaces the arrival ticket, and four times the threads walk the
+// summaries).  Generic in blockDim.x.
+__device__ __forceinline__ void fold_and_decide(const unsigned long long* __restrict__ bsum, const unsigned long long* __restrict__ ctmp,
+                                                unsigned long long* __restrict__ cand, StepState* __restrict__ st,
+                                                StepResultDev* __restrict__ out, double* __restrict__ rec, const LibCfg& c, int A,
+                                                double delta, int force, int seq, const unsigned long long* __restrict__ sense_err,
+                                                int agent, int nb) {
     const int tid = threadIdx.x;
-    st += agent;
-    cand += (long long)agent * kCandCap;
-    ctmp += (long long)agent * kTmpCap * 2;
-    bsum += (long long)agent * nb * 2 * A;
-    out += agent;
-    rec += (long long)agent * (3 + 4 * kMaxHeadings);
-
-    // ---- scores of this thread's view, all headings of the agent
-    const long long f = (long long)blockIdx.x * blockDim.x + tid;
-    const bool inb = f < c.F;
-    const long long fl = inb ? f : c.F - 1;
-    const int nsum = has_hs_sum + has_v_sum;
-    // integer sums first: per chunk, the loads of all headings are issued together (one round trip per chunk)
-    unsigned shs_u[NT * 16], sv_u[NT * 16];
-#pragma unroll
-    for (int k = 0; k < NT * 16; ++k) { shs_u[k] = 0; sv_u[k] = 0; }
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const unsigned* p = part + ((long long)ch * nsum * APAD) * c.Fpad + fl;
-        unsigned th[NT * 16], tv[NT * 16];
-#pragma unroll
-        for (int k = 0; k < NT * 16; ++k) {
-            const int a = a_base + (k < A ? k : A - 1);                            // clamped: no conditional loads
-            th[k] = has_hs_sum ? p[(long long)a * c.Fpad] : 0u;
-            tv[k] = has_v_sum ? p[(long long)((has_hs_sum ? APAD : 0) + a) * c.Fpad] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < NT * 16; ++k) { shs_u[k] += th[k]; sv_u[k] += tv[k]; }
-    }
-    double val[NT * 16];
-#pragma unroll
-    for (int k = 0; k < NT * 16; ++k) {
-        val[k] = 0.0;
-        if (k < A) {
-            // the chunk sums are int32 and may wrap on the way (bit-plane path: negative chunks); their total fits
-            const long long shs = (long long)hsconst[a_base + k] + (long long)(int)shs_u[k];
-            const long long sv = (long long)(vconst ? vconst[a_base + k] : 0) + (long long)(int)sv_u[k];
-            double acc = c.whs * (double)shs;
-            if (has_v_sum) acc = acc + c.wv * (double)sv;
-            val[k] = (double)c.P - acc / 255.;
-        }
-    }
-
-    // ---- per heading: the block's maximum and the first view attaining it.  Keys go through LDS transposed, 16
-    // headings at a time: thread (k = tid/16, j = tid%16) folds the 16 keys of heading k from views j*16..j*16+15
-    // (rows padded to 17 against bank conflicts), then the 16 partial results per heading meet in LDS atomics.
-    if (tid < kMaxHeadings) { s_bmax[tid] = 0; s_bview[tid] = ~0ull; }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t * 16 < A) {
-            __syncthreads();
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-                s_keys[(kk * 16 + (tid >> 4)) * 17 + (tid & 15)] = inb ? ordered_key(val[t * 16 + kk]) : 0ull;
-            __syncthreads();
-            const int k = tid >> 4, j = tid & 15;
-            unsigned long long m = 0;
-            int mi = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const unsigned long long x = s_keys[(k * 16 + j) * 17 + i];
-                if (x > m) { m = x; mi = i; }
-            }
-            if (t * 16 + k < A && m != 0) atomicMax(&s_bmax[t * 16 + k], m);
-            __syncthreads();
-            if (t * 16 + k < A && m != 0 && m == s_bmax[t * 16 + k])
-                atomicMin(&s_bview[t * 16 + k], (unsigned long long)((long long)blockIdx.x * blockDim.x + j * 16 + mi));
-        }
-    }
-    __syncthreads();
-    unsigned long long bbest = 0;
-    for (int k = 0; k < A; ++k) bbest = s_bmax[k] > bbest ? s_bmax[k] : bbest;
-    const double thr_b = key_to_double(bbest) - delta;
-    if (inb) {
-        double smin = __longlong_as_double(0x7ff0000000000000ll);
-#pragma unroll
-        for (int k = 0; k < NT * 16; ++k) {
-            if (k < A) {
-                smin = val[k] < smin ? val[k] : smin;
-                if (val[k] >= thr_b && !(ordered_key(val[k]) == s_bmax[k] && (unsigned long long)f == s_bview[k])) {
-                    const unsigned pos = __hip_atomic_fetch_add(&st->ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (pos < (unsigned)kTmpCap) {
-                        __hip_atomic_store(&ctmp[2 * pos], ((unsigned long long)k << 40) | (unsigned long long)f, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&ctmp[2 * pos + 1], ordered_key(val[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-        }
-        if (want_scene) scene[f] = smin;
-    }
-    if (tid < A) {
-        __hip_atomic_store(&bsum[((long long)blockIdx.x * 2 + 0) * A + tid], s_bmax[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&bsum[((long long)blockIdx.x * 2 + 1) * A + tid], s_bview[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    // ---- arrival ticket (see k_tail)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        s_last = (atomicAdd(&st->done, 1u) == (unsigned)(nb - 1)) ? 1 : 0;
-        if (fenced && s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!s_last) return;
-
     // ---- last block: fold the summaries, list the candidates, decide
     __shared__ unsigned long long s_amax[kMaxHeadings];
     __shared__ unsigned long long s_aview[kMaxHeadings];
@@ -1387,6 +1277,176 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
         const int o = 7 + (i / A) * kMaxHeadings + (i % A);
         dst[o] = src[o];
     }
+}
+
+template <int NT>                   // headings per agent <= 16 * NT, scores held in registers
+__global__ void __launch_bounds__(256)
+k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, const int* __restrict__ vconst, int nchunk,
+         int APAD, int has_hs_sum, int has_v_sum, StepState* __restrict__ st, unsigned long long* __restrict__ bsum,
+         unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand, double* __restrict__ scene,
+         StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int want_scene, int force,
+         int seq, const unsigned long long* __restrict__ sense_err, int fenced, int vb, int separate_fold) {
+    __shared__ unsigned long long s_bmax[kMaxHeadings];
+    __shared__ unsigned long long s_bview[kMaxHeadings];
+    __shared__ unsigned long long s_keys[16 * 16 * 17];          // 34 KB: key transposes of phase 2
+    __shared__ int s_last;
+    const int agent = blockIdx.y;
+    const int a_base = agent * A;
+    const int nb = gridDim.x;
+    const int tid = threadIdx.x;
+    st += agent;
+    cand += (long long)agent * kCandCap;
+    ctmp += (long long)agent * kTmpCap * 2;
+    bsum += (long long)agent * nb * 2 * A;
+    out += agent;
+    rec += (long long)agent * (3 + 4 * kMaxHeadings);
+
+    // ---- scores of this thread's views, all headings of the agent.  A block owns `vb` consecutive sets of 256 views
+    // (vb > 1 on large libraries: the last block's fold walks one summary per block, so fewer, larger blocks).
+    const int nsum = has_hs_sum + has_v_sum;
+    // Sixteen headings at a time (NT rounds), so that a thread never holds more than 16 scores: each round loads its
+    // integer sums (per chunk, all 16 headings' loads issued together), turns them into scores, finds the block's
+    // maximum and first view per heading through an LDS transpose, and lists candidates against the round's OWN best --
+    // a threshold that can only be lower than the block's or the global one, so the list stays a superset of what the
+    // last block keeps after it has derived the true threshold.
+    __shared__ unsigned long long s_blkmax[kMaxHeadings];        // over the view sets done so far (s_bmax / s_bview: current set)
+    __shared__ unsigned long long s_blkview[kMaxHeadings];
+    if (tid < kMaxHeadings) { s_blkmax[tid] = 0; s_blkview[tid] = ~0ull; }
+#pragma unroll 1
+  for (int vs = 0; vs < vb; ++vs) {
+    if (tid < kMaxHeadings) { s_bmax[tid] = 0; s_bview[tid] = ~0ull; }
+    const long long f = ((long long)blockIdx.x * vb + vs) * blockDim.x + tid;
+    const bool inb = f < c.F;
+    const long long fl = inb ? f : c.F - 1;
+    double smin = __longlong_as_double(0x7ff0000000000000ll);
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        if (t * 16 >= A) break;
+        const int At = (A - t * 16) < 16 ? (A - t * 16) : 16;                   // headings of this round
+        unsigned shs_u[16], sv_u[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { shs_u[k] = 0; sv_u[k] = 0; }
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const unsigned* p = part + ((long long)ch * nsum * APAD) * c.Fpad + fl;
+            unsigned th[16], tv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int a = a_base + t * 16 + (k < At ? k : At - 1);          // clamped: no conditional loads
+                th[k] = has_hs_sum ? p[(long long)a * c.Fpad] : 0u;
+                tv[k] = has_v_sum ? p[(long long)((has_hs_sum ? APAD : 0) + a) * c.Fpad] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { shs_u[k] += th[k]; sv_u[k] += tv[k]; }
+        }
+        double val[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            val[k] = 0.0;
+            if (k < At) {
+                // the chunk sums are int32 and may wrap on the way (bit-plane path: negative chunks); their total fits
+                const long long shs = (long long)hsconst[a_base + t * 16 + k] + (long long)(int)shs_u[k];
+                const long long sv = (long long)(vconst ? vconst[a_base + t * 16 + k] : 0) + (long long)(int)sv_u[k];
+                double acc = c.whs * (double)shs;
+                if (has_v_sum) acc = acc + c.wv * (double)sv;
+                val[k] = (double)c.P - acc / 255.;
+            }
+        }
+        // keys through LDS transposed: thread (k = tid/16, j = tid%16) folds the 16 keys of heading k from views
+        // j*16..j*16+15 (rows padded to 17 against bank conflicts), then the 16 partial results per heading meet in LDS atomics
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            s_keys[(kk * 16 + (tid >> 4)) * 17 + (tid & 15)] = inb ? ordered_key(val[kk]) : 0ull;
+        __syncthreads();
+        {
+            const int k = tid >> 4, j = tid & 15;
+            unsigned long long m = 0;
+            int mi = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned long long x = s_keys[(k * 16 + j) * 17 + i];
+                if (x > m) { m = x; mi = i; }
+            }
+            if (k < At && m != 0) atomicMax(&s_bmax[t * 16 + k], m);
+            __syncthreads();
+            if (k < At && m != 0 && m == s_bmax[t * 16 + k])
+                atomicMin(&s_bview[t * 16 + k], (unsigned long long)(((long long)blockIdx.x * vb + vs) * blockDim.x + j * 16 + mi));
+        }
+        __syncthreads();
+        unsigned long long rbest = 0;
+        for (int k = 0; k < At; ++k) rbest = s_bmax[t * 16 + k] > rbest ? s_bmax[t * 16 + k] : rbest;
+        const double thr_b = key_to_double(rbest) - delta;
+        if (inb) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < At) {
+                    const int a = t * 16 + k;
+                    smin = val[k] < smin ? val[k] : smin;
+                    if (val[k] >= thr_b && !(ordered_key(val[k]) == s_bmax[a] && (unsigned long long)f == s_bview[a])) {
+                        const unsigned pos = __hip_atomic_fetch_add(&st->ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (pos < (unsigned)kTmpCap) {
+                            __hip_atomic_store(&ctmp[2 * pos], ((unsigned long long)a << 40) | (unsigned long long)f, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&ctmp[2 * pos + 1], ordered_key(val[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (inb && want_scene) scene[f] = smin;
+    __syncthreads();
+    if (tid < A && s_bmax[tid] != 0) {
+        // This set's representative of heading tid against the block's so far: larger key, then smaller view, wins.  The
+        // loser was kept out of the shared list as a representative, so it is listed now if it lies within delta of the
+        // winner (anything within delta of the GLOBAL maximum does: the winner is no larger than that maximum).
+        const unsigned long long ck = s_bmax[tid], cv = s_bview[tid], bk = s_blkmax[tid], bv = s_blkview[tid];
+        if (bk == 0) {
+            s_blkmax[tid] = ck; s_blkview[tid] = cv;
+        } else {
+            const bool cur_wins = ck > bk || (ck == bk && cv < bv);
+            const unsigned long long wk = cur_wins ? ck : bk, lk = cur_wins ? bk : ck, lv = cur_wins ? bv : cv;
+            if (key_to_double(lk) >= key_to_double(wk) - delta) {
+                const unsigned pos = __hip_atomic_fetch_add(&st->ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pos < (unsigned)kTmpCap) {
+                    __hip_atomic_store(&ctmp[2 * pos], ((unsigned long long)tid << 40) | lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ctmp[2 * pos + 1], lk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (cur_wins) { s_blkmax[tid] = ck; s_blkview[tid] = cv; }
+        }
+    }
+    __syncthreads();
+  }
+    if (tid < A) {
+        __hip_atomic_store(&bsum[((long long)blockIdx.x * 2 + 0) * A + tid], s_blkmax[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&bsum[((long long)blockIdx.x * 2 + 1) * A + tid], s_blkview[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    if (separate_fold) return;          // k_fold, launched behind this kernel, does the rest: no ticket at all
+
+    // ---- arrival ticket (see k_tail)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = (atomicAdd(&st->done, 1u) == (unsigned)(nb - 1)) ? 1 : 0;
+        if (fenced && s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    fold_and_decide(bsum, ctmp, cand, st, out, rec, c, A, delta, force, seq, sense_err, agent, nb);
+}
+
+// fold_and_decide as its own launch: grid (1, agents), 1024 threads.
+__global__ void __launch_bounds__(1024)
+k_fold(unsigned long long* __restrict__ bsum, unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand,
+       StepState* __restrict__ st, StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int force,
+       int seq, const unsigned long long* __restrict__ sense_err, int nb) {
+    const int agent = blockIdx.y;
+    fold_and_decide(bsum + (long long)agent * nb * 2 * A, ctmp + (long long)agent * kTmpCap * 2, cand + (long long)agent * kCandCap,
+                    st + agent, out + agent, rec + (long long)agent * (3 + 4 * kMaxHeadings), c, A, delta, force, seq, sense_err, agent, nb);
 }
 
 // One single-wave block per candidate (a,f): the reference's exact value.  Lanes compute the per-pixel

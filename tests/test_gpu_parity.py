@@ -1011,3 +1011,40 @@ def test_matrix_core_kernel_forms_under_repetition(variant):
             assert got["best_view"] == (it * 997) % F and got["best_idex"] == it % A, it
     finally:
         e.close()
+
+
+def test_ties_inside_one_finishing_block_of_several_view_sets():
+    """On large libraries a k_finish block owns several consecutive sets of 256 views and keeps ONE representative per
+    heading; a set's representative that loses to a later set's must still reach the candidate list.  The best view is
+    duplicated in two sets of the same block (and far away), seen by two headings: the decision, every per-heading
+    maximum and the candidate count must be the oracle's / the two-kernel ending's."""
+    import os
+    F, h, w, A, cw = 300000, 4, 4, 20, 0.25                     # 300 000 views -> 3 view sets per block
+    lib = synth.synth_views(29, F, h, w)
+    star = lib[100000].copy()
+    star[0, 0] = (77, 200, 13)
+    dup = (2 * 768 + 700, 2 * 768 + 10, 2 * 768 + 300, 200000, 299999)       # three in block 2 (sets 2, 0, 1), two elsewhere
+    for f in dup:
+        lib[f] = star
+    pats = synth.synth_patches(29, A, h, w)
+    pats[7] = pats[18] = star
+    want = oracle.step(lib, pats, cw)
+    assert (want["best_idex"], want["best_view"]) == (7, min(dup))
+    seen = {}
+    for finish in ("2", "0"):
+        os.environ["DEJAVU_FINISH"] = finish
+        try:
+            e = navsim_amd.FamiliarityEngine(0)
+        finally:
+            os.environ.pop("DEJAVU_FINISH", None)
+        try:
+            e.set_library(lib, cw)
+            r = e.step(pats, want_scene=True)
+            assert (r["best_idex"], r["best_view"]) == (want["best_idex"], want["best_view"]), finish
+            np.testing.assert_allclose(r["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+            np.testing.assert_allclose(r["scene_familiarity"], want["scene_familiarity"], rtol=RTOL)
+            assert r["flags"] & 1                                   # resolved exactly
+            seen[finish] = r["n_candidates"]
+        finally:
+            e.close()
+    assert seen["2"] == seen["0"] >= 2 * len(dup)
