@@ -132,6 +132,11 @@ struct dv_ctx {
     int mfma_variant_env = 0;                 // DEJAVU_MFMA_VARIANT: other forms of the matrix-core kernel (A/B runs), see launch_mfma
     const int* int_hsconst = nullptr;         // constants that go with the partial sums of the last integer scoring pass
     const int* int_vconst = nullptr;
+    bool fuse_request = false;                // enqueue_step: this pass may finish its scores inside the scoring kernel
+    int fuse_want_scene = 0;
+    bool epilogue_fused = false;              // the last integer scoring pass finished its scores itself (k_sad_mfma_ring<.., true>): only k_fold is left
+    int fuse_env = 0;                         // DEJAVU_FUSE=1: one-chunk matrix-core passes finish their scores themselves (measured slower)
+    int fused_nb = 0;                         // summaries per agent it left
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -263,6 +268,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
     env_int("DEJAVU_FENCED", c->fenced_env, 0, 1);
     env_int("DEJAVU_FINISH_VB", c->finish_vb_env, 0, 16);
+    env_int("DEJAVU_FUSE", c->fuse_env, 0, 1);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -1345,22 +1351,47 @@ static void launch_mfma_variant(dv_ctx* c, int nchunk, int has_hs) {
                            c->APAD, a_off, has_hs);
 }
 
-template <int SK, int TILES, int RD>
-static void launch_mfma_ring(dv_ctx* c, int nchunk, int has_hs) {
+template <int SK, int TILES, int RD, bool FUSE>
+static void launch_mfma_ring_f(dv_ctx* c, int nchunk, int has_hs, const FuseArgs& fz_in) {
     static bool attr_set = false;
-    const size_t lds = (size_t)RD * (SK * 8 + 8 * SK * TILES) * 1024;
+    size_t lds = (size_t)RD * (SK * 8 + 8 * SK * TILES) * 1024;
+    if (FUSE) lds += (TILES == 1 ? 0 : (size_t)8 * TILES * 16 * 64 * 4) + (size_t)8 * TILES * 32 * 8 * 2 + 4 * 32 * 8;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_sad_mfma_ring<SK, TILES, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma_ring<SK, TILES, RD, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long long G32 = c->cfg.Fpad / 32;
     const long long items = ((G32 + 8 * TILES - 1) / (8 * TILES)) * nchunk;
     const unsigned grid = (unsigned)(items < 256 ? items : 256);
     const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
+    FuseArgs fz = fz_in;
+    fz.nb = (int)items;
     for (int a_off = 0; a_off < c->APAD; a_off += 32)
-        hipLaunchKernelGGL((k_sad_mfma_ring<SK, TILES, RD>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+        hipLaunchKernelGGL((k_sad_mfma_ring<SK, TILES, RD, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->d_coef + (size_t)(a_off / 32) * nkt * 512, reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk,
-                           c->APAD, a_off, has_hs);
+                           c->APAD, a_off, has_hs, fz);
+    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)items; }
+}
+
+template <int SK, int TILES, int RD>
+static void launch_mfma_ring(dv_ctx* c, int nchunk, int has_hs) {
+    // One chunk and a step that may end in k_fold: the kernel finishes its scores itself.
+    if (c->fuse_request && nchunk == 1 && c->fuse_env) {
+        FuseArgs fz{};
+        fz.hsconst = c->d_bconst;
+        fz.vconst = c->d_bconst + kMaxHeadings;
+        fz.bsum = c->d_bsum;
+        fz.ctmp = c->d_ctmp;
+        fz.st = c->d_state;
+        fz.scene = c->d_scene;
+        fz.A_real = c->A;
+        fz.A_agent = c->A_agent;
+        fz.want_scene = c->fuse_want_scene;
+        fz.delta = c->delta;
+        launch_mfma_ring_f<SK, TILES, RD, true>(c, nchunk, has_hs, fz);
+    } else {
+        launch_mfma_ring_f<SK, TILES, RD, false>(c, nchunk, has_hs, FuseArgs{});
+    }
 }
 
 // Work items of k_sad_mfma = (chunk of K-steps, 8*TILES view groups of 32).  Two view groups per wave halve the
@@ -1416,6 +1447,7 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial,
     int has_hs_sum, has_v_sum = g.hasv;
     c->int_hsconst = c->d_hsconst;
     c->int_vconst = nullptr;
+    c->epilogue_fused = false;                           // set again below by a pass that finishes its own scores
     if (!g.generic && shape_now(c) == 6) {
         if (!c->coef_ready) { const int rc = enqueue_bit_prep(c, true); if (rc) return rc; }
         has_hs_sum = g.nhs > 0 ? 1 : 0;
@@ -1444,6 +1476,7 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial,
     if (after_tiles) HIP_TRY(c, hipEventRecord(after_tiles, c->stream));
     c->int_has_hs = has_hs_sum;
     c->int_has_v = has_v_sum;
+    if (c->epilogue_fused) return DV_OK;                 // the scoring kernel finished its scores itself: only k_fold is left
     if (!with_combine) return DV_OK;                     // the step ends in k_finish, which does the combining itself
     *n_partial = (int)((g.Fpad + 1023) / 1024);
     hipLaunchKernelGGL(k_combine, dim3((unsigned)*n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_part, c->int_hsconst,
@@ -1462,6 +1495,10 @@ static int tune_workgroup_shape(dv_ctx* c) {
     const int cls = apad_class(c->APAD);
     float best = 0.f;
     int rc = DV_OK, pick = 1, np = 0;
+    // the timing passes never finish their scores themselves: a fused epilogue appends candidates that only k_fold
+    // clears, and the shapes are compared on scoring + k_combine
+    const bool fuse_request = c->fuse_request;
+    c->fuse_request = false;
     for (int sh = 1; sh <= kMaxShape && rc == DV_OK; ++sh) {
         if (!shape_valid(c, cls, sh)) continue;
         c->force_shape = sh;
@@ -1478,6 +1515,8 @@ static int tune_workgroup_shape(dv_ctx* c) {
         }
     }
     c->force_shape = 0;
+    c->fuse_request = fuse_request;
+    c->epilogue_fused = false;
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
     if (rc == DV_ERR_HIP) return fail(c, DV_ERR_HIP, "timing the workgroup shapes failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1615,10 +1654,21 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     // one wave per SIMD): 1103 vs 1029 us at 200 000 views; 8-16 headings on 20 000 views: 1-2 us slower.
     const bool fused = c->metric == 0 && !c->exact && c->A_agent <= 32 &&
                        (c->finish_fused == 2 || (c->finish_fused == 1 && g.F >= 32768 && (c->A_agent <= 16 || g.F >= 131072)));
+    // With one chunk the matrix-core kernel can finish its scores in its own epilogue (k_sad_mfma_ring<.., FUSE>): the
+    // partial sums never reach HBM and the step ends in k_fold alone.  scene_fam needs all of a view's headings in one
+    // pass, i.e. at most 32 resident headings.
+    c->fuse_request = c->metric == 0 && !c->exact && (!scene_on || c->APAD <= 32) && (!want_scene || scene_on);
+    c->fuse_want_scene = scene_on;
+    c->epilogue_fused = false;
     int rc = launch_scoring(c, !fused);
+    c->fuse_request = false;
     if (rc) return rc;
     Range range("dv:finish");
-    if (fused) {
+    if (c->epilogue_fused) {
+        hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3(1024), 0, c->stream, c->d_bsum, c->d_ctmp, c->d_cand, c->d_state,
+                           c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,
+                           c->A_agent, c->delta, force, ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->fused_nb);
+    } else if (fused) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
         else launch_finish<2>(c, scene_on, force);
     } else {

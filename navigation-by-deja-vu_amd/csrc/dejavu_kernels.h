@@ -2283,56 +2283,6 @@ k_sad_mfma(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int
     }
 }
 
-// ------------------------------------------------------------------ error / coverage metrics of the agent
-// update_error of the reference (navsim/NavBySceneFamiliarity.py:252-276) for one position: the distance to every
-// training point in the reference's double arithmetic (delta*delta summed, sqrt; no contraction), its minimum, and
-// the coverage marks `dist <= reach` (the reference ORs them in only when the minimum is within reach, which is the
-// same set: no distance is within reach unless the smallest is).  The last block to arrive hands {nearest, seq} to the
-// host through mapped memory.  Off the step's critical path: the host collects the answer one step later.
-struct PathErrState { unsigned long long minkey; unsigned ticket; unsigned pad; };
-struct alignas(16) PathErrOut { double nearest; unsigned long long seq; };
-
-__global__ void __launch_bounds__(256)
-k_path_error(const double* __restrict__ xy, long long n, double x, double y, double reach, unsigned char* __restrict__ cover,
-             PathErrState* __restrict__ st, PathErrOut* __restrict__ out, unsigned long long seq) {
-    __shared__ unsigned long long wmin[4];
-    unsigned long long key = ~0ull;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        double dx = xy[2 * i] - x, dy = xy[2 * i + 1] - y;
-        dx *= dx;
-        dy *= dy;
-        const double dist = sqrt(dx + dy);
-        if (dist <= reach) cover[i] = 1;
-        const unsigned long long k = (unsigned long long)__double_as_longlong(dist);     // dist >= 0: bit order = value order
-        key = k < key ? k : key;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o);
-        key = other < key ? other : key;
-    }
-    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long m = wmin[0];
-        for (int i = 1; i < 4; ++i) m = wmin[i] < m ? wmin[i] : m;
-        atomicMin(&st->minkey, m);
-        __threadfence();
-        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
-            __threadfence();
-            const unsigned long long all = __hip_atomic_load(&st->minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&st->minkey, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // answer and sequence number leave in ONE 16-byte store to the mapped host record (one PCIe write: the host,
-            // which polls the sequence word and then reads the answer, can never pair a new number with an old answer),
-            // so no system-scope fence sits between them
-            v4u_t rec;
-            rec.x = (unsigned)all; rec.y = (unsigned)(all >> 32); rec.z = (unsigned)seq; rec.w = (unsigned)(seq >> 32);
-            *reinterpret_cast<v4u_t*>(out) = rec;
-        }
-    }
-}
-
 // The same scoring with BOTH operands streamed through LDS rings by LDS-DMA (global_load_lds, no destination
 // registers) RD stages deep, and every vector-memory wait counted by hand:
 //   stage = SK K-steps; per stage a wave fetches its share of the coefficient rows (SK*8 rows of 1 KB over the 8 waves)
@@ -2361,11 +2311,29 @@ __device__ __forceinline__ void lds_dma_16_nt(const uint4* gsrc, unsigned lds_by
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int SK, int TILES, int RD>
+// With one chunk the sums of an item never leave the workgroup: FUSE = true turns them into scores right here (k_finish's
+// arithmetic, operation for operation), reduces them to the item's summary per heading -- maximum and first view -- and
+// lists candidates against the item's own best (the superset rule of k_finish); k_fold behind the kernel folds the
+// summaries and decides.  The partial sums then cross HBM not at all, and k_finish / k_combine + k_tail drop out of the step.
+struct FuseArgs {
+    const int* hsconst;             // per-heading constants of the two sums (k_bit_prep)
+    const int* vconst;
+    unsigned long long* bsum;       // [agents][nb][2][A_agent] item summaries
+    unsigned long long* ctmp;       // [agents][kTmpCap][2] shared extra-candidate lists
+    StepState* st;                  // [agents]
+    double* scene;                  // [F] min over headings per view (single agent, want_scene)
+    int A_real;                     // resident headings
+    int A_agent;                    // headings per agent
+    int nb;                         // items = summaries per agent
+    int want_scene;
+    double delta;
+};
+
+template <int SK, int TILES, int RD, bool FUSE>
 __global__ void __launch_bounds__(512, 2)
 k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, LibCfg c, BitCfg b,
-                int nchunk, int apad_total, int a_off, int has_hs_sum) {
-    extern __shared__ uint4 lds_ring[];           // [RD][ coefficient rows SK*8 | library rows 8 waves * SK * TILES ][64]
+                int nchunk, int apad_total, int a_off, int has_hs_sum, FuseArgs fz) {
+    extern __shared__ uint4 lds_ring[];           // [RD][ coefficient rows SK*8 | library rows 8 waves * SK * TILES ][64], then FUSE scratch
     constexpr int NW = 8;
     constexpr int VW = NW * TILES;
     constexpr int COEF_ROWS = SK * 8;             // per stage
@@ -2395,6 +2363,9 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
             gidx[t] = g;
             lib[t] = btiles + (g * b.GS) * 64 + lane;
         }
+        constexpr bool PARK_REGS = TILES == 1;            // FUSE: the saturation sums wait in registers (one view group) or LDS (two)
+        int parkr[TILES][16];
+        (void)parkr;
 #pragma unroll 1
         for (int seg = 0; seg < 2; ++seg) {
             if (seg == 0 && !has_hs_sum) continue;
@@ -2482,18 +2453,205 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
             }
             const int type_row = seg ? has_hs_sum : 0;
             const int nsum = has_hs_sum + c.hasv;
+            int tot[TILES][16];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                if (live[t]) {
-                    int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+            for (int t = 0; t < TILES; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int tot = acc[t][0][r] + (acc[t][1][r] >> 1) + (acc[t][2][r] >> 2) + (acc[t][3][r] >> 3);
-                        if (m < rows) dst[(long long)m * c.Fpad] = tot;
+                for (int r = 0; r < 16; ++r)
+                    tot[t][r] = acc[t][0][r] + (acc[t][1][r] >> 1) + (acc[t][2][r] >> 2) + (acc[t][3][r] >> 3);
+            if constexpr (!FUSE) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    if (live[t]) {
+                        int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            if (m < rows) dst[(long long)m * c.Fpad] = tot[t][r];
+                        }
                     }
                 }
+            } else {
+                // ---- fused finishing (one chunk): scratch behind the rings
+                int* park = reinterpret_cast<int*>(lds_ring + RD * SLOT16);                        // [NW][TILES][16][64] (two view groups per wave)
+                unsigned long long* sum_key = reinterpret_cast<unsigned long long*>(park + (PARK_REGS ? 0 : NW * TILES * 16 * 64));   // [NW*TILES][32]
+                unsigned long long* sum_view = sum_key + NW * TILES * 32;
+                unsigned long long* item_key = sum_view + NW * TILES * 32;                           // [32]
+                unsigned long long* item_view = item_key + 32;
+                unsigned long long* abest = item_view + 32;                                           // [32] per agent of the pass
+                unsigned long long* thr_m = abest + 32;                                               // [32] per heading
+                if (seg == 0 && c.hasv) {
+                    // the saturation sums wait in LDS for the value sums (this wave's own words: no barrier)
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if constexpr (PARK_REGS) parkr[t][r] = tot[t][r];
+                            else park[((wave * TILES + t) * 16 + r) * 64 + lane] = tot[t][r];
+                        }
+                } else {
+                    const int half = lane >> 5, n = lane & 31;
+                    const int agent0 = a_off / fz.A_agent;
+                    if (threadIdx.x < 32) abest[threadIdx.x] = 0;
+                    // score of (view group t, accumulator register r) of this lane, as an ordered key (0: no such heading or
+                    // view); k_finish's arithmetic, operation for operation.  Recomputed where it is needed: nothing but the
+                    // integer sums stays in registers across the barriers below.
+                    auto score = [&](int t, int r, bool inb, double& val, bool& valid) -> unsigned long long {
+                        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int a = a_off + m;
+                        valid = a < fz.A_real;
+                        const int ac = valid ? a : fz.A_real - 1;
+                        int hs = 0, v = 0;
+                        if (has_hs_sum) {
+                            if (seg == 0) hs = tot[t][r];
+                            else if constexpr (PARK_REGS) hs = parkr[t][r];
+                            else hs = park[((wave * TILES + t) * 16 + r) * 64 + lane];
+                        }
+                        if (c.hasv) v = tot[t][r];
+                        const long long shs = (long long)fz.hsconst[ac] + (long long)hs;
+                        const long long sv = (long long)(fz.vconst ? fz.vconst[ac] : 0) + (long long)v;
+                        double sc = c.whs * (double)shs;
+                        if (c.hasv) sc = sc + c.wv * (double)sv;
+                        val = (double)c.P - sc / 255.;
+                        return (valid && inb) ? ordered_key(val) : 0ull;
+                    };
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        const long long f = gidx[t] * 32 + n;
+                        const bool inb = live[t] && f < c.F;
+                        double smin = __longlong_as_double(0x7ff0000000000000ll);
+                        // per heading: maximum over this half's 32 views and the first view attaining it
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            double val;
+                            bool valid;
+                            const unsigned long long k = score(t, r, inb, val, valid);
+                            if (valid) smin = val < smin ? val : smin;
+                            unsigned long long mk = k;
+#pragma unroll
+                            for (int o = 16; o > 0; o >>= 1) {
+                                const unsigned long long other = __shfl_xor(mk, o);
+                                mk = other > mk ? other : mk;
+                            }
+                            const unsigned long long hit = __ballot(mk != 0 && k == mk);
+                            const unsigned mine = half ? (unsigned)(hit >> 32) : (unsigned)hit;
+                            if (n == 0) {
+                                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                                sum_key[(wave * TILES + t) * 32 + m] = mk;
+                                sum_view[(wave * TILES + t) * 32 + m] = mk ? (unsigned long long)(gidx[t] * 32 + (__ffs(mine) - 1)) : ~0ull;
+                            }
+                        }
+                        if (fz.want_scene) {                       // single agent, one pass: both halves hold half of the headings
+                            const double other = __shfl_xor(smin, 32);
+                            smin = other < smin ? other : smin;
+                            if (half == 0 && inb) fz.scene[f] = smin;
+                        }
+                    }
+                    __syncthreads();
+                    if (threadIdx.x < 32) {                        // thread m: the item's summary of heading a_off + m
+                        const int m = threadIdx.x, a = a_off + m;
+                        unsigned long long bk = 0, bv = ~0ull;
+                        if (a < fz.A_real) {
+                            for (int i = 0; i < NW * TILES; ++i) {
+                                const unsigned long long k = sum_key[i * 32 + m], v = sum_view[i * 32 + m];
+                                if (k > bk || (k == bk && k != 0 && v < bv)) { bk = k; bv = v; }
+                            }
+                            const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
+                            unsigned long long* bs = fz.bsum + ((long long)agent * fz.nb + gq) * 2 * fz.A_agent;
+                            bs[kk] = bk;
+                            bs[fz.A_agent + kk] = bv;
+                            if (bk) atomicMax(&abest[agent - agent0], bk);
+                        }
+                        item_key[m] = bk;
+                        item_view[m] = bv;
+                    }
+                    __syncthreads();
+                    if (threadIdx.x < 32) {
+                        const int a = a_off + (int)threadIdx.x;
+                        unsigned long long tk = ~0ull;
+                        if (a < fz.A_real) {
+                            const unsigned long long best = abest[a / fz.A_agent - agent0];
+                            tk = best ? ordered_key(key_to_double(best) - fz.delta) : ~0ull;
+                        }
+                        thr_m[threadIdx.x] = tk;
+                    }
+                    __syncthreads();
+                    // candidates: everything within delta of the item's best (per agent) that is not a representative
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        const long long f = gidx[t] * 32 + n;
+                        const bool inb = live[t] && f < c.F;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                            double val;
+                            bool valid;
+                            const unsigned long long k = score(t, r, inb, val, valid);
+                            if (k != 0 && k >= thr_m[m] && !(k == item_key[m] && (unsigned long long)f == item_view[m])) {
+                                const int a = a_off + m;
+                                const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
+                                const unsigned pos = __hip_atomic_fetch_add(&fz.st[agent].ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (pos < (unsigned)kTmpCap) {
+                                    unsigned long long* ct = fz.ctmp + (long long)agent * kTmpCap * 2;
+                                    ct[2 * pos] = ((unsigned long long)kk << 40) | (unsigned long long)f;
+                                    ct[2 * pos + 1] = k;
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();               // the scratch is reused by the next item
+                }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ error / coverage metrics of the agent
+// update_error of the reference (navsim/NavBySceneFamiliarity.py:252-276) for one position: the distance to every
+// training point in the reference's double arithmetic (delta*delta summed, sqrt; no contraction), its minimum, and
+// the coverage marks `dist <= reach` (the reference ORs them in only when the minimum is within reach, which is the
+// same set: no distance is within reach unless the smallest is).  The last block to arrive hands {nearest, seq} to the
+// host through mapped memory.  Off the step's critical path: the host collects the answer one step later.
+struct PathErrState { unsigned long long minkey; unsigned ticket; unsigned pad; };
+struct alignas(16) PathErrOut { double nearest; unsigned long long seq; };
+
+__global__ void __launch_bounds__(256)
+k_path_error(const double* __restrict__ xy, long long n, double x, double y, double reach, unsigned char* __restrict__ cover,
+             PathErrState* __restrict__ st, PathErrOut* __restrict__ out, unsigned long long seq) {
+    __shared__ unsigned long long wmin[4];
+    unsigned long long key = ~0ull;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double dx = xy[2 * i] - x, dy = xy[2 * i + 1] - y;
+        dx *= dx;
+        dy *= dy;
+        const double dist = sqrt(dx + dy);
+        if (dist <= reach) cover[i] = 1;
+        const unsigned long long k = (unsigned long long)__double_as_longlong(dist);     // dist >= 0: bit order = value order
+        key = k < key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmin[0];
+        for (int i = 1; i < 4; ++i) m = wmin[i] < m ? wmin[i] : m;
+        atomicMin(&st->minkey, m);
+        __threadfence();
+        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const unsigned long long all = __hip_atomic_load(&st->minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->minkey, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // answer and sequence number leave in ONE 16-byte store to the mapped host record (one PCIe write: the host,
+            // which polls the sequence word and then reads the answer, can never pair a new number with an old answer),
+            // so no system-scope fence sits between them
+            v4u_t rec;
+            rec.x = (unsigned)all; rec.y = (unsigned)(all >> 32); rec.z = (unsigned)seq; rec.w = (unsigned)(seq >> 32);
+            *reinterpret_cast<v4u_t*>(out) = rec;
         }
     }
 }
