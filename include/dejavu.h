@@ -96,7 +96,7 @@ typedef struct dv_lib_info {
     int32_t bit_planes_hs;      /* thermometer planes of the saturation bytes (0: no bit-plane copy, or none needed) */
     int32_t bit_planes_v;       /* thermometer planes of the value byte */
     int32_t has_bit_planes;     /* 1: the bit-plane copy exists (scoring shape 6 is available) */
-    int32_t reserved_;
+    int32_t fp4_form;           /* 1: the planes also allow the fp4 form of that kernel (on-level patches, see dv_patches_on_level) */
     int64_t bit_tile_bytes;     /* bytes the matrix-core scoring kernel streams per pass */
 } dv_lib_info;
 
@@ -326,6 +326,13 @@ int dv_stream_read_gbps(dv_ctx *ctx, int64_t n_bytes, int iters, double *gbps);
  */
 int dv_range_push(const char *name);
 int dv_range_pop(void);
+
+/* 1 when the resident patches have every byte on one of the library's levels (or outside their range), i.e. the last
+ * coefficient prep allowed the fp4 form of the matrix-core kernel; 0 when a byte lies strictly inside a gap (the int8
+ * form scored or will score them); DV_ERR_STATE when the library has no fp4 form or no patches were prepared for it.
+ * Waits for the stream.  Diagnostic: the kernel itself reads the same word on the device, nothing on the host decides.
+ * (The reference has no counterpart; its patches come out of the quantiser of NavBySceneFamiliarity.py:176-186.) */
+int dv_patches_on_level(dv_ctx *ctx);
 
 const char *dv_version(void);
 

@@ -133,9 +133,15 @@ struct dv_ctx {
     const int* int_hsconst = nullptr;         // constants that go with the partial sums of the last integer scoring pass
     const int* int_vconst = nullptr;
     bool fuse_request = false;                // enqueue_step: this pass may finish its scores inside the scoring kernel
-    int fuse_want_scene = 0;
     bool epilogue_fused = false;              // the last integer scoring pass finished its scores itself (k_sad_mfma_ring<.., true>): only k_fold is left
-    int fuse_env = 0;                         // DEJAVU_FUSE=1: one-chunk matrix-core passes finish their scores themselves (measured slower)
+    // fp4 form of the matrix-core kernel (sad_ring_fp4): possible when every plane of a segment has one gap width
+    bool fp4_ok = false;                      // this library's planes qualify (build_bit_planes)
+    int fp4_env = 1;                          // DEJAVU_FP4=0: never
+    uint4* d_coef4 = nullptr;                 // [pass][K-step][4][64] E2M1 sign images (k_bit_prep)
+    unsigned* d_offlevel = nullptr;           // [2]: nonzero = the patches of that prep have a byte strictly inside a gap
+    int prep_seq = 0;                         // preps so far: word prep_seq & 1 belongs to the latest
+    int fp4_variant_env = 0;                  // DEJAVU_FP4_VARIANT: A/B of the ring shapes
+    int fuse_env = 1;                         // DEJAVU_FUSE=0: one-chunk matrix-core passes leave their sums to k_finish instead of finishing them
     int fused_nb = 0;                         // summaries per agent it left
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
@@ -220,7 +226,7 @@ static void free_library(dv_ctx* c) {
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
-    F(c->d_btiles); F(c->d_coef); F(c->d_bconst);
+    F(c->d_btiles); F(c->d_coef); F(c->d_bconst); F(c->d_coef4); F(c->d_offlevel);
     c->bits_ok = false; c->coef_ready = false; c->btile_bytes = 0;
     c->metric = 0;
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
@@ -269,6 +275,8 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_FENCED", c->fenced_env, 0, 1);
     env_int("DEJAVU_FINISH_VB", c->finish_vb_env, 0, 16);
     env_int("DEJAVU_FUSE", c->fuse_env, 0, 1);
+    env_int("DEJAVU_FP4", c->fp4_env, 0, 1);
+    env_int("DEJAVU_FP4_VARIANT", c->fp4_variant_env, 0, 8);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -435,6 +443,7 @@ static long long group_stride(const dv_ctx* c, long long kb) {
 static int build_bit_planes(dv_ctx* c) {
     const LibCfg& g = c->cfg;
     c->bits_ok = false;
+    c->fp4_ok = false;
     if (c->bits_env == 0 || c->metric != 0 || g.generic) return DV_OK;
     unsigned* d_presence = nullptr;
     uint32_t presence[(kMaxHues + 1) * 8];
@@ -474,6 +483,17 @@ static int build_bit_planes(dv_ctx* c) {
     for (int seg = 0; seg < 2; ++seg) b.NK[seg] = (int)(((long long)b.T[seg] * g.P + 255) / 256);
     const int nkt = b.NK[0] + b.NK[1];
     b.GS = nkt | 1;
+    // fp4 form of the kernel: the planes that land on bit b of a nibble (K-element n = plane n % T on bit n % 4) share a width
+    bool one_width = true;
+    for (int seg = 0; seg < 2; ++seg) {
+        const int first = seg ? b.T[0] : 0, T = b.T[seg];
+        for (int bit = 0; bit < 4; ++bit) {
+            b.wacc[seg][bit] = T ? b.w[first + bit % T] : 0;
+            for (int k = 0; k < T; ++k)                                  // (bit + 4k) % T runs through every plane on this bit
+                if (T && b.w[first + (bit + 4 * k) % T] != b.wacc[seg][bit]) one_width = false;
+        }
+    }
+    c->fp4_ok = one_width && c->fp4_env != 0;
     const long long G32 = g.Fpad / 32;
     c->btile_bytes = (size_t)G32 * nkt * 1024;
     if (hipMalloc(&c->d_btiles, (size_t)G32 * b.GS * 1024) != hipSuccess || hipMalloc(&c->d_coef, (size_t)2 * nkt * 8192) != hipSuccess ||
@@ -483,6 +503,11 @@ static int build_bit_planes(dv_ctx* c) {
         if (c->d_coef) { (void)hipFree(c->d_coef); c->d_coef = nullptr; }
         if (c->d_bconst) { (void)hipFree(c->d_bconst); c->d_bconst = nullptr; }
         return DV_OK;
+    }
+    if (c->fp4_ok && (hipMalloc(&c->d_coef4, (size_t)2 * nkt * 4096) != hipSuccess || hipMalloc(&c->d_offlevel, 2 * sizeof(unsigned)) != hipSuccess ||
+                      hipMemsetAsync(c->d_offlevel, 0, 2 * sizeof(unsigned), c->stream) != hipSuccess)) {
+        (void)hipGetLastError();
+        c->fp4_ok = false;                                              // the int8 form alone
     }
     c->bcfg = b;
     const long long total_t = G32 * nkt * 64;
@@ -501,8 +526,9 @@ static int enqueue_bit_prep(dv_ctx* c, bool force = false) {
     if (!c->bits_ok || !(force || mfma_path_possible(c))) return DV_OK;
     const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
     const int npass = c->APAD > 32 ? 2 : 1;
+    ++c->prep_seq;
     hipLaunchKernelGGL(k_bit_prep, dim3((unsigned)(nkt * npass + c->A)), dim3(512), 0, c->stream, c->d_raw_patches, c->d_coef,
-                       c->d_bconst, c->cfg, c->bcfg, c->A, npass);
+                       c->d_bconst, c->cfg, c->bcfg, c->A, npass, c->fp4_ok ? c->d_coef4 : nullptr, c->d_offlevel, c->prep_seq & 1);
     HIP_TRY(c, hipGetLastError());
     c->coef_ready = true;
     return DV_OK;
@@ -1092,6 +1118,17 @@ extern "C" int dv_generate_library(dv_ctx* c, uint64_t seed, int64_t F, int h, i
     return DV_OK;
 }
 
+extern "C" int dv_patches_on_level(dv_ctx* c) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib || !c->bits_ok || !c->fp4_ok) return fail(c, DV_ERR_STATE, "this library has no fp4 form");
+    if (!c->coef_ready) return fail(c, DV_ERR_STATE, "no coefficient image of the resident patches yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned word = 0;
+    HIP_TRY(c, hipMemcpyAsync(&word, c->d_offlevel + (c->prep_seq & 1), sizeof word, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return word == 0 ? 1 : 0;
+}
+
 extern "C" int dv_clear_library(dv_ctx* c) {
     if (!c) return DV_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1120,6 +1157,7 @@ extern "C" int dv_get_library_info(const dv_ctx* c, dv_lib_info* o) {
     o->n_hues = 0;
     if (c->cfg.cw > 0.0 && !c->cfg.generic) o->n_hues = c->cfg.signed_s ? 2 : c->cfg.nhs;
     o->has_bit_planes = c->bits_ok ? 1 : 0;
+    o->fp4_form = (c->bits_ok && c->fp4_ok) ? 1 : 0;
     o->bit_planes_hs = c->bits_ok ? c->bcfg.T[0] : 0;
     o->bit_planes_v = c->bits_ok ? c->bcfg.T[1] : 0;
     o->bit_tile_bytes = c->bits_ok ? (int64_t)c->btile_bytes : 0;
@@ -1351,11 +1389,24 @@ static void launch_mfma_variant(dv_ctx* c, int nchunk, int has_hs) {
                            c->APAD, a_off, has_hs);
 }
 
+static FuseArgs fuse_args(const dv_ctx* c) {
+    FuseArgs fz{};
+    fz.hsconst = c->d_bconst;
+    fz.vconst = c->d_bconst + kMaxHeadings;
+    fz.bsum = c->d_bsum;
+    fz.ctmp = c->d_ctmp;
+    fz.st = c->d_state;
+    fz.A_real = c->A;
+    fz.A_agent = c->A_agent;
+    fz.delta = c->delta;
+    return fz;
+}
+
 template <int SK, int TILES, int RD, bool FUSE>
 static void launch_mfma_ring_f(dv_ctx* c, int nchunk, int has_hs, const FuseArgs& fz_in) {
     static bool attr_set = false;
     size_t lds = (size_t)RD * (SK * 8 + 8 * SK * TILES) * 1024;
-    if (FUSE) lds += (TILES == 1 ? 0 : (size_t)8 * TILES * 16 * 64 * 4) + (size_t)8 * TILES * 32 * 8 * 2 + 4 * 32 * 8;
+    if (FUSE) lds += (size_t)kFuseScratchBytes;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_sad_mfma_ring<SK, TILES, RD, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
@@ -1377,21 +1428,40 @@ template <int SK, int TILES, int RD>
 static void launch_mfma_ring(dv_ctx* c, int nchunk, int has_hs) {
     // One chunk and a step that may end in k_fold: the kernel finishes its scores itself.
     if (c->fuse_request && nchunk == 1 && c->fuse_env) {
-        FuseArgs fz{};
-        fz.hsconst = c->d_bconst;
-        fz.vconst = c->d_bconst + kMaxHeadings;
-        fz.bsum = c->d_bsum;
-        fz.ctmp = c->d_ctmp;
-        fz.st = c->d_state;
-        fz.scene = c->d_scene;
-        fz.A_real = c->A;
-        fz.A_agent = c->A_agent;
-        fz.want_scene = c->fuse_want_scene;
-        fz.delta = c->delta;
+        const FuseArgs fz = fuse_args(c);
         launch_mfma_ring_f<SK, TILES, RD, true>(c, nchunk, has_hs, fz);
     } else {
         launch_mfma_ring_f<SK, TILES, RD, false>(c, nchunk, has_hs, FuseArgs{});
     }
+}
+
+// Both forms in one launch (k_sad_mfma_dual): the fp4 form when this prep's patches sit on the library's levels.
+template <int SK8, int RD8, int SK4, int RD4, int TILES, bool FUSE>
+static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
+    static bool attr_set = false;
+    const size_t lds8 = (size_t)RD8 * (SK8 * 8 + 8 * SK8 * TILES) * 1024, lds4 = (size_t)RD4 * (SK4 * 4 + 8 * SK4 * TILES) * 1024;
+    const size_t lds = (lds8 > lds4 ? lds8 : lds4) + (FUSE ? (size_t)kFuseScratchBytes : 0);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, TILES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long long G32 = c->cfg.Fpad / 32;
+    const long long items = ((G32 + 8 * TILES - 1) / (8 * TILES)) * nchunk;
+    const unsigned grid = (unsigned)(items < 256 ? items : 256);
+    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
+    FuseArgs fz{};
+    if (FUSE) { fz = fuse_args(c); fz.nb = (int)items; }
+    for (int a_off = 0; a_off < c->APAD; a_off += 32)
+        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, TILES, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+                           c->d_coef + (size_t)(a_off / 32) * nkt * 512, c->d_coef4 + (size_t)(a_off / 32) * nkt * 256,
+                           c->d_offlevel + (c->prep_seq & 1), reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz);
+    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)items; }
+}
+
+template <int SK8, int RD8, int SK4, int RD4, int TILES>
+static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
+    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, TILES, true>(c, nchunk, has_hs);
+    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, TILES, false>(c, nchunk, has_hs);
 }
 
 // Work items of k_sad_mfma = (chunk of K-steps, 8*TILES view groups of 32).  Two view groups per wave halve the
@@ -1421,6 +1491,22 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     // <1,2,3..6> 1.29 ms.  50 000 views x 64x64 x 16 headings, one view group per wave: register-staged, stage of 8
     // K-steps 56.7 us; rings <2,1,4> 50.2, <4,1,2> 46.7, <1,1,6> 50.9 us.
     const int var = c->mfma_variant_env;
+    if (c->fp4_ok && var == 0) {
+        const int v4 = c->fp4_variant_env;
+        if (tiles == 2) {
+            switch (v4) {
+                case 1: launch_mfma_dual<1, 3, 2, 2, 2>(c, nchunk, has_hs); break;
+                default: launch_mfma_dual<1, 3, 2, 3, 2>(c, nchunk, has_hs);
+            }
+        } else {
+            switch (v4) {
+                case 1: launch_mfma_dual<4, 2, 2, 4, 1>(c, nchunk, has_hs); break;
+                case 2: launch_mfma_dual<4, 2, 2, 6, 1>(c, nchunk, has_hs); break;
+                default: launch_mfma_dual<4, 2, 4, 3, 1>(c, nchunk, has_hs);
+            }
+        }
+        return;
+    }
     if (tiles == 2) {
         switch (var) {
             case 1: launch_mfma_variant<2, 2>(c, nchunk, has_hs); break;
@@ -1655,10 +1741,9 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     const bool fused = c->metric == 0 && !c->exact && c->A_agent <= 32 &&
                        (c->finish_fused == 2 || (c->finish_fused == 1 && g.F >= 32768 && (c->A_agent <= 16 || g.F >= 131072)));
     // With one chunk the matrix-core kernel can finish its scores in its own epilogue (k_sad_mfma_ring<.., FUSE>): the
-    // partial sums never reach HBM and the step ends in k_fold alone.  scene_fam needs all of a view's headings in one
-    // pass, i.e. at most 32 resident headings.
-    c->fuse_request = c->metric == 0 && !c->exact && (!scene_on || c->APAD <= 32) && (!want_scene || scene_on);
-    c->fuse_want_scene = scene_on;
+    // partial sums never reach HBM and the step ends in k_fold alone.  Not with scene_fam: its minimum over headings
+    // runs across the lanes there.
+    c->fuse_request = c->metric == 0 && !c->exact && !want_scene;
     c->epilogue_fused = false;
     int rc = launch_scoring(c, !fused);
     c->fuse_request = false;

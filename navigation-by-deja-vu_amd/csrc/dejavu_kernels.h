@@ -1989,6 +1989,7 @@ struct BitCfg {
     int T[2];               // planes of the HS segment and of the V segment
     int NK[2];              // K-steps (256 K-elements) of each segment
     int GS;                 // 1-KB rows between consecutive view groups in btiles (>= NK[0] + NK[1], odd)
+    int wacc[2][4];         // fp4 form (sad_ring_fp4): the one gap width of the planes that land on bit b of a nibble, per segment
     int nbp;                // byte planes described below (= LibCfg::npl)
     unsigned char pl[kMaxBitPlanes];   // byte plane of bit plane t (HS planes first, then V)
     unsigned char lo[kMaxBitPlanes];   // lower level of its gap
@@ -2073,9 +2074,10 @@ k_bitpack(const uint4* __restrict__ tiles, uint4* __restrict__ btiles, LibCfg c,
 //   that does not depend on the view (incl. the hue-outside-the-set and clamped-saturation terms of k_prep).
 __global__ void __launch_bounds__(512)
 k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int* __restrict__ bconst, LibCfg c, BitCfg b,
-           int A, int npass) {
+           int A, int npass, uint4* __restrict__ coef4, unsigned* __restrict__ offlevel, int slot) {
     const int NKT = b.NK[0] + b.NK[1];
     const int ncoef = NKT * npass;
+    if (coef4 && blockIdx.x == 0 && threadIdx.x == 0) offlevel[slot ^ 1] = 0;      // the next prep's word starts clean
     if ((int)blockIdx.x < ncoef) {
         const int pass = blockIdx.x / NKT, ks = blockIdx.x % NKT;
         const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
@@ -2098,6 +2100,30 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
             }
         }
         coef[((long long)blockIdx.x * 8 + s) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (coef4 && s < 4) {
+            // fp4 (E2M1) image of the same K-step: nibble i of dword j = sign of the coefficient of library bit 4i + s of
+            // that dword, +1.0 (0x2) or -1.0 (0xA); the magnitude is the segment's one gap width, multiplied in at the end.
+            // A patch byte strictly inside a gap has no such coefficient: the step then takes the int8 image.
+            unsigned v[4] = {0, 0, 0, 0};
+            bool off = false;
+            if (a < A) {
+                const unsigned char* p = raw + (long long)a * c.P * 3;
+                for (int j = 0; j < 4; ++j) {
+                    const long long n0 = (((long long)ksl * 2 + half) * 4 + j) * 32;
+                    for (int i = 0; i < 8; ++i) {
+                        int plane, px;
+                        if (!bit_element(b, c.P, seg, n0 + 4 * i + s, plane, px)) continue;
+                        const int av = (int)plane_byte(c, b.pl[plane], p[px * 3], p[px * 3 + 1], p[px * 3 + 2]);
+                        const int alpha = av - (int)b.lo[plane];
+                        if (alpha <= 0) v[j] |= 0x2u << (4 * i);
+                        else if (alpha >= (int)b.w[plane]) v[j] |= 0xAu << (4 * i);
+                        else off = true;
+                    }
+                }
+            }
+            coef4[((long long)blockIdx.x * 4 + s) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+            if (off) atomicOr(&offlevel[slot], 1u);
+        }
         return;
     }
     const int a = blockIdx.x - ncoef;
@@ -2321,18 +2347,188 @@ struct FuseArgs {
     unsigned long long* bsum;       // [agents][nb][2][A_agent] item summaries
     unsigned long long* ctmp;       // [agents][kTmpCap][2] shared extra-candidate lists
     StepState* st;                  // [agents]
-    double* scene;                  // [F] min over headings per view (single agent, want_scene)
     int A_real;                     // resident headings
     int A_agent;                    // headings per agent
     int nb;                         // items = summaries per agent
-    int want_scene;
     double delta;
 };
 
+// Fused finishing of one item (FUSE forms).  The accumulators are transposed there (library bits as the A operand of the
+// MFMA): a lane holds ONE heading (a_off + (lane & 31)) and its registers are views, so the reduction over views is an
+// in-lane loop.  The score P - sc / 255 falls as sc = whs * shs + wv * sv rises (k_finish's arithmetic, operation for
+// operation; division by a positive constant and the subtraction are monotone, roundings included), so the maximum over
+// views is taken on sc and only the representatives -- and the few entries near the threshold -- pay for the division:
+//   * per heading, the item leaves the key of its best score and a view attaining it (bsum).  Where several views round
+//     to that same best score, all of them are within delta of it: whichever is the representative, the others are
+//     listed below, and two entries within delta of the step's best send the step to the exact resolver anyway;
+//   * every other entry within delta of the item's best (per agent) goes to the shared list (ctmp).  Such an entry is
+//     either its lane's smallest (kept in two registers) or within the same margin of it: those -- normally a handful
+//     per item, equal sums -- wait in a small LDS queue, so that nothing but a lane's smallest stays in registers across
+//     the barriers.  Both are tested on sc against a bound loose by more than every rounding involved, then on the key.
+//     Past a full queue they go to the shared list untested (k_fold keeps what reaches the step's threshold).
+// `scratch`: LDS, kFuseScratchBytes.  hs / v: the integer sums of this lane (register r = view
+// (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of view group t).
+constexpr int kFuseQueue = 256;
+constexpr int kFuseScratchBytes = (2 * 8 * 32 + 5 * 32 + 2 * kFuseQueue) * 8 + 16;
+
+template <int TILES, int NW, typename HsOf, typename VOf>
+__device__ __forceinline__ void
+fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&live)[TILES],
+             unsigned long long* scratch, const LibCfg& c, const FuseArgs& fz, int a_off, int has_hs_sum, long long gq, int lane, int wave) {
+    static_assert(NW == 8, "scratch layout");
+    unsigned long long* sum_sc = scratch;                      // [NW][32] bits of the (non-negative) sc: bit order = value order
+    unsigned long long* sum_view = sum_sc + NW * 32;
+    unsigned long long* item_view = sum_view + NW * 32;        // [32]
+    unsigned long long* abest = item_view + 32;                // [32] per agent of the pass: bits of its smallest sc
+    unsigned long long* thr_key = abest + 32;                  // [32] per heading
+    unsigned long long* loose_sc = thr_key + 32;               // [32] per heading
+    unsigned long long* q_sc = loose_sc + 32;                  // [kFuseQueue] bits of sc
+    unsigned long long* q_id = q_sc + kFuseQueue;              // [kFuseQueue] heading of the pass << 40 | view
+    unsigned* q_n = reinterpret_cast<unsigned*>(q_id + kFuseQueue);
+    // The lane index is made opaque here: everything below that depends on it is loop-invariant, and the compiler
+    // would otherwise compute it once per kernel and hold it in registers through the scoring loop (48 64-bit values
+    // per lane: the kernel then spills several hundred bytes per lane and reloads them entry by entry).
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5, n = lane & 31;
+    const int agent0 = a_off / fz.A_agent;
+    const int a = a_off + n;
+    const bool valid = a < fz.A_real;
+    const int ac = valid ? a : fz.A_real - 1;
+    const int hsc = fz.hsconst[ac], vc = fz.vconst ? fz.vconst[ac] : 0;
+    if (threadIdx.x < 32) abest[threadIdx.x] = ~0ull;
+    if (threadIdx.x == 32) *q_n = 0;
+    __syncthreads();
+    // score >= best - delta  =>  sc <= sc_best + 255 delta up to roundings of a few ulp of P: loose by far more
+    const double margin = 256. * fz.delta + 256. * (double)c.P * 8.9e-16;
+    const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+    double bs = kInf;                                          // this lane's smallest sc and its entry
+    int bi = 0;                                                // local view index t * 32 + view: ascends with (t, r)
+    int nreal[TILES];                                          // real views of each group: entries [0, nreal)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const long long left = c.F - gidx[t] * 32;
+        nreal[t] = (valid && live[t]) ? (left > 32 ? 32 : (int)left) : 0;
+    }
+    // The sums fit an int32 (build_bit_planes), so (double)(int) is k_finish's (double)(long long) of the same value.
+    auto sc_of = [&](int t, int r) -> double {
+        const int shs = hsc + (has_hs_sum ? hs_of(t, r) : 0);
+        const int sv = vc + (c.hasv ? v_of(t, r) : 0);
+        double sc = c.whs * (double)shs;
+        if (c.hasv) sc = sc + c.wv * (double)sv;
+        return ((r & 3) + 8 * (r >> 2) + 4 * half) < nreal[t] ? sc : kInf;
+    };
+    // One pass for the smallest; `near`: some other entry came within the margin of the smallest so far (a superset of
+    // "within the margin of the final smallest": the smallest only falls) -- rare, and only then are the entries walked
+    // again to queue those within the margin of the final smallest.
+    bool near = false;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double sc = sc_of(t, r);
+            const bool less = sc < bs;                         // "<" keeps the first minimum
+            near |= less ? (bs <= sc + margin) : (sc <= bs + margin && sc != kInf);
+            if (less) { bs = sc; bi = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
+        }
+    if (__any(near)) {
+        const double lim = bs + margin;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int vv = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const double sc = sc_of(t, r);
+                if (sc <= lim && sc != kInf && t * 32 + vv != bi) {      // (a lane without entries has lim = +inf)
+                    const unsigned pos = atomicAdd(q_n, 1u);
+                    if (pos < (unsigned)kFuseQueue) {
+                        q_sc[pos] = (unsigned long long)__double_as_longlong(sc);
+                        q_id[pos] = ((unsigned long long)n << 40) | (unsigned long long)(gidx[t] * 32 + vv);
+                    } else {
+                        // the queue is full (a library of duplicates): straight to the shared list, untested -- k_fold
+                        // keeps what reaches the step's threshold
+                        const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
+                        const unsigned gpos = __hip_atomic_fetch_add(&fz.st[agent].ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (gpos < (unsigned)kTmpCap) {
+                            unsigned long long* ct = fz.ctmp + (long long)agent * kTmpCap * 2;
+                            ct[2 * gpos] = ((unsigned long long)kk << 40) | (unsigned long long)(gidx[t] * 32 + vv);
+                            ct[2 * gpos + 1] = ordered_key((double)c.P - sc / 255.);
+                        }
+                    }
+                }
+            }
+    }
+    unsigned long long own_v = ~0ull;                          // the view of the lane's smallest
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+        if ((bi >> 5) == t) own_v = (unsigned long long)(gidx[t] * 32 + (bi & 31));
+    const double own_s = bs;
+    {
+        const double os = __shfl_xor(bs, 32);
+        const unsigned long long ov = __shfl_xor(own_v, 32);
+        unsigned long long bv = own_v;
+        if (os < bs || (os == bs && ov < bv)) { bs = os; bv = ov; }
+        if (half == 0) { sum_sc[wave * 32 + n] = (unsigned long long)__double_as_longlong(bs); sum_view[wave * 32 + n] = bv; }
+    }
+    __syncthreads();
+    const unsigned long long kNone = 0x7ff0000000000000ull;   // +inf: no entry (sc >= 0: bit order = value order)
+    if (threadIdx.x < 32) {                                    // thread n: the item's summary of heading a_off + n
+        unsigned long long is = kNone, iv = ~0ull;
+        if (valid) {
+            for (int i = 0; i < NW; ++i) {
+                const unsigned long long k = sum_sc[i * 32 + n], w = sum_view[i * 32 + n];
+                if (k < is || (k == is && w < iv)) { is = k; iv = w; }
+            }
+            const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
+            unsigned long long* bsm = fz.bsum + ((long long)agent * fz.nb + gq) * 2 * fz.A_agent;
+            const bool any = is != kNone;
+            bsm[kk] = any ? ordered_key((double)c.P - __longlong_as_double((long long)is) / 255.) : 0ull;
+            bsm[fz.A_agent + kk] = any ? iv : ~0ull;
+            if (any) atomicMin(&abest[agent - agent0], is);
+            if (!any) iv = ~0ull;
+        }
+        item_view[n] = iv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        unsigned long long tk = ~0ull, ls = 0ull;              // nothing passes
+        if (valid) {
+            const unsigned long long best = abest[a / fz.A_agent - agent0];
+            if (best != ~0ull) {
+                const double scb = __longlong_as_double((long long)best);
+                tk = ordered_key(((double)c.P - scb / 255.) - fz.delta);
+                ls = (unsigned long long)__double_as_longlong(scb + margin);
+            }
+        }
+        thr_key[n] = tk;
+        loose_sc[n] = ls;
+    }
+    __syncthreads();
+    auto list = [&](int m, double sc, unsigned long long f) {  // heading a_off + m of the pass, an entry within the loose bound
+        const unsigned long long k = ordered_key((double)c.P - sc / 255.);
+        if (k >= thr_key[m] && f != item_view[m]) {
+            const int am = a_off + m, agent = am / fz.A_agent, kk = am - agent * fz.A_agent;
+            const unsigned pos = __hip_atomic_fetch_add(&fz.st[agent].ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pos < (unsigned)kTmpCap) {
+                unsigned long long* ct = fz.ctmp + (long long)agent * kTmpCap * 2;
+                ct[2 * pos] = ((unsigned long long)kk << 40) | f;
+                ct[2 * pos + 1] = k;
+            }
+        }
+    };
+    if (own_s <= __longlong_as_double((long long)loose_sc[n])) list(n, own_s, own_v);      // (+inf = no entry; the bound is finite)
+    const unsigned qn = *q_n;
+    for (unsigned i = threadIdx.x; i < (qn < (unsigned)kFuseQueue ? qn : (unsigned)kFuseQueue); i += blockDim.x) {
+        const int m = (int)(q_id[i] >> 40);
+        const double sc = __longlong_as_double((long long)q_sc[i]);
+        if (sc <= __longlong_as_double((long long)loose_sc[m])) list(m, sc, q_id[i] & ((1ull << 40) - 1));
+    }
+    __syncthreads();               // the scratch is reused by the next item
+}
+
 template <int SK, int TILES, int RD, bool FUSE>
-__global__ void __launch_bounds__(512, 2)
-k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, LibCfg c, BitCfg b,
-                int nchunk, int apad_total, int a_off, int has_hs_sum, FuseArgs fz) {
+__device__ __forceinline__ void
+sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
+            int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz) {
     extern __shared__ uint4 lds_ring[];           // [RD][ coefficient rows SK*8 | library rows 8 waves * SK * TILES ][64], then FUSE scratch
     constexpr int NW = 8;
     constexpr int VW = NW * TILES;
@@ -2363,7 +2559,6 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
             gidx[t] = g;
             lib[t] = btiles + (g * b.GS) * 64 + lane;
         }
-        constexpr bool PARK_REGS = TILES == 1;            // FUSE: the saturation sums wait in registers (one view group) or LDS (two)
         int parkr[TILES][16];
         (void)parkr;
 #pragma unroll 1
@@ -2443,7 +2638,8 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
                             for (int s = 0; s < 4; ++s) {
                                 const unsigned m = on ? (0x01010101u << s) : 0u;
                                 const v4i_t bo = v4i_t{(int)(src.x & m), (int)(src.y & m), (int)(src.z & m), (int)(src.w & m)};
-                                acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[hs & 1][s], bo, acc[t][s], 0, 0, 0);
+                                if constexpr (FUSE) acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bo, a[hs & 1][s], acc[t][s], 0, 0, 0);   // views x headings
+                                else acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[hs & 1][s], bo, acc[t][s], 0, 0, 0);
                             }
                         }
                     }
@@ -2472,138 +2668,214 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
                     }
                 }
             } else {
-                // ---- fused finishing (one chunk): scratch behind the rings
-                int* park = reinterpret_cast<int*>(lds_ring + RD * SLOT16);                        // [NW][TILES][16][64] (two view groups per wave)
-                unsigned long long* sum_key = reinterpret_cast<unsigned long long*>(park + (PARK_REGS ? 0 : NW * TILES * 16 * 64));   // [NW*TILES][32]
-                unsigned long long* sum_view = sum_key + NW * TILES * 32;
-                unsigned long long* item_key = sum_view + NW * TILES * 32;                           // [32]
-                unsigned long long* item_view = item_key + 32;
-                unsigned long long* abest = item_view + 32;                                           // [32] per agent of the pass
-                unsigned long long* thr_m = abest + 32;                                               // [32] per heading
+                // ---- fused finishing (one chunk): the saturation sums wait in registers for the value sums
                 if (seg == 0 && c.hasv) {
-                    // the saturation sums wait in LDS for the value sums (this wave's own words: no barrier)
 #pragma unroll
                     for (int t = 0; t < TILES; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            if constexpr (PARK_REGS) parkr[t][r] = tot[t][r];
-                            else park[((wave * TILES + t) * 16 + r) * 64 + lane] = tot[t][r];
-                        }
+                        for (int r = 0; r < 16; ++r) parkr[t][r] = tot[t][r];
                 } else {
-                    const int half = lane >> 5, n = lane & 31;
-                    const int agent0 = a_off / fz.A_agent;
-                    if (threadIdx.x < 32) abest[threadIdx.x] = 0;
-                    // score of (view group t, accumulator register r) of this lane, as an ordered key (0: no such heading or
-                    // view); k_finish's arithmetic, operation for operation.  Recomputed where it is needed: nothing but the
-                    // integer sums stays in registers across the barriers below.
-                    auto score = [&](int t, int r, bool inb, double& val, bool& valid) -> unsigned long long {
-                        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const int a = a_off + m;
-                        valid = a < fz.A_real;
-                        const int ac = valid ? a : fz.A_real - 1;
-                        int hs = 0, v = 0;
-                        if (has_hs_sum) {
-                            if (seg == 0) hs = tot[t][r];
-                            else if constexpr (PARK_REGS) hs = parkr[t][r];
-                            else hs = park[((wave * TILES + t) * 16 + r) * 64 + lane];
-                        }
-                        if (c.hasv) v = tot[t][r];
-                        const long long shs = (long long)fz.hsconst[ac] + (long long)hs;
-                        const long long sv = (long long)(fz.vconst ? fz.vconst[ac] : 0) + (long long)v;
-                        double sc = c.whs * (double)shs;
-                        if (c.hasv) sc = sc + c.wv * (double)sv;
-                        val = (double)c.P - sc / 255.;
-                        return (valid && inb) ? ordered_key(val) : 0ull;
-                    };
-#pragma unroll
-                    for (int t = 0; t < TILES; ++t) {
-                        const long long f = gidx[t] * 32 + n;
-                        const bool inb = live[t] && f < c.F;
-                        double smin = __longlong_as_double(0x7ff0000000000000ll);
-                        // per heading: maximum over this half's 32 views and the first view attaining it
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            double val;
-                            bool valid;
-                            const unsigned long long k = score(t, r, inb, val, valid);
-                            if (valid) smin = val < smin ? val : smin;
-                            unsigned long long mk = k;
-#pragma unroll
-                            for (int o = 16; o > 0; o >>= 1) {
-                                const unsigned long long other = __shfl_xor(mk, o);
-                                mk = other > mk ? other : mk;
-                            }
-                            const unsigned long long hit = __ballot(mk != 0 && k == mk);
-                            const unsigned mine = half ? (unsigned)(hit >> 32) : (unsigned)hit;
-                            if (n == 0) {
-                                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                                sum_key[(wave * TILES + t) * 32 + m] = mk;
-                                sum_view[(wave * TILES + t) * 32 + m] = mk ? (unsigned long long)(gidx[t] * 32 + (__ffs(mine) - 1)) : ~0ull;
-                            }
-                        }
-                        if (fz.want_scene) {                       // single agent, one pass: both halves hold half of the headings
-                            const double other = __shfl_xor(smin, 32);
-                            smin = other < smin ? other : smin;
-                            if (half == 0 && inb) fz.scene[f] = smin;
-                        }
-                    }
-                    __syncthreads();
-                    if (threadIdx.x < 32) {                        // thread m: the item's summary of heading a_off + m
-                        const int m = threadIdx.x, a = a_off + m;
-                        unsigned long long bk = 0, bv = ~0ull;
-                        if (a < fz.A_real) {
-                            for (int i = 0; i < NW * TILES; ++i) {
-                                const unsigned long long k = sum_key[i * 32 + m], v = sum_view[i * 32 + m];
-                                if (k > bk || (k == bk && k != 0 && v < bv)) { bk = k; bv = v; }
-                            }
-                            const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
-                            unsigned long long* bs = fz.bsum + ((long long)agent * fz.nb + gq) * 2 * fz.A_agent;
-                            bs[kk] = bk;
-                            bs[fz.A_agent + kk] = bv;
-                            if (bk) atomicMax(&abest[agent - agent0], bk);
-                        }
-                        item_key[m] = bk;
-                        item_view[m] = bv;
-                    }
-                    __syncthreads();
-                    if (threadIdx.x < 32) {
-                        const int a = a_off + (int)threadIdx.x;
-                        unsigned long long tk = ~0ull;
-                        if (a < fz.A_real) {
-                            const unsigned long long best = abest[a / fz.A_agent - agent0];
-                            tk = best ? ordered_key(key_to_double(best) - fz.delta) : ~0ull;
-                        }
-                        thr_m[threadIdx.x] = tk;
-                    }
-                    __syncthreads();
-                    // candidates: everything within delta of the item's best (per agent) that is not a representative
-#pragma unroll
-                    for (int t = 0; t < TILES; ++t) {
-                        const long long f = gidx[t] * 32 + n;
-                        const bool inb = live[t] && f < c.F;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                            double val;
-                            bool valid;
-                            const unsigned long long k = score(t, r, inb, val, valid);
-                            if (k != 0 && k >= thr_m[m] && !(k == item_key[m] && (unsigned long long)f == item_view[m])) {
-                                const int a = a_off + m;
-                                const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
-                                const unsigned pos = __hip_atomic_fetch_add(&fz.st[agent].ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (pos < (unsigned)kTmpCap) {
-                                    unsigned long long* ct = fz.ctmp + (long long)agent * kTmpCap * 2;
-                                    ct[2 * pos] = ((unsigned long long)kk << 40) | (unsigned long long)f;
-                                    ct[2 * pos + 1] = k;
-                                }
-                            }
-                        }
-                    }
-                    __syncthreads();               // the scratch is reused by the next item
+                    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds_ring + RD * SLOT16);
+                    auto of_tot = [&](int t, int r) -> int { return tot[t][r]; };
+                    auto of_park = [&](int t, int r) -> int { return parkr[t][r]; };
+                    if (seg == 0) fused_finish<TILES, NW>(of_tot, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
+                    else fused_finish<TILES, NW>(of_park, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
                 }
             }
         }
     }
+}
+
+template <int SK, int TILES, int RD, bool FUSE>
+__global__ void __launch_bounds__(512, 2)
+k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, LibCfg c, BitCfg b,
+                int nchunk, int apad_total, int a_off, int has_hs_sum, FuseArgs fz) {
+    sad_ring_i8<SK, TILES, RD, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
+}
+
+// The fp4 form of the same kernel.  When every patch byte sits on a level or outside the library's range (the
+// reference's patches come through the quantiser the library came through, NavBySceneFamiliarity.py:176-186), every
+// coefficient w_t - 2 alpha_t is +w_t or -w_t; and when the planes that land on bit position b of a nibble all have one
+// gap width w_b (K-element n = plane n % T sits on bit n % 4: always so for 1, 2 or 4 planes per pixel, else when the
+// widths agree), the sum over the K-elements on bit b is
+//     sum B (w - 2 alpha) = w_b * sum B * (+-1):
+// the signs are exact in fp4 (E2M1: +-1.0), the library bits too (bit 0/1/2 of a nibble ARE the E2M1 values 0.5/1/2, bit 3
+// comes down by a shift), and v_mfma_f32_32x32x64_f8f6f4 multiplies 64 K-elements in the time the int8 form takes for 32
+// (measured: 21.2 vs 18.3 ns per instruction and SIMD, tools/exp/mfma_fp4.hip).  The SAME bit tiles are the B operand:
+// K-element <-> (dword j, bit 4i + b) pairs with nibble i of coefficient image b of that K-step (k_bit_prep), and any
+// pairing works as long as both operands use it.  Sums of +-{0.5, 1, 2} stay exact in the fp32 accumulators (below 2^24
+// in halves); the four accumulators (one per bit position) are multiplied by their widths as integers at the end: the int32 sums are
+// the int8 form's, bit for bit.  With the coefficient image half the size, the kernel is left to the HBM stream.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+template <int SK, int TILES, int RD, bool FUSE>
+__device__ __forceinline__ void
+sad_ring_fp4(const uint4* __restrict__ btiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
+             int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz) {
+    extern __shared__ uint4 lds_ring[];           // [RD][ coefficient rows SK*4 | library rows 8 waves * SK * TILES ][64], then FUSE scratch
+    constexpr int NW = 8;
+    constexpr int VW = NW * TILES;
+    constexpr int COEF_ROWS = SK * 4;             // per stage
+    constexpr int LIB_ROWS = NW * SK * TILES;
+    constexpr int SLOT16 = (COEF_ROWS + LIB_ROWS) * 64;
+    constexpr int CPW = COEF_ROWS / NW;
+    constexpr int NDMA = CPW + SK * TILES;
+    static_assert(COEF_ROWS % NW == 0 && RD >= 2 && NDMA * (RD - 1) < 64, "ring shape");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long G32 = c.Fpad / 32;
+    const long long GQ = (G32 + VW - 1) / VW;
+    const long long n_items = GQ * nchunk;
+    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ch = (int)(item / GQ);
+        const long long gq = item - (long long)ch * GQ;
+        const uint4* lib[TILES];
+        long long gidx[TILES];
+        bool live[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            long long g = gq * VW + wave * TILES + t;
+            live[t] = g < G32;
+            if (!live[t]) g = G32 - 1;
+            gidx[t] = g;
+            lib[t] = btiles + (g * b.GS) * 64 + lane;
+        }
+        int parkr[TILES][16];                             // FUSE: the saturation sums wait here for the value sums
+        (void)parkr;
+#pragma unroll 1
+        for (int seg = 0; seg < 2; ++seg) {
+            if (seg == 0 && !has_hs_sum) continue;
+            if (seg == 1 && !c.hasv) continue;
+            const int kbase = seg ? b.NK[0] : 0;
+            const int k0 = kbase + (int)(((long long)ch * b.NK[seg]) / nchunk);
+            const int k1 = kbase + (int)(((long long)(ch + 1) * b.NK[seg]) / nchunk);
+            const int nst = (k1 - k0 + SK - 1) / SK;
+            v16f_t acc[TILES][4];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
+            if (nst > 0) {
+                auto kclamp = [&](int k) { return k < k1 ? k : k1 - 1; };
+                auto issue_stage = [&](int st) {
+                    const int kb = k0 + st * SK;
+                    const unsigned slot = lds_base + (unsigned)((st % RD) * SLOT16) * 16u;
+#pragma unroll
+                    for (int i = 0; i < CPW; ++i) {
+                        const int row = wave * CPW + i;                       // (K-step, bit position) row of the stage
+                        long long src = ((long long)kb * 4 + row) * 64 + lane;
+                        const long long lim = (long long)k1 * 256;
+                        if (src >= lim) src = lim - 64 + lane;                // past the chunk: any valid row (masked below)
+                        lds_dma_16(coef4 + src, __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u));
+                    }
+#pragma unroll
+                    for (int k = 0; k < SK; ++k)
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const int row = COEF_ROWS + (wave * SK + k) * TILES + t;
+                            lds_dma_16_nt(lib[t] + (long long)kclamp(kb + k) * 64, __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u));
+                        }
+                };
+#pragma unroll
+                for (int r = 0; r < RD - 1; ++r) issue_stage(r);
+                for (int st = 0; st < nst; ++st) {
+                    wait_vmcnt_le<NDMA * (RD - 2)>();
+                    __builtin_amdgcn_s_barrier();
+                    issue_stage(st + RD - 1);
+                    const int kb = k0 + st * SK;
+                    const uint4* cbuf = lds_ring + (st % RD) * SLOT16 + lane;
+                    const uint4* lbuf = cbuf + (COEF_ROWS + wave * SK * TILES) * 64;
+                    uint4 a[2][4], xl[2][TILES];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) a[0][s] = cbuf[s * 64];
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) xl[0][t] = lbuf[t * 64];
+#pragma unroll
+                    for (int k = 0; k < SK; ++k) {
+                        if (k + 1 < SK) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) a[(k + 1) & 1][s] = cbuf[((k + 1) * 4 + s) * 64];
+#pragma unroll
+                            for (int t = 0; t < TILES; ++t) xl[(k + 1) & 1][t] = lbuf[((k + 1) * TILES + t) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const bool on = kb + k < k1;
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const uint4 x = xl[k & 1][t];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
+                                const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
+                                const int sh = s < 3 ? 0 : 2;
+                                const v8i_t bo = v8i_t{(int)((x.x >> sh) & m), (int)((x.y >> sh) & m), (int)((x.z >> sh) & m), (int)((x.w >> sh) & m), 0, 0, 0, 0};
+                                const uint4 w = a[k & 1][s];
+                                const v8i_t ao = v8i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w, 0, 0, 0, 0};
+                                if constexpr (FUSE) acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bo, ao, acc[t][s], 4, 4, 0, 0, 0, 0);   // views x headings
+                                else acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[t][s], 4, 4, 0, 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                wait_vmcnt_le<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            const int type_row = seg ? has_hs_sum : 0;
+            const int nsum = has_hs_sum + c.hasv;
+            const int w0 = b.wacc[seg][0], w1 = b.wacc[seg][1], w2 = b.wacc[seg][2], w3 = b.wacc[seg][3];
+            // bits stood for 0.5 / 1 / 2 / 1: signed counts 2 acc0, acc1, acc2 / 2, acc3 (integers), each times the gap width of
+            // the planes on that bit position
+            int tot[TILES][16];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tot[t][r] = __mul24(w0, (int)(2.f * acc[t][0][r])) + __mul24(w1, (int)acc[t][1][r]) + __mul24(w2, (int)(0.5f * acc[t][2][r])) + __mul24(w3, (int)acc[t][3][r]);   // widths < 256, |counts| < 2^23
+            if constexpr (!FUSE) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    if (live[t]) {
+                        int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            if (m < rows) dst[(long long)m * c.Fpad] = tot[t][r];
+                        }
+                    }
+                }
+            } else {
+                if (seg == 0 && c.hasv) {
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) parkr[t][r] = tot[t][r];
+                } else {
+                    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds_ring + RD * SLOT16);
+                    auto of_tot = [&](int t, int r) -> int { return tot[t][r]; };
+                    auto of_park = [&](int t, int r) -> int { return parkr[t][r]; };
+                    if (seg == 0) fused_finish<TILES, NW>(of_tot, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
+                    else fused_finish<TILES, NW>(of_park, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
+                }
+            }
+        }
+    }
+}
+
+// One launch, both forms: `offlevel` (k_bit_prep) says whether this step's patches allow the fp4 coefficients.
+template <int SK8, int RD8, int SK4, int RD4, int TILES, bool FUSE>
+__global__ void __launch_bounds__(512, 2)
+k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4,
+                const unsigned* __restrict__ offlevel, int* __restrict__ part, LibCfg c, BitCfg b, int nchunk, int apad_total, int a_off,
+                int has_hs_sum, FuseArgs fz) {
+    if (__builtin_amdgcn_readfirstlane(*offlevel) == 0u)
+        sad_ring_fp4<SK4, TILES, RD4, FUSE>(btiles, coef4, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
+    else
+        sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
 }
 
 // ------------------------------------------------------------------ error / coverage metrics of the agent

@@ -64,7 +64,7 @@ class LibInfo(ctypes.Structure):
         ("bit_planes_hs", ctypes.c_int32),
         ("bit_planes_v", ctypes.c_int32),
         ("has_bit_planes", ctypes.c_int32),
-        ("reserved_", ctypes.c_int32),
+        ("fp4_form", ctypes.c_int32),
         ("bit_tile_bytes", ctypes.c_int64),
     ]
 
@@ -157,6 +157,7 @@ PROTOTYPES = {
     "dv_stream_read_gbps": (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int, _f64p]),
     "dv_range_push": (ctypes.c_int, [ctypes.c_char_p]),
     "dv_range_pop": (ctypes.c_int, []),
+    "dv_patches_on_level": (ctypes.c_int, [ctypes.c_void_p]),
     "dv_version": (ctypes.c_char_p, []),
 }
 

@@ -105,7 +105,8 @@ class FamiliarityEngine(object):
                     has_value_plane=bool(info.has_value_plane), tile_bytes=info.tile_bytes,
                     chem_weight=info.chem_weight, delta=info.delta, hues=[int(x) for x in info.hues][:info.n_hues],
                     signed_saturation=bool(info.signed_saturation), has_bit_planes=bool(info.has_bit_planes),
-                    bit_planes_hs=info.bit_planes_hs, bit_planes_v=info.bit_planes_v, bit_tile_bytes=info.bit_tile_bytes)
+                    bit_planes_hs=info.bit_planes_hs, bit_planes_v=info.bit_planes_v, bit_tile_bytes=info.bit_tile_bytes,
+                    fp4_form=bool(info.fp4_form))
 
     def read_planes(self, v0, n):
         info = self.library_info()
@@ -414,6 +415,13 @@ class FamiliarityEngine(object):
         out = np.empty(int(n), dtype=np.uint8)
         self._check(self._lib.dv_path_coverage(self._ctx, N.u8ptr(out), int(n)), "dv_path_coverage")
         return out.astype(bool)
+
+    def patches_on_level(self):
+        """True when the resident patches allowed the fp4 form of the matrix-core kernel (dv_patches_on_level)."""
+        rc = self._lib.dv_patches_on_level(self._ctx)
+        if rc < 0:
+            self._check(rc, "dv_patches_on_level")
+        return bool(rc)
 
     def path_reset(self):
         self._check(self._lib.dv_path_reset(self._ctx), "dv_path_reset")

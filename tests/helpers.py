@@ -50,15 +50,19 @@ def step_case_inputs(case):
 #   k_finish / k_combine+k_tail : the two ways a step ends (DEJAVU_FINISH=2 / 0), byte-plane kernels timed as usual;
 #   mfma    : the bit-plane copy is built whenever the library's values allow it (DEJAVU_BITS=2) and scored on the matrix
 #             cores (DEJAVU_SHAPE=6, k_sad_mfma); libraries it cannot describe fall back to the byte-plane kernels;
+#             finishing epilogue outside the kernel (DEJAVU_FUSE=0), int8 coefficients only (DEJAVU_FP4=0);
+#   mfma+fold : the matrix-core kernel as it ships: the fp4 form where the patches sit on the library's levels, the
+#             finishing epilogue inside the kernel, the step ends in k_fold;
 #   default : nothing set -- what ships (the engine times the kernel forms and picks the step ending by library size).
-ENGINE_MODES = ["k_finish", "k_combine+k_tail", "mfma", "default"]
+ENGINE_MODES = ["k_finish", "k_combine+k_tail", "mfma", "mfma+fold", "default"]
 _MODE_ENV = {
     "k_finish": {"DEJAVU_FINISH": "2"},
     "k_combine+k_tail": {"DEJAVU_FINISH": "0"},
-    "mfma": {"DEJAVU_FINISH": "2", "DEJAVU_SHAPE": "6", "DEJAVU_BITS": "2"},
+    "mfma": {"DEJAVU_FINISH": "2", "DEJAVU_SHAPE": "6", "DEJAVU_BITS": "2", "DEJAVU_FUSE": "0", "DEJAVU_FP4": "0"},
+    "mfma+fold": {"DEJAVU_SHAPE": "6", "DEJAVU_BITS": "2"},
     "default": {},
 }
-_MODE_KEYS = ("DEJAVU_FINISH", "DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FENCED")
+_MODE_KEYS = ("DEJAVU_FINISH", "DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FENCED", "DEJAVU_FUSE", "DEJAVU_FP4")
 
 
 class engine_mode(object):

@@ -576,7 +576,7 @@ def test_workgroup_shape_is_reported_after_the_first_step(eng):
     lib = synth.synth_views(3, 700, 16, 16)
     pats = synth.synth_patches(3, 12, 16, 16)
     eng.set_library(lib, 0.25)
-    if eng.mode == "mfma":                                   # DEJAVU_SHAPE=6: forced, nothing is timed
+    if eng.mode in ("mfma", "mfma+fold"):                                   # DEJAVU_SHAPE=6: forced, nothing is timed
         assert eng.workgroup_shape(12) == 6 and eng.library_info()["has_bit_planes"]
         eng.step(pats, want_scene=False)
         assert eng.workgroup_shape(12) == 6
@@ -1048,3 +1048,105 @@ def test_ties_inside_one_finishing_block_of_several_view_sets():
         finally:
             e.close()
     assert seen["2"] == seen["0"] >= 2 * len(dup)
+
+
+def _engine_with(env):
+    import os
+    keys = ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FP4", "DEJAVU_FUSE", "DEJAVU_FP4_VARIANT", "DEJAVU_MFMA_TILES")
+    before = {k: os.environ.pop(k, None) for k in keys}
+    os.environ.update(env)
+    try:
+        return navsim_amd.FamiliarityEngine(0)
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if before[k] is not None:
+                os.environ[k] = before[k]
+
+
+@pytest.mark.parametrize("F,h,w,A,cw,tiles", [(5000, 32, 32, 32, 0.5, "0"), (3001, 20, 24, 7, 0.3, "2"), (9037, 16, 16, 64, 0.5, "0"),
+                                               (4100, 32, 32, 16, 0.0, "2"), (2500, 12, 20, 33, 1.0, "0")])
+def test_fp4_form_gives_the_int8_forms_sums(F, h, w, A, cw, tiles):
+    """The fp4 form of the matrix-core kernel (on-level patches, one gap width per nibble bit) must leave the very
+    integer sums of the int8 form: scores, per-heading maxima and decisions identical to the last bit, with the
+    finishing epilogue inside the kernel or outside it; and both agree with the oracle."""
+    lib = synth.synth_views(11, F, h, w)
+    pat = synth.synth_patches(11, A, h, w)            # the library's own level set
+    pat[A // 2] = synth.near_match_patch(lib[F // 3], 5, fraction=0.03)
+    want = oracle.step(lib, pat, cw)
+    seen = {}
+    for fp4 in ("1", "0"):
+        for fuse in ("1", "0"):
+            e = _engine_with(dict(DEJAVU_SHAPE="6", DEJAVU_BITS="2", DEJAVU_FP4=fp4, DEJAVU_FUSE=fuse, DEJAVU_MFMA_TILES=tiles))
+            try:
+                e.set_library(lib, cw)
+                info = e.library_info()
+                assert info["has_bit_planes"] and info["fp4_form"] == (fp4 == "1")
+                got = e.step(pat, want_scene=False)
+                if fp4 == "1":
+                    assert e.patches_on_level()
+                assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]) == (A // 2, F // 3)
+                np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL, atol=1e-12)
+                scene = e.step(pat, want_scene=True)["scene_familiarity"]
+                np.testing.assert_allclose(scene, want["scene_familiarity"], rtol=RTOL, atol=1e-12)
+                fam = np.empty(F)
+                e.score(pat[0], fam)
+                seen[fp4, fuse] = (np.array(got["angle_familiarity"]), np.array(got["angle_view"]), scene.copy(), fam, got["n_candidates"])
+            finally:
+                e.close()
+    first = seen["1", "1"]
+    for key, other in seen.items():
+        for x, y in zip(first[:4], other[:4]):
+            assert np.array_equal(x, y), key
+        assert first[4] == other[4], key
+
+
+def test_off_level_patches_take_the_int8_form_in_the_same_launch():
+    """A patch byte strictly inside a gap of the library's levels has no fp4 coefficient: k_bit_prep flags the prep and
+    the same launch scores with the int8 image.  Alternating on-level and off-level patch sets on one engine: every
+    step against the oracle, and the flag follows the patches."""
+    F, h, w, A, cw = 6000 + 5, 24, 16, 12, 0.4
+    lib = synth.synth_views(23, F, h, w)
+    e = _engine_with(dict(DEJAVU_SHAPE="6", DEJAVU_BITS="2"))
+    try:
+        e.set_library(lib, cw)
+        assert e.library_info()["fp4_form"]
+        for it in range(8):
+            pat = synth.synth_patches(100 + it, A, h, w)
+            off = it % 2 == 1
+            if off:
+                pat[it % A, it % h, (3 * it) % w, 2] ^= 0x10          # one V byte off its level
+            pat[(it + 1) % A] = synth.near_match_patch(lib[(it * 811) % F], it, fraction=0.02)
+            want = oracle.step(lib, pat, cw)
+            got = e.step(pat, want_scene=True)
+            assert e.patches_on_level() == (not off), it
+            assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]), it
+            np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=RTOL, atol=1e-12)
+    finally:
+        e.close()
+
+
+def test_fp4_form_needs_one_gap_width_per_nibble_bit():
+    """K-element n = plane n % T sits on bit n % 4 of a nibble.  Five V levels (four planes) put ONE plane on each bit, so
+    the widths 63, 64, 64, 64 of the reference's five-level quantiser are fine; four levels with unequal gaps (three
+    planes: every plane lands on every bit) are not, and keep the int8 form; equal gaps are fine again."""
+    F, h, w = 700, 8, 8
+    rng = np.random.default_rng(3)
+    for levels, ok in (([0, 63, 127, 191, 255], True), ([0, 60, 130, 255], False), ([0, 85, 170, 255], True), ([0, 255], False), ([0, 100], True)):
+        lib = np.zeros((F, h, w, 3), np.uint8)
+        lib[..., 2] = np.array(levels, np.uint8)[rng.integers(0, len(levels), (F, h, w))]
+        pat = np.zeros((3, h, w, 3), np.uint8)
+        pat[..., 2] = np.array(levels, np.uint8)[rng.integers(0, len(levels), (3, h, w))]
+        e = _engine_with(dict(DEJAVU_SHAPE="6", DEJAVU_BITS="2"))
+        try:
+            e.set_library(lib, 0.0)
+            info = e.library_info()
+            assert info["has_bit_planes"] and info["fp4_form"] == ok, levels      # (0, 255: one gap split 127 + 127 + 1)
+            got = e.step(pat, want_scene=True)
+            want = oracle.step(lib, pat, 0.0)
+            assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]), levels
+            np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=RTOL, atol=1e-12)
+        finally:
+            e.close()

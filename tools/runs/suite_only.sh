@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/suite
-timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/suite/pytest.log 2>&1
+timeout -k 10 1100 python -m pytest tests -m gpu -q -x "$@" > gpurun_out/suite/pytest.log 2>&1
 rc=$?
-tail -40 gpurun_out/suite/pytest.log
+tail -30 gpurun_out/suite/pytest.log
 exit $rc

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/tune gpurun_out/suite
-timeout -k 10 1100 python -m pytest tests -m gpu -q -x > gpurun_out/suite/pytest.log 2>&1
+timeout -k 10 1100 python -m pytest tests -m gpu -q -x -k "fold or mfma" > gpurun_out/suite/pytest.log 2>&1
 rc=$?
 tail -25 gpurun_out/suite/pytest.log
 if [ $rc -ne 0 ]; then exit $rc; fi
@@ -10,15 +10,17 @@ run() {
   python -c "
 import json,sys
 d=json.loads(open('gpurun_out/tune/$name.json').read().strip().splitlines()[-1])
-print('%-28s step %.4f ms  kernel %.4f ms  rest %.1f us value %.3e' % ('$name', d['ms_per_step'], d['roofline']['kernel_ms'], (d['ms_per_step']-d['roofline']['kernel_ms'])*1e3, d['value']))
+print('%-28s step %.4f ms  kernel %.4f ms  rest %.1f us value %.3e  %s' % ('$name', d['ms_per_step'], d['roofline']['kernel_ms'], (d['ms_per_step']-d['roofline']['kernel_ms'])*1e3, d['value'], d['roofline'].get('kernel')))
 "
 }
 BARGS="--steps 50 --warmup 5"
-run c2_fused DEJAVU_FUSE=1
-run c2_nofuse DEJAVU_FUSE=0
+run c2_fp4 X=1
+run c2_fp4_fused DEJAVU_FUSE=1
+run c2_i8_fused DEJAVU_FUSE=1 DEJAVU_FP4=0
 BARGS="--views 50000 --sensor 64 --headings 16 --steps 300 --warmup 30 --event-every 4"
-run c1_fused DEJAVU_FUSE=1
-run c1_nofuse DEJAVU_FUSE=0
+run c1_fp4 X=1
+run c1_fp4_fused DEJAVU_FUSE=1
+run c1_i8_fused DEJAVU_FUSE=1 DEJAVU_FP4=0
 BARGS="--views 100000 --sensor 64 --headings 64 --steps 100 --warmup 10"
-run b64_fused DEJAVU_FUSE=1
-run b64_nofuse DEJAVU_FUSE=0
+run b64_fp4 X=1
+run b64_fp4_fused DEJAVU_FUSE=1
