@@ -28,6 +28,7 @@ for _p in (REPO, os.path.join(REPO, "navigation-by-deja-vu_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+FP4_MFMA_PEAK_TOPS = 10000.0  # dense fp4 (f8f6f4) peak, twice the int8 figure (MI355X_MICROARCH.md, Matrix cores)
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 matrix-core peak: 2x the ~2.5 PF dense bf16 figure (MI355X_MICROARCH.md, Matrix cores)
 CLOCK_PEAK_GHZ = 2.4
 
@@ -245,13 +246,18 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
     t = kern_ms * 1e-3
     # partial sums written once per chunk; their count is the engine's choice, so only a lower bound (one chunk) is
     # known here -- the PMC figure, when present, has the real number
-    constructed = streamed + float(nsum) * apad * F * 4
+    try:
+        form = eng.scoring_form()
+    except Exception:                                            # an engine without the call
+        form = dict(matrix_cores=shape == 6, fp4=False, fused_finish=False)
+    constructed = streamed + (0.0 if form["fused_finish"] else float(nsum) * apad * F * 4)
     basis = moved if moved is not None else constructed
     out = {
         "bound": "hbm", "kernel": kernel, "achieved": basis / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": basis / t / 1e9 / HBM_PEAK_GBPS,
         "traffic": moved, "traffic_source": ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch, " + traffic[1]) if traffic else None,
         "bytes_basis": "pmc traffic" if moved is not None else "streamed library bytes + partial sums (by construction)",
+        "kernel_form": form,
         "streamed_library_bytes_per_launch": streamed, "kernel_ms": kern_ms, "launches_timed": kern_n,
         "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_achieved": algo_bytes / t / 1e9,
         "frac_algorithmic": algo_bytes / t / 1e9 / HBM_PEAK_GBPS,
@@ -262,8 +268,11 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
         k_total = streamed / (((F + 63) // 64) * 64 / 32.0) / 1024.0 * 256.0
         passes = (apad + 31) // 32
         ops = 2.0 * 32 * (((F + 63) // 64) * 64) * k_total * passes
-        out["mfma"] = {"dtype": "i8", "ops_per_launch": ops, "achieved": ops / t / 1e12, "peak": I8_MFMA_PEAK_TOPS,
-                       "unit": "TOP/s", "frac": ops / t / 1e12 / I8_MFMA_PEAK_TOPS,
+        # the fp4 form (on-level patches) multiplies the same K-elements with v_mfma_f32_32x32x64_f8f6f4: twice the int8 peak
+        peak = FP4_MFMA_PEAK_TOPS if form["fp4"] else I8_MFMA_PEAK_TOPS
+        out["mfma"] = {"dtype": "fp4 (E2M1 signs x library bits, f32 accumulate, exact)" if form["fp4"] else "i8",
+                       "ops_per_launch": ops, "achieved": ops / t / 1e12, "peak": peak,
+                       "unit": "TOP/s", "frac": ops / t / 1e12 / peak,
                        "useful_ops_per_launch": 2.0 * A * F * h * w * (info["bit_planes_hs"] + info["bit_planes_v"])}
     else:
         # v_sad_u8 issues one wave64 instruction per SIMD every 4 cycles: 256 CUs x 4 SIMDs x 64 lanes / 4

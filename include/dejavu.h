@@ -334,6 +334,15 @@ int dv_range_pop(void);
  * (The reference has no counterpart; its patches come out of the quantiser of NavBySceneFamiliarity.py:176-186.) */
 int dv_patches_on_level(dv_ctx *ctx);
 
+/* Form of the last integer scoring pass, as flags: DV_FORM_MATRIX_CORES (bit-plane library on the matrix cores, workgroup
+ * shape 6), DV_FORM_FP4 (its fp4 coefficients: the prep's patches were on-level), DV_FORM_FUSED_FINISH (the kernel
+ * finished its scores itself; the step ended in k_fold).  Waits for the stream when the fp4 word has to be read.
+ * Diagnostic for benchmarks and tests; negative on error. */
+#define DV_FORM_MATRIX_CORES 1
+#define DV_FORM_FP4 2
+#define DV_FORM_FUSED_FINISH 4
+int dv_scoring_form(dv_ctx *ctx);
+
 const char *dv_version(void);
 
 #ifdef __cplusplus

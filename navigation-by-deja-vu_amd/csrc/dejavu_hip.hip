@@ -102,6 +102,7 @@ struct dv_ctx {
     unsigned* d_prep = nullptr;               // [npl][Q][4][64]
     int* d_hsconst_pair = nullptr;            // [2][64]: the sensed path alternates (k_sense_prep clears the other one)
     int* d_hsconst = nullptr;                 // the buffer of the resident patches
+    unsigned long long* d_bsum2 = nullptr;    // k_fold_reduce: [agents][kFoldSlices][2][headings per agent]
     unsigned long long* d_bsum = nullptr;     // k_finish: per-block, per-heading (maximum, first view) [blocks][2][headings]
     unsigned long long* d_ctmp = nullptr;     // k_finish: shared extra-candidate list [agents][kTmpCap][2]
     int int_has_hs = 0, int_has_v = 0;        // which sums the last integer scoring pass produced
@@ -140,7 +141,8 @@ struct dv_ctx {
     uint4* d_coef4 = nullptr;                 // [pass][K-step][4][64] E2M1 sign images (k_bit_prep)
     unsigned* d_offlevel = nullptr;           // [2]: nonzero = the patches of that prep have a byte strictly inside a gap
     int prep_seq = 0;                         // preps so far: word prep_seq & 1 belongs to the latest
-    int fp4_variant_env = 0;                  // DEJAVU_FP4_VARIANT: A/B of the ring shapes
+    int fp4_variant_env = 0;
+    int last_form = 0;                        // DV_FORM_* of the last integer scoring pass (fp4 bit: the dual kernel was launched)                  // DEJAVU_FP4_VARIANT: A/B of the ring shapes
     int fuse_env = 1;                         // DEJAVU_FUSE=0: one-chunk matrix-core passes leave their sums to k_finish instead of finishing them
     int fused_nb = 0;                         // summaries per agent it left
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
@@ -224,7 +226,7 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
-    F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_ctmp);
+    F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
     F(c->d_btiles); F(c->d_coef); F(c->d_bconst); F(c->d_coef4); F(c->d_offlevel);
     c->bits_ok = false; c->coef_ready = false; c->btile_bytes = 0;
@@ -588,6 +590,7 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     // per-agent state of a batched pass: up to kMaxHeadings agents (one heading each)
     HIP_TRY(c, hipMalloc(&c->d_state, kMaxHeadings * sizeof(StepState)));
     HIP_TRY(c, hipMalloc(&c->d_bsum, (size_t)((g.F + 255) / 256) * 2 * kMaxHeadings * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc(&c->d_bsum2, (size_t)kFoldSlices * 2 * kMaxHeadings * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_ctmp, (size_t)kMaxHeadings * kTmpCap * 2 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand, (size_t)kMaxHeadings * kCandCap * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand_exact, (size_t)kMaxHeadings * kCandCap * sizeof(double)));
@@ -1129,6 +1132,19 @@ extern "C" int dv_patches_on_level(dv_ctx* c) {
     return word == 0 ? 1 : 0;
 }
 
+extern "C" int dv_scoring_form(dv_ctx* c) {
+    if (!c) return DV_ERR_INVALID;
+    int form = c->last_form;
+    if (form & DV_FORM_FP4) {                              // the dual kernel ran: which image it took is on the device
+        HIP_TRY(c, hipSetDevice(c->device));
+        unsigned word = 0;
+        HIP_TRY(c, hipMemcpyAsync(&word, c->d_offlevel + (c->prep_seq & 1), sizeof word, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (word != 0) form &= ~DV_FORM_FP4;
+    }
+    return form;
+}
+
 extern "C" int dv_clear_library(dv_ctx* c) {
     if (!c) return DV_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1469,7 +1485,9 @@ static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
 // small libraries cut the K-steps into chunks instead so that there are at least as many items as CUs.
 static void launch_mfma(dv_ctx* c, int has_hs) {
     const long long G32 = c->cfg.Fpad / 32;
-    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (G32 >= 16ll * 256 * 2 ? 2 : 1);     // two, once every CU still gets two items
+    // two view groups per wave once there are about 1.25 such items per CU (200 000 views x 128x128 x 32 headings, 391 items:
+    // 0.432 ms with two, 0.474 ms with one; 500 000 views: two)
+    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (G32 >= 16ll * 320 ? 2 : 1);
     const long long GQ = (G32 + 8 * tiles - 1) / (8 * tiles);
     int nchunk = 1;
     if (c->mfma_chunk_env) {
@@ -1494,15 +1512,15 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     if (c->fp4_ok && var == 0) {
         const int v4 = c->fp4_variant_env;
         if (tiles == 2) {
-            switch (v4) {
+            switch (v4) {                                      // 500 000 views x 128x128 x 32 headings: 0.96 / 1.07 ms
                 case 1: launch_mfma_dual<1, 3, 2, 2, 2>(c, nchunk, has_hs); break;
                 default: launch_mfma_dual<1, 3, 2, 3, 2>(c, nchunk, has_hs);
             }
         } else {
-            switch (v4) {
-                case 1: launch_mfma_dual<4, 2, 2, 4, 1>(c, nchunk, has_hs); break;
+            switch (v4) {                                      // 50 000 views x 64x64 x 16 headings: 38.6 / 40.6 / 41.4 us
+                case 1: launch_mfma_dual<4, 2, 4, 3, 1>(c, nchunk, has_hs); break;
                 case 2: launch_mfma_dual<4, 2, 2, 6, 1>(c, nchunk, has_hs); break;
-                default: launch_mfma_dual<4, 2, 4, 3, 1>(c, nchunk, has_hs);
+                default: launch_mfma_dual<4, 2, 2, 4, 1>(c, nchunk, has_hs);
             }
         }
         return;
@@ -1534,10 +1552,12 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial,
     c->int_hsconst = c->d_hsconst;
     c->int_vconst = nullptr;
     c->epilogue_fused = false;                           // set again below by a pass that finishes its own scores
+    c->last_form = 0;
     if (!g.generic && shape_now(c) == 6) {
         if (!c->coef_ready) { const int rc = enqueue_bit_prep(c, true); if (rc) return rc; }
         has_hs_sum = g.nhs > 0 ? 1 : 0;
         launch_mfma(c, has_hs_sum);
+        c->last_form = DV_FORM_MATRIX_CORES | ((c->fp4_ok && c->mfma_variant_env == 0) ? DV_FORM_FP4 : 0) | (c->epilogue_fused ? DV_FORM_FUSED_FINISH : 0);
         c->int_hsconst = c->d_bconst;
         c->int_vconst = c->d_bconst + kMaxHeadings;
     } else if (g.generic) {
@@ -1706,6 +1726,24 @@ static int step_fenced(const dv_ctx* c) {
 }
 
 // One step on the resident patches: scoring (2 launches) + k_tail.  The result record lands in mapped host memory.
+// k_fold behind summaries left by k_finish or by a fused scoring epilogue.  Long lists (more than 512 summaries per
+// agent) are first cut down to kFoldSlices by k_fold_reduce on as many workgroups: one workgroup walking 977 summaries x
+// 32 headings took 23.5 us at 500 000 views (DEJAVU_FOLD2=0 keeps that form).
+static void launch_fold(dv_ctx* c, int nb, StepResultDev* outp, double* recp, int force, int seq, const unsigned long long* serr) {
+    static const int two_level = getenv("DEJAVU_FOLD2") ? atoi(getenv("DEJAVU_FOLD2")) : 1;
+    unsigned long long* sums = c->d_bsum;
+    if (two_level && nb > 512) {
+        const int per = (nb + kFoldSlices - 1) / kFoldSlices;
+        const int slices = (nb + per - 1) / per;
+        hipLaunchKernelGGL(k_fold_reduce, dim3((unsigned)slices, (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_bsum, c->d_bsum2,
+                           c->d_ctmp, c->d_state, c->A_agent, c->delta, nb, per);
+        sums = c->d_bsum2;
+        nb = slices;
+    }
+    hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3(1024), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state,
+                       outp, recp, c->cfg, c->A_agent, c->delta, force, seq, serr, nb);
+}
+
 template <int NT>
 static void launch_finish(dv_ctx* c, int want_scene, int force) {
     const LibCfg& g = c->cfg;
@@ -1724,9 +1762,7 @@ static void launch_finish(dv_ctx* c, int want_scene, int force) {
                        c->d_part, c->int_hsconst, c->int_vconst, c->nchunk, c->APAD, c->int_has_hs, c->int_has_v, c->d_state, c->d_bsum, c->d_ctmp,
                        c->d_cand, c->d_scene, outp, recp, c->cfg, c->A_agent, c->delta, want_scene, force,
                        c->seq, serr, step_fenced(c), (int)vb, separate);
-    if (separate)
-        hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3(1024), 0, c->stream, c->d_bsum, c->d_ctmp, c->d_cand, c->d_state,
-                           outp, recp, c->cfg, c->A_agent, c->delta, force, c->seq, serr, (int)nb);
+    if (separate) launch_fold(c, (int)nb, outp, recp, force, c->seq, serr);
 }
 
 static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
@@ -1750,9 +1786,8 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     if (rc) return rc;
     Range range("dv:finish");
     if (c->epilogue_fused) {
-        hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3(1024), 0, c->stream, c->d_bsum, c->d_ctmp, c->d_cand, c->d_state,
-                           c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,
-                           c->A_agent, c->delta, force, ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->fused_nb);
+        launch_fold(c, c->fused_nb, c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), force,
+                    ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr);
     } else if (fused) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
         else launch_finish<2>(c, scene_on, force);
@@ -2132,11 +2167,12 @@ extern "C" int dv_stream_read_gbps(dv_ctx* c, int64_t n_bytes, int iters, double
     if (e == hipSuccess) e = hipMemsetAsync(buf, 0x5a, (size_t)n16 * 16, c->stream);
     float ms = 0.f;
     if (e == hipSuccess) {
-        const dim3 grid(256 * 8), block(256);
-        hipLaunchKernelGGL(k_stream_read, grid, block, 0, c->stream, buf, n16, sink);   // warm-up
+        const dim3 grid(256 * 2), block(512);
+        const size_t lds = 64 * 1024;
+        hipLaunchKernelGGL(k_stream_read, grid, block, lds, c->stream, buf, n16, sink);   // warm-up
         e = hipEventRecord(c->t0, c->stream);
         for (int i = 0; i < iters && e == hipSuccess; ++i) {
-            hipLaunchKernelGGL(k_stream_read, grid, block, 0, c->stream, buf, n16, sink);
+            hipLaunchKernelGGL(k_stream_read, grid, block, lds, c->stream, buf, n16, sink);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipEventRecord(c->t1, c->stream);

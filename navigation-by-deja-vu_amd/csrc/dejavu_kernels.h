@@ -1449,6 +1449,61 @@ k_fold(unsigned long long* __restrict__ bsum, unsigned long long* __restrict__ c
                     st + agent, out + agent, rec + (long long)agent * (3 + 4 * kMaxHeadings), c, A, delta, force, seq, sense_err, agent, nb);
 }
 
+// First level of a two-level fold for long summary lists (grid (slices, agents), 256 threads): a block reduces the
+// summaries [slice * per, slice * per + per) of its agent to ONE summary of the same form -- per heading the maximum and
+// the smallest view attaining it -- in bsum2, and lists every other representative within delta of the slice's own
+// best (the superset rule of k_finish, one level up) in the shared list.  k_fold on bsum2 then walks `slices` entries
+// instead of thousands with one workgroup.
+constexpr int kFoldSlices = 32;
+__global__ void __launch_bounds__(256)
+k_fold_reduce(const unsigned long long* __restrict__ bsum, unsigned long long* __restrict__ bsum2, unsigned long long* __restrict__ ctmp,
+              StepState* __restrict__ st, int A, double delta, int nb, int per) {
+    const int agent = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long* base = bsum + (long long)agent * nb * 2 * A;
+    const int b0 = slice * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+    __shared__ unsigned long long s_max[kMaxHeadings], s_view[kMaxHeadings];
+    if (tid < kMaxHeadings) { s_max[tid] = 0; s_view[tid] = ~0ull; }
+    __syncthreads();
+    const int G = blockDim.x / A, a = tid % A, r = tid / A;
+    const bool active = r < G;
+    unsigned long long lk = 0;
+    if (active)
+        for (int b = b0 + r; b < b1; b += G) {
+            const unsigned long long k = base[((long long)b * 2 + 0) * A + a];
+            lk = k > lk ? k : lk;
+        }
+    if (active && lk) atomicMax(&s_max[a], lk);
+    __syncthreads();
+    unsigned long long gkey = 0;
+    for (int k = 0; k < A; ++k) gkey = s_max[k] > gkey ? s_max[k] : gkey;
+    const unsigned long long thr = gkey ? ordered_key(key_to_double(gkey) - delta) : ~0ull;
+    const unsigned long long amax_a = active ? s_max[a] : 0;
+    if (active && amax_a)
+        for (int b = b0 + r; b < b1; b += G)
+            if (base[((long long)b * 2 + 0) * A + a] == amax_a) atomicMin(&s_view[a], base[((long long)b * 2 + 1) * A + a]);
+    __syncthreads();
+    if (active && amax_a >= thr)                              // (a heading whose best falls short of the threshold lists nothing)
+        for (int b = b0 + r; b < b1; b += G) {
+            const unsigned long long k = base[((long long)b * 2 + 0) * A + a];
+            if (k != 0 && k >= thr) {
+                const unsigned long long view = base[((long long)b * 2 + 1) * A + a];
+                if (!(k == amax_a && view == s_view[a])) {
+                    const unsigned pos = __hip_atomic_fetch_add(&st[agent].ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pos < (unsigned)kTmpCap) {
+                        unsigned long long* ct = ctmp + (long long)agent * kTmpCap * 2;
+                        ct[2 * pos] = ((unsigned long long)a << 40) | view;
+                        ct[2 * pos + 1] = k;
+                    }
+                }
+            }
+        }
+    if (tid < A) {
+        unsigned long long* dst = bsum2 + ((long long)agent * gridDim.x + slice) * 2 * A;
+        dst[tid] = s_max[tid];
+        dst[A + tid] = s_max[tid] ? s_view[tid] : ~0ull;
+    }
+}
+
 // One single-wave block per candidate (a,f): the reference's exact value.  Lanes compute the per-pixel
 // terms of 1024 pixels at a time into LDS; the sequential double accumulation over them is
 // then done identically by every lane (broadcast reads).
@@ -2928,17 +2983,28 @@ k_path_error(const double* __restrict__ xy, long long n, double x, double y, dou
     }
 }
 
-// Streaming-read microbenchmark: sum of all dwords, one store per thread that found a nonzero sum.
-__global__ void k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    unsigned acc = 0;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c2 = src[i + 2 * stride], d = src[i + 3 * stride];
-        acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c2.x ^ c2.y ^ c2.z ^ c2.w ^ d.x ^ d.y ^ d.z ^ d.w;
+// Streaming-read microbenchmark: the scoring kernels' access pattern without their arithmetic -- every wave pulls 1-KB
+// rows straight into LDS by non-temporal LDS-DMA, eight rows in flight per wave, eight waves per workgroup -- as the
+// measured ceiling the library stream is held against.
+__global__ void __launch_bounds__(512)
+k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
+    extern __shared__ uint4 lds_stream[];          // [8 waves][8 rows][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned base = (unsigned)(unsigned long long)(lds_ptr_t)lds_stream + (unsigned)wave * 8u * 1024u;
+    const long long rows = n16 / 64;
+    const long long stride = (long long)gridDim.x * 8;
+    long long row = (long long)blockIdx.x * 8 + wave;
+    for (; row + 7 * stride < rows; row += 8 * stride) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_dma_16_nt(src + (row + i * stride) * 64 + lane, __builtin_amdgcn_readfirstlane(base + (unsigned)i * 1024u));
+        wait_vmcnt_le<0>();
     }
-    for (; i < n16; i += stride) { const uint4 a = src[i]; acc += a.x ^ a.y ^ a.z ^ a.w; }
-    if (acc == 0x9E3779B9u) sink[0] = acc;
+    for (; row < rows; row += stride) {
+        lds_dma_16_nt(src + row * 64 + lane, __builtin_amdgcn_readfirstlane(base));
+        wait_vmcnt_le<0>();
+    }
+    if (lds_stream[threadIdx.x].x == 0x9E3779B9u && lds_stream[threadIdx.x].y == 0x12345u) sink[0] = 1;
 }
 
 }  // namespace dv

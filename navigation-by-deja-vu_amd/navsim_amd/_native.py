@@ -158,6 +158,7 @@ PROTOTYPES = {
     "dv_range_push": (ctypes.c_int, [ctypes.c_char_p]),
     "dv_range_pop": (ctypes.c_int, []),
     "dv_patches_on_level": (ctypes.c_int, [ctypes.c_void_p]),
+    "dv_scoring_form": (ctypes.c_int, [ctypes.c_void_p]),
     "dv_version": (ctypes.c_char_p, []),
 }
 

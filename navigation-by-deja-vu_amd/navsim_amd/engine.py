@@ -423,6 +423,13 @@ class FamiliarityEngine(object):
             self._check(rc, "dv_patches_on_level")
         return bool(rc)
 
+    def scoring_form(self):
+        """Form of the last integer scoring pass (dv_scoring_form): matrix cores / fp4 coefficients / fused finishing."""
+        rc = self._lib.dv_scoring_form(self._ctx)
+        if rc < 0:
+            self._check(rc, "dv_scoring_form")
+        return dict(matrix_cores=bool(rc & 1), fp4=bool(rc & 2), fused_finish=bool(rc & 4))
+
     def path_reset(self):
         self._check(self._lib.dv_path_reset(self._ctx), "dv_path_reset")
 

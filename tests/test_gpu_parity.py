@@ -1150,3 +1150,28 @@ def test_fp4_form_needs_one_gap_width_per_nibble_bit():
             np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=RTOL, atol=1e-12)
         finally:
             e.close()
+
+
+@pytest.mark.parametrize("A", [32, 12])
+def test_two_level_fold_with_ties_across_slices(eng, A):
+    """More than 512 summaries per agent: k_fold_reduce cuts them to 32 on as many workgroups before k_fold decides.  The
+    best view duplicated in slices far apart (and twice inside one slice), seen under three headings; the oracle's
+    decision (first heading, first view), every per-heading maximum, and the candidate count."""
+    F, h, w, cw = 300000 + 123, 4, 4, 0.25
+    lib = synth.synth_views(19, F, h, w)
+    pats = synth.synth_patches(19, A, h, w)
+    star = lib[150000].copy()
+    star[0, 0] = (77, 200, 13)                          # unlike the 2-hue, 5-level crowd: a unique best match
+    dup = (299999, 150000, 150300, 801, 77000)
+    for f in dup:
+        lib[f] = star
+    for a in (A - 1, A // 2, 2):
+        pats[a] = star
+    want = oracle.step(lib, pats, cw)
+    assert (want["best_idex"], want["best_view"]) == (2, 801)
+    eng.set_library(lib, cw)
+    got = eng.step(pats, want_scene=False)
+    assert (got["best_idex"], got["best_view"]) == (2, 801)
+    assert got["n_candidates"] == 3 * len(dup) and got["flags"] & 1
+    np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=1e-12)
+    assert list(got["angle_view"]) == list(want["angle_view"]) if "angle_view" in want else True

@@ -24,7 +24,7 @@ shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, tag + "_summary
 shutil.copy(biggest("trace/*/*_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 for name, out in (("pmc_fetch", "pmc_fetch_size"), ("pmc_write", "pmc_write_size")):
     # keep the scoring-path rows only: the full per-dispatch table is several MB
-    keep = ("k_sad", "k_finish", "k_combine", "k_tail", "k_ssd", "k_exact")
+    keep = ("k_sad", "k_finish", "k_fold", "k_combine", "k_tail", "k_ssd", "k_exact")
     with open(biggest(name + "/*/*_counter_collection.csv")) as f, open(os.path.join(dst, f"{tag}_{out}.csv"), "w") as o:
         for i, line in enumerate(f):
             if i == 0 or any(k in line for k in keep):
