@@ -250,6 +250,8 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
         form = eng.scoring_form()
     except Exception:                                            # an engine without the call
         form = dict(matrix_cores=shape == 6, fp4=False, fused_finish=False)
+    if shape == 6 and form["fp4"] and info.get("code_tile_bytes"):
+        streamed = float(info["code_tile_bytes"])                # the fp4 form reads the value plane as 3-bit level codes
     constructed = streamed + (0.0 if form["fused_finish"] else float(nsum) * apad * F * 4)
     basis = moved if moved is not None else constructed
     out = {
@@ -265,7 +267,7 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
     if shape == 6:
         # int8 MFMA work actually issued: 32 heading rows x 32 views x 32 K per instruction, K = planes x pixels
         # rounded up to 256 per segment; one pass per 32 resident headings
-        k_total = streamed / (((F + 63) // 64) * 64 / 32.0) / 1024.0 * 256.0
+        k_total = float(info["bit_tile_bytes"]) / (((F + 63) // 64) * 64 / 32.0) / 1024.0 * 256.0
         passes = (apad + 31) // 32
         ops = 2.0 * 32 * (((F + 63) // 64) * 64) * k_total * passes
         # the fp4 form (on-level patches) multiplies the same K-elements with v_mfma_f32_32x32x64_f8f6f4: twice the int8 peak
@@ -475,7 +477,8 @@ def main():
                              "(util.pyx:31-73); BASELINE.json's 'fp32' SSD wording is the ssd_f32 block",
                 "scoring_kernel": kernel_of_shape(shape), "workgroup_shape": shape,
                 "bytes_per_pixel_reference": 3 if cw > 0 else 1,
-                "bytes_per_pixel_streamed": (info["bit_planes_hs"] + info["bit_planes_v"]) / 8.0 if shape == 6 else info["n_planes"],
+                "bytes_per_pixel_streamed": ((info["code_tile_bytes"] or info["bit_tile_bytes"]) / float(((F + 63) // 64) * 64 * h * w)
+                                             if shape == 6 else info["n_planes"]),
                 "parallelism": "library sharded x%d" % world,
                 "exchange": "none" if not use_dist else "1 exchange of per-heading records per step (%s)" % (
                     "mailbox in host-shared memory, no collective" if args.exchange == "mailbox" else

@@ -97,7 +97,8 @@ typedef struct dv_lib_info {
     int32_t bit_planes_v;       /* thermometer planes of the value byte */
     int32_t has_bit_planes;     /* 1: the bit-plane copy exists (scoring shape 6 is available) */
     int32_t fp4_form;           /* 1: the planes also allow the fp4 form of that kernel (on-level patches, see dv_patches_on_level) */
-    int64_t bit_tile_bytes;     /* bytes the matrix-core scoring kernel streams per pass */
+    int64_t bit_tile_bytes;     /* bytes the matrix-core scoring kernel streams per pass (int8 form; fp4 form without code tiles) */
+    int64_t code_tile_bytes;    /* bytes its fp4 form streams per pass when the value plane is stored as 3-bit level codes, else 0 */
 } dv_lib_info;
 
 /* ---- lifetime ---------------------------------------------------------- */

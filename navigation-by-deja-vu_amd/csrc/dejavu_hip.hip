@@ -141,6 +141,13 @@ struct dv_ctx {
     uint4* d_coef4 = nullptr;                 // [pass][K-step][4][64] E2M1 sign images (k_bit_prep)
     unsigned* d_offlevel = nullptr;           // [2]: nonzero = the patches of that prep have a byte strictly inside a gap
     int prep_seq = 0;                         // preps so far: word prep_seq & 1 belongs to the latest
+    uint4* d_ctiles = nullptr;                // [Fpad/32][GSC][64] code tiles (k_bitpack_code), when bcfg.vcode
+    size_t ctile_bytes = 0;
+    // DEJAVU_VCODE=1: the fp4 form reads five-level value planes as 3-bit codes (k_bitpack_code: a third copy of the library, 5
+    // bits per pixel).  Off by default: at 500 000 views x 128x128 it moves 5.16 GB instead of 6.18 GB per pass in the SAME
+    // 0.94 ms -- with the library stream out of the way the loop is bound by its LDS operand traffic and the matrix pipe
+    // (tools/exp/fp4_ladder.hip), so the copy would cost 5 GB and buy nothing yet.
+    int vcode_env = 0;
     int fp4_variant_env = 0;
     int last_form = 0;                        // DV_FORM_* of the last integer scoring pass (fp4 bit: the dual kernel was launched)                  // DEJAVU_FP4_VARIANT: A/B of the ring shapes
     int fuse_env = 1;                         // DEJAVU_FUSE=0: one-chunk matrix-core passes leave their sums to k_finish instead of finishing them
@@ -228,7 +235,7 @@ static void free_library(dv_ctx* c) {
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
-    F(c->d_btiles); F(c->d_coef); F(c->d_bconst); F(c->d_coef4); F(c->d_offlevel);
+    F(c->d_btiles); F(c->d_coef); F(c->d_bconst); F(c->d_coef4); F(c->d_offlevel); F(c->d_ctiles); c->ctile_bytes = 0;
     c->bits_ok = false; c->coef_ready = false; c->btile_bytes = 0;
     c->metric = 0;
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
@@ -278,6 +285,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_FINISH_VB", c->finish_vb_env, 0, 16);
     env_int("DEJAVU_FUSE", c->fuse_env, 0, 1);
     env_int("DEJAVU_FP4", c->fp4_env, 0, 1);
+    env_int("DEJAVU_VCODE", c->vcode_env, 0, 1);
     env_int("DEJAVU_FP4_VARIANT", c->fp4_variant_env, 0, 8);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
@@ -483,6 +491,8 @@ static int build_bit_planes(dv_ctx* c) {
     for (int seg = 0; seg < 2; ++seg)
         if ((double)b.T[seg] * g.P * 127.0 > 1.9e9) return DV_OK;
     for (int seg = 0; seg < 2; ++seg) b.NK[seg] = (int)(((long long)b.T[seg] * g.P + 255) / 256);
+    // Five value levels (four planes of the one value byte plane): the fp4 form may read them as 3-bit codes (k_bitpack_code)
+    const bool five_levels = c->fp4_env != 0 && c->vcode_env != 0 && g.hasv && b.T[1] == 4;
     const int nkt = b.NK[0] + b.NK[1];
     b.GS = nkt | 1;
     // fp4 form of the kernel: the planes that land on bit b of a nibble (K-element n = plane n % T on bit n % 4) share a width
@@ -511,10 +521,30 @@ static int build_bit_planes(dv_ctx* c) {
         (void)hipGetLastError();
         c->fp4_ok = false;                                              // the int8 form alone
     }
+    b.vcode = 0;
+    b.GSC = b.GS;
+    if (c->fp4_ok && five_levels) {
+        const long long units = 4ll * b.NK[0] + 3ll * b.NK[1];          // 256-byte units of a view group: 1-KB HS rows, 768-B V rows
+        long long kib = (units + 3) / 4;
+        if (kib % 2 == 0) ++kib;                                        // an odd number of KiB apart, like the bit tiles
+        b.GSC = (int)(kib * 4);
+        if (hipMalloc(&c->d_ctiles, (size_t)G32 * b.GSC * 256) == hipSuccess) {
+            b.vcode = 1;
+            c->ctile_bytes = (size_t)G32 * units * 256;
+        } else {
+            (void)hipGetLastError();                                    // no room for the third copy: the fp4 form reads the bit tiles
+            b.GSC = b.GS;
+        }
+    }
     c->bcfg = b;
     const long long total_t = G32 * nkt * 64;
     hipLaunchKernelGGL(k_bitpack, dim3((unsigned)((total_t + 255) / 256)), dim3(256), 0, c->stream, c->d_tiles, c->d_btiles, c->cfg, b);
     HIP_TRY(c, hipGetLastError());
+    if (b.vcode) {
+        hipLaunchKernelGGL(k_bitpack_code, dim3((unsigned)((total_t + 255) / 256)), dim3(256), 0, c->stream, c->d_btiles,
+                           reinterpret_cast<unsigned*>(c->d_ctiles), c->cfg, b);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->bits_ok = true;
     c->coef_ready = false;
@@ -1177,6 +1207,7 @@ extern "C" int dv_get_library_info(const dv_ctx* c, dv_lib_info* o) {
     o->bit_planes_hs = c->bits_ok ? c->bcfg.T[0] : 0;
     o->bit_planes_v = c->bits_ok ? c->bcfg.T[1] : 0;
     o->bit_tile_bytes = c->bits_ok ? (int64_t)c->btile_bytes : 0;
+    o->code_tile_bytes = (c->bits_ok && c->bcfg.vcode) ? (int64_t)c->ctile_bytes : 0;
     return DV_OK;
 }
 
@@ -1452,13 +1483,17 @@ static void launch_mfma_ring(dv_ctx* c, int nchunk, int has_hs) {
 }
 
 // Both forms in one launch (k_sad_mfma_dual): the fp4 form when this prep's patches sit on the library's levels.
-template <int SK8, int RD8, int SK4, int RD4, int TILES, bool FUSE>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE>
 static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     static bool attr_set = false;
-    const size_t lds8 = (size_t)RD8 * (SK8 * 8 + 8 * SK8 * TILES) * 1024, lds4 = (size_t)RD4 * (SK4 * 4 + 8 * SK4 * TILES) * 1024;
-    const size_t lds = (lds8 > lds4 ? lds8 : lds4) + (FUSE ? (size_t)kFuseScratchBytes : 0);
+    const size_t lds8 = (size_t)RD8 * (SK8 * 8 + 8 * SK8 * TILES) * 1024;
+    const size_t lds4 = (size_t)fp4_ring_bytes(SK4, TILES, RD4, false), ldsc = (size_t)fp4_ring_bytes(SKC, TILES, RDC, true);
+    size_t lds = lds8 > lds4 ? lds8 : lds4;
+    if (ldsc > lds) lds = ldsc;
+    lds += FUSE ? (size_t)kFuseScratchBytes : 0;
+    static_assert(fp4_ring_bytes(SKC, TILES, RDC, true) + kFuseScratchBytes <= 160 * 1024 && fp4_ring_bytes(SK4, TILES, RD4, false) + kFuseScratchBytes <= 160 * 1024, "LDS");
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, TILES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long long G32 = c->cfg.Fpad / 32;
@@ -1468,16 +1503,17 @@ static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     FuseArgs fz{};
     if (FUSE) { fz = fuse_args(c); fz.nb = (int)items; }
     for (int a_off = 0; a_off < c->APAD; a_off += 32)
-        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, TILES, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
-                           c->d_coef + (size_t)(a_off / 32) * nkt * 512, c->d_coef4 + (size_t)(a_off / 32) * nkt * 256,
-                           c->d_offlevel + (c->prep_seq & 1), reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz);
+        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+                           c->bcfg.vcode ? c->d_ctiles : c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
+                           c->d_coef4 + (size_t)(a_off / 32) * nkt * 256, c->d_offlevel + (c->prep_seq & 1), reinterpret_cast<int*>(c->d_part),
+                           c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz);
     if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)items; }
 }
 
-template <int SK8, int RD8, int SK4, int RD4, int TILES>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES>
 static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
-    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, TILES, true>(c, nchunk, has_hs);
-    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, TILES, false>(c, nchunk, has_hs);
+    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, true>(c, nchunk, has_hs);
+    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, false>(c, nchunk, has_hs);
 }
 
 // Work items of k_sad_mfma = (chunk of K-steps, 8*TILES view groups of 32).  Two view groups per wave halve the
@@ -1511,16 +1547,18 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     const int var = c->mfma_variant_env;
     if (c->fp4_ok && var == 0) {
         const int v4 = c->fp4_variant_env;
+        // <int8 stage, ring | fp4 stage, ring (thermometer rows) | fp4 stage, ring (code rows), view groups per wave>
         if (tiles == 2) {
-            switch (v4) {                                      // 500 000 views x 128x128 x 32 headings: 0.96 / 1.07 ms
-                case 1: launch_mfma_dual<1, 3, 2, 2, 2>(c, nchunk, has_hs); break;
-                default: launch_mfma_dual<1, 3, 2, 3, 2>(c, nchunk, has_hs);
+            switch (v4) {                                      // 500 000 views x 128x128 x 32 headings, bit tiles: 0.96 / 1.07 ms
+                case 1: launch_mfma_dual<1, 3, 2, 3, 4, 2, 2>(c, nchunk, has_hs); break;
+                case 2: launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs); break;
+                default: launch_mfma_dual<1, 3, 2, 3, 2, 4, 2>(c, nchunk, has_hs);
             }
         } else {
-            switch (v4) {                                      // 50 000 views x 64x64 x 16 headings: 38.6 / 40.6 / 41.4 us
-                case 1: launch_mfma_dual<4, 2, 4, 3, 1>(c, nchunk, has_hs); break;
-                case 2: launch_mfma_dual<4, 2, 2, 6, 1>(c, nchunk, has_hs); break;
-                default: launch_mfma_dual<4, 2, 2, 4, 1>(c, nchunk, has_hs);
+            switch (v4) {                                      // 50 000 views x 64x64 x 16 headings, bit tiles: 38.6 / 40.6 / 41.4 us
+                case 1: launch_mfma_dual<4, 2, 4, 3, 4, 3, 1>(c, nchunk, has_hs); break;
+                case 2: launch_mfma_dual<4, 2, 2, 6, 2, 4, 1>(c, nchunk, has_hs); break;
+                default: launch_mfma_dual<4, 2, 2, 4, 2, 6, 1>(c, nchunk, has_hs);
             }
         }
         return;

@@ -2044,6 +2044,8 @@ struct BitCfg {
     int T[2];               // planes of the HS segment and of the V segment
     int NK[2];              // K-steps (256 K-elements) of each segment
     int GS;                 // 1-KB rows between consecutive view groups in btiles (>= NK[0] + NK[1], odd)
+    int vcode;              // 1: the fp4 form reads the V segment as 3-bit level codes (ctiles, see k_bitpack_code)
+    int GSC;                // 256-byte units between view groups in ctiles (>= 4 NK[0] + 3 NK[1])
     int wacc[2][4];         // fp4 form (sad_ring_fp4): the one gap width of the planes that land on bit b of a nibble, per segment
     int nbp;                // byte planes described below (= LibCfg::npl)
     unsigned char pl[kMaxBitPlanes];   // byte plane of bit plane t (HS planes first, then V)
@@ -2121,6 +2123,49 @@ k_bitpack(const uint4* __restrict__ tiles, uint4* __restrict__ btiles, LibCfg c,
         }
     }
     btiles[(g * b.GS + ks) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Code tiles: the library of the fp4 form when the value plane has exactly five levels (the reference's default
+// n_sensor_levels, NavBySceneFamiliarity.py:66): its four thermometer bits per pixel carry log2(5) bits of information, and
+// three stored bits decode back to them with two or three VALU operations per plane --
+//     level 0..4  ->  code b2 b1 b0 = 000, 001, 010, 110, 111:   t1 = b0 | b1,  t2 = b1,  t3 = b2,  t4 = b0 & b2.
+// The HS rows are the bit tiles' (1 KB: thermometer bits as they are).  A V row is THREE dwords per lane (768 B, moved
+// by 48 lanes of a global_load_lds_dwordx4) for the same K-step whose bit-tile row has four: nibble i of dword w (w = 0, 1, 2) holds in
+// bits 0..2 the code of the pixel whose thermometer bits are nibble i of dword w of the bit-tile row, and in bit 3 bit w
+// of the code of the pixel at nibble i of dword 3.  5 bits per pixel where the bit tiles take 6; the K-elements, hence
+// the coefficient image and the sums, are the same.  One thread per (view group of 32, K-step, lane).
+__device__ __forceinline__ unsigned level_code(unsigned thermo4) {       // thermometer nibble t4 t3 t2 t1 -> code
+    const unsigned level = __popc(thermo4 & 15u);
+    return level == 0 ? 0u : level == 1 ? 1u : level == 2 ? 2u : level == 3 ? 6u : 7u;
+}
+__global__ void __launch_bounds__(256)
+k_bitpack_code(const uint4* __restrict__ btiles, unsigned* __restrict__ ctiles, LibCfg c, BitCfg b) {
+    const int NKT = b.NK[0] + b.NK[1];
+    const long long G32 = c.Fpad / 32;
+    const long long total = G32 * NKT * 64;
+    const long long tt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tt >= total) return;
+    const int lane = (int)(tt & 63);
+    const long long rr = tt >> 6;
+    const int ks = (int)(rr % NKT);
+    const long long g = rr / NKT;
+    const uint4 own = btiles[(g * b.GS + ks) * 64 + lane];
+    unsigned* group = ctiles + g * b.GSC * 64;                          // GSC is in 256-byte units = 64 dwords
+    if (ks < b.NK[0]) {
+        reinterpret_cast<uint4*>(group + (long long)ks * 256)[lane] = own;
+    } else {
+        const unsigned o[4] = {own.x, own.y, own.z, own.w};
+        unsigned* row = group + (long long)b.NK[0] * 256 + (long long)(ks - b.NK[0]) * 192 + lane * 3;
+        for (int w = 0; w < 3; ++w) {
+            unsigned x = 0;
+            for (int i = 0; i < 8; ++i) {
+                const unsigned code = level_code(o[w] >> (4 * i));
+                const unsigned extra = (level_code(o[3] >> (4 * i)) >> w) & 1u;
+                x |= (code | (extra << 3)) << (4 * i);
+            }
+            row[w] = x;
+        }
+    }
 }
 
 // Per-step operand of the MFMA path, from the raw patches uint8[A][P][3] (left by k_prep / k_sense_prep):
@@ -2385,6 +2430,15 @@ __device__ __forceinline__ void lds_dma_16(const uint4* gsrc, unsigned lds_byte_
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+// A 768-byte row: lanes 0..47 move 16 bytes each, so the row lands in LDS without holes (global_load_lds_dwordx3 would put
+// every lane's 12 bytes 16 apart: tools/exp/lds_dma3.hip).  gsrc: row + 16 * lane (lanes 48..63 are masked off).
+__device__ __forceinline__ void lds_dma_768_nt(const unsigned char* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    unsigned long long keep_exec;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_lshr_b64 exec, -1, 16\n\t"
+                 "global_load_lds_dwordx4 %2, off nt\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(keep_exec) : "v"(gsrc), "s"(lds_byte_addr) : "memory", "scc");
 }
 __device__ __forceinline__ void lds_dma_16_nt(const uint4* gsrc, unsigned lds_byte_addr) {  // library rows: used once per step
     unsigned keep;
@@ -2764,30 +2818,198 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
-template <int SK, int TILES, int RD, bool FUSE>
+// LDS operand reads of the fp4 loop, written out: hipcc sinks ordinary LDS loads to their first use when registers are
+// tight (254 of 256 here), which put a full LDS round trip in front of every second MFMA (0.94 ms at 500 000 views whatever
+// the ring depth, stage length or HBM bytes).  The reads below stay where they are issued -- one K-step ahead of their use --
+// and lds_wait ties the registers to the counted wait, so nothing that uses them can move above it.
+template <int OFF>
+__device__ __forceinline__ void lds_read16(v4u_t& dst, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read12(v4u_t& dst, unsigned addr) {      // three dwords, 4-byte aligned
+    static_assert(OFF >= 0 && OFF + 8 < 65536, "ds offset field");
+    asm volatile("ds_read_b32 %0, %3 offset:%4\n\tds_read_b32 %1, %3 offset:%5\n\tds_read_b32 %2, %3 offset:%6"
+                 : "=&v"(dst.x), "=&v"(dst.y), "=&v"(dst.z) : "v"(addr), "n"(OFF), "n"(OFF + 4), "n"(OFF + 8));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_tie(v4u_t& a) { asm volatile("" : "+v"(a)); }
+template <int K> struct IntC { static constexpr int value = K; };
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IntC<I>{}); static_for<N, I + 1>(f); }
+}
+
+// One segment (HS or V) of one item in the fp4 form: the ring loop, then the segment's integer sums in tot.
+//   CODE = false: library rows are thermometer bits, 1 KB per K-step (bit tiles, or the HS rows of the code tiles);
+//   CODE = true : the V rows of the code tiles, 768 B per K-step (k_bitpack_code), decoded in registers:
+//                 t1 = (x | x >> 1) & m, t2 = x & 2m, t3 = x & 4m, t4 = x & (x >> 2) & m per code dword, m = 0x11111111.
+// [k0, k1): K-steps of the coefficient image (absolute); lib[t]: this lane's place in the library row of K-step k0
+// (row pitch 1024 or 768 bytes).  w[b]: gap width of the planes on bit b.
+template <int SK, int TILES, int RD, bool FUSE, bool CODE>
 __device__ __forceinline__ void
-sad_ring_fp4(const uint4* __restrict__ btiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
-             int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz) {
-    extern __shared__ uint4 lds_ring[];           // [RD][ coefficient rows SK*4 | library rows 8 waves * SK * TILES ][64], then FUSE scratch
+fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ coef4, int k0, int k1, const int (&w)[4],
+            int lane, int wave, int (&tot)[TILES][16]) {
+    extern __shared__ uint4 lds_ring[];
     constexpr int NW = 8;
-    constexpr int VW = NW * TILES;
-    constexpr int COEF_ROWS = SK * 4;             // per stage
+    constexpr int ROWB = CODE ? 768 : 1024;       // bytes of a library row, in HBM and in LDS
+    constexpr int LROWB = ROWB;
+    constexpr int COEF_ROWS = SK * 4;
     constexpr int LIB_ROWS = NW * SK * TILES;
-    constexpr int SLOT16 = (COEF_ROWS + LIB_ROWS) * 64;
+    constexpr int SLOTB = COEF_ROWS * 1024 + LIB_ROWS * LROWB;
     constexpr int CPW = COEF_ROWS / NW;
     constexpr int NDMA = CPW + SK * TILES;
     static_assert(COEF_ROWS % NW == 0 && RD >= 2 && NDMA * (RD - 1) < 64, "ring shape");
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
+    const int nst = (k1 - k0 + SK - 1) / SK;
+    v16f_t acc[TILES][4];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
+    if (nst > 0) {
+        // DMA instruction d of stage st: CPW coefficient rows of this wave, then its SK * TILES library rows
+        auto issue_one = [&](int st, int d) {
+            const int kb = k0 + st * SK;
+            const unsigned slot = lds_base + (unsigned)((st % RD) * SLOTB);
+            if (d < CPW) {
+                const int row = wave * CPW + d;                       // (K-step, bit position) row of the stage
+                long long src = ((long long)kb * 4 + row) * 64 + lane;
+                const long long lim = (long long)k1 * 256;
+                if (src >= lim) src = lim - 64 + lane;                // past the chunk: any valid row (masked below)
+                lds_dma_16(coef4 + src, __builtin_amdgcn_readfirstlane(slot + (unsigned)row * 1024u));
+            } else {
+                const int k = (d - CPW) / TILES, t = (d - CPW) % TILES;
+                const int row = (wave * SK + k) * TILES + t;
+                int lr = st * SK + k;
+                lr = lr < k1 - k0 ? lr : k1 - k0 - 1;                 // clamped: masked below
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)(COEF_ROWS * 1024 + row * LROWB));
+                if constexpr (CODE) lds_dma_768_nt(lib[t] + (long long)lr * ROWB, dst);
+                else lds_dma_16_nt(reinterpret_cast<const uint4*>(lib[t] + (long long)lr * ROWB), dst);
+            }
+        };
+        auto issue_stage = [&](int st) {
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d) issue_one(st, d);
+        };
+#pragma unroll
+        for (int r = 0; r < RD - 1; ++r) issue_stage(r);
+        for (int st = 0; st < nst; ++st) {
+            wait_vmcnt_le<NDMA * (RD - 2)>();
+            __builtin_amdgcn_s_barrier();
+            // The DMA of stage st + RD - 1 (into the slot everybody finished with a barrier ago) is NOT issued here in one
+            // burst: eight waves leaving the barrier together queue 8 x NDMA wave-instructions on the CU's one vector-memory
+            // path (16 cycles each) while every matrix pipe waits.  One instruction goes out after every few MFMAs instead,
+            // behind matrix work that is already running.
+            int dma_next = 0;
+            constexpr int MFMAS = SK * TILES * 4;
+            constexpr int EVERY = MFMAS / NDMA > 0 ? MFMAS / NDMA : 1;
+            int mfma_count = 0;
+            const int kb = k0 + st * SK;
+            const unsigned sad = lds_base + (unsigned)((st % RD) * SLOTB);
+            const unsigned cad = sad + (unsigned)lane * 16u;                                              // coefficient row r: + 1024 r
+            const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * SK * TILES * LROWB) + (unsigned)lane * (CODE ? 12u : 16u);
+            auto mfma = [&](int t, int s, const v4u_t& av, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+                const v8i_t bo = v8i_t{(int)b0, (int)b1, (int)b2, (int)b3, 0, 0, 0, 0};
+                const v8i_t ao = v8i_t{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+                if constexpr (FUSE) acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bo, ao, acc[t][s], 4, 4, 0, 0, 0, 0);   // views x headings
+                else acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[t][s], 4, 4, 0, 0, 0, 0);
+                if (++mfma_count % EVERY == 0 && dma_next < NDMA) issue_one(st + RD - 1, dma_next++);
+            };
+            // operands of K-step k of the stage: 4 coefficient rows, TILES library rows (READS instructions in all)
+            constexpr int READS = 4 + TILES * (CODE ? 3 : 1);
+            v4u_t a[2][4], xl[2][TILES];
+            auto fetch = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * 4 + s_) * 1024>(a[k & 1][s_], cad); });
+                static_for<TILES>([&](auto tc) {
+                    constexpr int t_ = decltype(tc)::value;
+                    if constexpr (CODE) lds_read12<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);
+                    else lds_read16<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);
+                });
+            };
+            fetch(IntC<0>{});
+            static_for<SK>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k + 1 < SK) {
+                    fetch(IntC<k + 1>{});                 // one K-step ahead
+                    lds_wait<READS>();                    // all but the newest READS reads have landed: K-step k's
+                } else {
+                    lds_wait<0>();
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) lds_tie(a[k & 1][s]);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) lds_tie(xl[k & 1][t]);
+                const bool on = kb + k < k1;
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    unsigned x[4] = {xl[k & 1][t].x, xl[k & 1][t].y, xl[k & 1][t].z, xl[k & 1][t].w};
+                    if constexpr (!CODE) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
+                            const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
+                            const int sh = s < 3 ? 0 : 2;
+                            mfma(t, s, a[k & 1][s], (x[0] >> sh) & m, (x[1] >> sh) & m, (x[2] >> sh) & m, (x[3] >> sh) & m);
+                        }
+                    } else {
+                        const unsigned m1 = 0x11111111u;
+                        const unsigned m = on ? m1 : 0u;
+                        // the fourth dword's pixels: bit 3 of the three code dwords' nibbles
+                        x[3] = ((x[0] >> 3) & m1) | ((x[1] >> 2) & (m1 << 1)) | ((x[2] >> 1) & (m1 << 2));
+                        // E2M1 operands of the four thermometer planes: t1, t4 as 0.5 (bit 0), t2 as 1 (bit 1), t3 as 2 (bit 2)
+                        mfma(t, 0, a[k & 1][0], (x[0] | (x[0] >> 1)) & m, (x[1] | (x[1] >> 1)) & m, (x[2] | (x[2] >> 1)) & m, (x[3] | (x[3] >> 1)) & m);
+                        mfma(t, 1, a[k & 1][1], x[0] & (m << 1), x[1] & (m << 1), x[2] & (m << 1), x[3] & (m << 1));
+                        mfma(t, 2, a[k & 1][2], x[0] & (m << 2), x[1] & (m << 2), x[2] & (m << 2), x[3] & (m << 2));
+                        mfma(t, 3, a[k & 1][3], x[0] & (x[0] >> 2) & m, x[1] & (x[1] >> 2) & m, x[2] & (x[2] >> 2) & m, x[3] & (x[3] >> 2) & m);
+                    }
+                }
+            });
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d)
+                if (d >= dma_next) issue_one(st + RD - 1, d);         // (none left when the MFMAs divide evenly)
+        }
+        wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+    // bits stood for 0.5 / 1 / 2 / (1, CODE: 0.5): signed counts 2 acc0, acc1, acc2 / 2, acc3 (CODE: 2 acc3) -- integers --
+    // each times the gap width of the planes on that bit position (widths < 256, |counts| < 2^23)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tot[t][r] = __mul24(w[0], (int)(2.f * acc[t][0][r])) + __mul24(w[1], (int)acc[t][1][r]) + __mul24(w[2], (int)(0.5f * acc[t][2][r])) +
+                        __mul24(w[3], (int)((CODE ? 2.f : 1.f) * acc[t][3][r]));
+}
+
+// LDS the rings of fp4_segment take (the FUSE scratch sits behind the larger of a kernel's two).
+constexpr int fp4_ring_bytes(int SK, int TILES, int RD, bool code) { return RD * (SK * 4 * 1024 + 8 * SK * TILES * (code ? 768 : 1024)); }
+
+template <int SK, int TILES, int RD, int SKC, int RDC, bool FUSE>
+__device__ __forceinline__ void
+sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
+             int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz) {
+    extern __shared__ uint4 lds_ring[];           // the rings of fp4_segment, then the FUSE scratch
+    constexpr int NW = 8;
+    constexpr int VW = NW * TILES;
+    constexpr int RING = fp4_ring_bytes(SK, TILES, RD, false) > fp4_ring_bytes(SKC, TILES, RDC, true) ? fp4_ring_bytes(SK, TILES, RD, false)
+                                                                                                         : fp4_ring_bytes(SKC, TILES, RDC, true);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long G32 = c.Fpad / 32;
     const long long GQ = (G32 + VW - 1) / VW;
     const long long n_items = GQ * nchunk;
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
-    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
+    const long long gbytes = b.vcode ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / GQ);
         const long long gq = item - (long long)ch * GQ;
-        const uint4* lib[TILES];
+        const unsigned char* grp[TILES];
         long long gidx[TILES];
         bool live[TILES];
 #pragma unroll
@@ -2796,139 +3018,67 @@ sad_ring_fp4(const uint4* __restrict__ btiles, const uint4* __restrict__ coef4, 
             live[t] = g < G32;
             if (!live[t]) g = G32 - 1;
             gidx[t] = g;
-            lib[t] = btiles + (g * b.GS) * 64 + lane;
+            grp[t] = reinterpret_cast<const unsigned char*>(ftiles) + g * gbytes;
         }
-        int parkr[TILES][16];                             // FUSE: the saturation sums wait here for the value sums
-        (void)parkr;
-#pragma unroll 1
-        for (int seg = 0; seg < 2; ++seg) {
-            if (seg == 0 && !has_hs_sum) continue;
-            if (seg == 1 && !c.hasv) continue;
-            const int kbase = seg ? b.NK[0] : 0;
-            const int k0 = kbase + (int)(((long long)ch * b.NK[seg]) / nchunk);
-            const int k1 = kbase + (int)(((long long)(ch + 1) * b.NK[seg]) / nchunk);
-            const int nst = (k1 - k0 + SK - 1) / SK;
-            v16f_t acc[TILES][4];
+        int tot_hs[TILES][16], tot_v[TILES][16];
+        (void)tot_hs;
+        (void)tot_v;
+        if (has_hs_sum) {
+            const int k0 = (int)(((long long)ch * b.NK[0]) / nchunk), k1 = (int)(((long long)(ch + 1) * b.NK[0]) / nchunk);
+            const unsigned char* lib[TILES];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t)
+            for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)k0 * 1024 + lane * 16;
+            fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, k0, k1, b.wacc[0], lane, wave, tot_hs);
+        }
+        if (c.hasv) {
+            const int r0 = (int)(((long long)ch * b.NK[1]) / nchunk), r1 = (int)(((long long)(ch + 1) * b.NK[1]) / nchunk);
+            const unsigned char* lib[TILES];
+            if (b.vcode) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)b.NK[0] * 1024 + (long long)r0 * 768 + lane * 16;   // (lanes 0..47 move the row)
+                fp4_segment<SKC, TILES, RDC, FUSE, true>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v);
+            } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
-            if (nst > 0) {
-                auto kclamp = [&](int k) { return k < k1 ? k : k1 - 1; };
-                auto issue_stage = [&](int st) {
-                    const int kb = k0 + st * SK;
-                    const unsigned slot = lds_base + (unsigned)((st % RD) * SLOT16) * 16u;
-#pragma unroll
-                    for (int i = 0; i < CPW; ++i) {
-                        const int row = wave * CPW + i;                       // (K-step, bit position) row of the stage
-                        long long src = ((long long)kb * 4 + row) * 64 + lane;
-                        const long long lim = (long long)k1 * 256;
-                        if (src >= lim) src = lim - 64 + lane;                // past the chunk: any valid row (masked below)
-                        lds_dma_16(coef4 + src, __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u));
-                    }
-#pragma unroll
-                    for (int k = 0; k < SK; ++k)
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) {
-                            const int row = COEF_ROWS + (wave * SK + k) * TILES + t;
-                            lds_dma_16_nt(lib[t] + (long long)kclamp(kb + k) * 64, __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u));
-                        }
-                };
-#pragma unroll
-                for (int r = 0; r < RD - 1; ++r) issue_stage(r);
-                for (int st = 0; st < nst; ++st) {
-                    wait_vmcnt_le<NDMA * (RD - 2)>();
-                    __builtin_amdgcn_s_barrier();
-                    issue_stage(st + RD - 1);
-                    const int kb = k0 + st * SK;
-                    const uint4* cbuf = lds_ring + (st % RD) * SLOT16 + lane;
-                    const uint4* lbuf = cbuf + (COEF_ROWS + wave * SK * TILES) * 64;
-                    uint4 a[2][4], xl[2][TILES];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) a[0][s] = cbuf[s * 64];
-#pragma unroll
-                    for (int t = 0; t < TILES; ++t) xl[0][t] = lbuf[t * 64];
-#pragma unroll
-                    for (int k = 0; k < SK; ++k) {
-                        if (k + 1 < SK) {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) a[(k + 1) & 1][s] = cbuf[((k + 1) * 4 + s) * 64];
-#pragma unroll
-                            for (int t = 0; t < TILES; ++t) xl[(k + 1) & 1][t] = lbuf[((k + 1) * TILES + t) * 64];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        const bool on = kb + k < k1;
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) {
-                            const uint4 x = xl[k & 1][t];
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
-                                const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
-                                const int sh = s < 3 ? 0 : 2;
-                                const v8i_t bo = v8i_t{(int)((x.x >> sh) & m), (int)((x.y >> sh) & m), (int)((x.z >> sh) & m), (int)((x.w >> sh) & m), 0, 0, 0, 0};
-                                const uint4 w = a[k & 1][s];
-                                const v8i_t ao = v8i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w, 0, 0, 0, 0};
-                                if constexpr (FUSE) acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bo, ao, acc[t][s], 4, 4, 0, 0, 0, 0);   // views x headings
-                                else acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[t][s], 4, 4, 0, 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-                wait_vmcnt_le<0>();
-                __builtin_amdgcn_s_barrier();
+                for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)(b.NK[0] + r0) * 1024 + lane * 16;
+                fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v);
             }
-            const int type_row = seg ? has_hs_sum : 0;
+        }
+        if constexpr (!FUSE) {
             const int nsum = has_hs_sum + c.hasv;
-            const int w0 = b.wacc[seg][0], w1 = b.wacc[seg][1], w2 = b.wacc[seg][2], w3 = b.wacc[seg][3];
-            // bits stood for 0.5 / 1 / 2 / 1: signed counts 2 acc0, acc1, acc2 / 2, acc3 (integers), each times the gap width of
-            // the planes on that bit position
-            int tot[TILES][16];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t)
+            for (int t = 0; t < TILES; ++t) {
+                if (live[t]) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tot[t][r] = __mul24(w0, (int)(2.f * acc[t][0][r])) + __mul24(w1, (int)acc[t][1][r]) + __mul24(w2, (int)(0.5f * acc[t][2][r])) + __mul24(w3, (int)acc[t][3][r]);   // widths < 256, |counts| < 2^23
-            if constexpr (!FUSE) {
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    if (live[t]) {
+                    for (int seg = 0; seg < 2; ++seg) {
+                        if (seg == 0 ? !has_hs_sum : !c.hasv) continue;
+                        const int type_row = seg ? has_hs_sum : 0;
                         int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            if (m < rows) dst[(long long)m * c.Fpad] = tot[t][r];
+                            if (m < rows) dst[(long long)m * c.Fpad] = seg ? tot_v[t][r] : tot_hs[t][r];
                         }
                     }
                 }
-            } else {
-                if (seg == 0 && c.hasv) {
-#pragma unroll
-                    for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) parkr[t][r] = tot[t][r];
-                } else {
-                    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds_ring + RD * SLOT16);
-                    auto of_tot = [&](int t, int r) -> int { return tot[t][r]; };
-                    auto of_park = [&](int t, int r) -> int { return parkr[t][r]; };
-                    if (seg == 0) fused_finish<TILES, NW>(of_tot, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
-                    else fused_finish<TILES, NW>(of_park, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
-                }
             }
+        } else {
+            unsigned long long* scratch = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING);
+            auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
+            auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
+            fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
         }
     }
 }
 
-// One launch, both forms: `offlevel` (k_bit_prep) says whether this step's patches allow the fp4 coefficients.
-template <int SK8, int RD8, int SK4, int RD4, int TILES, bool FUSE>
+// One launch, both forms: `offlevel` (k_bit_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form
+// reads ftiles (the code tiles when the library has them, else the bit tiles), the int8 form the bit tiles.
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE>
 __global__ void __launch_bounds__(512, 2)
-k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4,
+k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ ftiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4,
                 const unsigned* __restrict__ offlevel, int* __restrict__ part, LibCfg c, BitCfg b, int nchunk, int apad_total, int a_off,
                 int has_hs_sum, FuseArgs fz) {
     if (__builtin_amdgcn_readfirstlane(*offlevel) == 0u)
-        sad_ring_fp4<SK4, TILES, RD4, FUSE>(btiles, coef4, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
+        sad_ring_fp4<SK4, TILES, RD4, SKC, RDC, FUSE>(ftiles, coef4, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
     else
         sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
 }

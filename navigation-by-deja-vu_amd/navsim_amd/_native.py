@@ -66,6 +66,7 @@ class LibInfo(ctypes.Structure):
         ("has_bit_planes", ctypes.c_int32),
         ("fp4_form", ctypes.c_int32),
         ("bit_tile_bytes", ctypes.c_int64),
+        ("code_tile_bytes", ctypes.c_int64),
     ]
 
 

@@ -106,7 +106,7 @@ class FamiliarityEngine(object):
                     chem_weight=info.chem_weight, delta=info.delta, hues=[int(x) for x in info.hues][:info.n_hues],
                     signed_saturation=bool(info.signed_saturation), has_bit_planes=bool(info.has_bit_planes),
                     bit_planes_hs=info.bit_planes_hs, bit_planes_v=info.bit_planes_v, bit_tile_bytes=info.bit_tile_bytes,
-                    fp4_form=bool(info.fp4_form))
+                    fp4_form=bool(info.fp4_form), code_tile_bytes=info.code_tile_bytes)
 
     def read_planes(self, v0, n):
         info = self.library_info()

@@ -1052,7 +1052,7 @@ def test_ties_inside_one_finishing_block_of_several_view_sets():
 
 def _engine_with(env):
     import os
-    keys = ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FP4", "DEJAVU_FUSE", "DEJAVU_FP4_VARIANT", "DEJAVU_MFMA_TILES")
+    keys = ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FP4", "DEJAVU_FUSE", "DEJAVU_FP4_VARIANT", "DEJAVU_MFMA_TILES", "DEJAVU_VCODE")
     before = {k: os.environ.pop(k, None) for k in keys}
     os.environ.update(env)
     try:
@@ -1075,15 +1075,19 @@ def test_fp4_form_gives_the_int8_forms_sums(F, h, w, A, cw, tiles):
     pat[A // 2] = synth.near_match_patch(lib[F // 3], 5, fraction=0.03)
     want = oracle.step(lib, pat, cw)
     seen = {}
-    for fp4 in ("1", "0"):
+    for fp4 in ("1", "code", "0"):                    # "code": the value plane as 3-bit level codes (DEJAVU_VCODE=1, k_bitpack_code)
         for fuse in ("1", "0"):
-            e = _engine_with(dict(DEJAVU_SHAPE="6", DEJAVU_BITS="2", DEJAVU_FP4=fp4, DEJAVU_FUSE=fuse, DEJAVU_MFMA_TILES=tiles))
+            e = _engine_with(dict(DEJAVU_SHAPE="6", DEJAVU_BITS="2", DEJAVU_FP4="0" if fp4 == "0" else "1", DEJAVU_FUSE=fuse,
+                                  DEJAVU_MFMA_TILES=tiles, DEJAVU_VCODE="1" if fp4 == "code" else "0"))
             try:
                 e.set_library(lib, cw)
                 info = e.library_info()
-                assert info["has_bit_planes"] and info["fp4_form"] == (fp4 == "1")
+                assert info["has_bit_planes"] and info["fp4_form"] == (fp4 != "0")
+                assert (info["code_tile_bytes"] > 0) == (fp4 == "code" and cw < 1.0)
+                if info["code_tile_bytes"]:
+                    assert info["code_tile_bytes"] < info["bit_tile_bytes"]
                 got = e.step(pat, want_scene=False)
-                if fp4 == "1":
+                if fp4 != "0":
                     assert e.patches_on_level()
                 assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]) == (A // 2, F // 3)
                 np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL, atol=1e-12)

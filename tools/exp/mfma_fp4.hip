@@ -23,6 +23,35 @@ __global__ void k_one(const uint4* a, const uint4* b, float* d) {
     for (int r = 0; r < 16; ++r) d[r * 64 + lane] = c[r];
 }
 
+// MFMA with its B operand made by VALU right before it (NV v_and per operand dword set), as the scoring kernel does
+template <int NV, bool FP4>
+__global__ void __launch_bounds__(256) k_rate_valu(const uint4* a, float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    const uint4 av = a[lane];
+    v8i_t A = {(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+    v4i_t A4 = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+    v16f_t c[4]; v16i_t ci[4];
+    for (int s = 0; s < 4; ++s) for (int r = 0; r < 16; ++r) { c[s][r] = 0.f; ci[s][r] = 0; }
+    unsigned x0 = av.x, x1 = av.y, x2 = av.z, x3 = av.w;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            unsigned b0 = x0, b1 = x1, b2 = x2, b3 = x3;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const unsigned m = (0x11111111u << ((s + v) & 3)) | (unsigned)it;
+                b0 = (b0 >> v) & m; b1 = (b1 >> v) & m; b2 = (b2 >> v) & m; b3 = (b3 >> v) & m;
+            }
+            if (FP4) { v8i_t B = {(int)b0, (int)b1, (int)b2, (int)b3, 0, 0, 0, 0}; c[s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c[s], 4, 4, 0, 0, 0, 0); }
+            else { v4i_t B = {(int)b0, (int)b1, (int)b2, (int)b3}; ci[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A4, B, ci[s], 0, 0, 0); }
+        }
+        x0 += 0x9E3779B9u; x1 ^= x0; x2 += x1; x3 ^= x2;
+    }
+    float sum = 0.f;
+    for (int s = 0; s < 4; ++s) for (int r = 0; r < 16; ++r) sum += c[s][r] + (float)ci[s][r];
+    if (sum == 12345.678f) out[0] = sum;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rate(const uint4* a, float* out, int iters) {
     const int lane = threadIdx.x & 63;
@@ -103,6 +132,23 @@ int main() {
             if (rep) printf("%s: %.3f ms, %.1f Top/s, %.1f ns per MFMA per SIMD\n", mode == 0 ? "fp4 32x32x64" : "i8 32x32x32", ms, ops / ms * 1e-9,
                             ms * 1e6 / (n / 1024.0));
         }
+    }
+    {
+        auto time = [&](auto kern, const char* name) {
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(kern, dim3(256 * 2), dim3(256), 0, 0, da, dout, iters);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                const double n = 512.0 * 4 * iters * 4;
+                if (rep) printf("%s: %.3f ms, %.1f ns per MFMA per SIMD\n", name, ms, ms * 1e6 / (n / 1024.0));
+            }
+        };
+        time(k_rate_valu<1, true>, "fp4 + 8 VALU per MFMA (1 shift+and per dword)");
+        time(k_rate_valu<2, true>, "fp4 + 16 VALU per MFMA");
+        time(k_rate_valu<3, true>, "fp4 + 24 VALU per MFMA");
+        time(k_rate_valu<1, false>, "i8 + 8 VALU per MFMA");
+        time(k_rate_valu<2, false>, "i8 + 16 VALU per MFMA");
     }
     return 0;
 }
