@@ -2205,8 +2205,9 @@ extern "C" int dv_stream_read_gbps(dv_ctx* c, int64_t n_bytes, int iters, double
     if (e == hipSuccess) e = hipMemsetAsync(buf, 0x5a, (size_t)n16 * 16, c->stream);
     float ms = 0.f;
     if (e == hipSuccess) {
-        const dim3 grid(256 * 2), block(512);
-        const size_t lds = 64 * 1024;
+        const dim3 grid(256), block(512);
+        const size_t lds = (size_t)8 * kStreamRows * 1024;
+        (void)hipFuncSetAttribute((const void*)k_stream_read, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_stream_read, grid, block, lds, c->stream, buf, n16, sink);   // warm-up
         e = hipEventRecord(c->t0, c->stream);
         for (int i = 0; i < iters && e == hipSuccess; ++i) {

@@ -3134,20 +3134,22 @@ k_path_error(const double* __restrict__ xy, long long n, double x, double y, dou
 }
 
 // Streaming-read microbenchmark: the scoring kernels' access pattern without their arithmetic -- every wave pulls 1-KB
-// rows straight into LDS by non-temporal LDS-DMA, eight rows in flight per wave, eight waves per workgroup -- as the
-// measured ceiling the library stream is held against.
+// rows straight into LDS by non-temporal LDS-DMA, sixteen rows in flight per wave, eight waves per workgroup, one workgroup
+// per CU (tools/exp/dma_rate.hip: 5.7 TB/s with eight in flight, 6.7 with sixteen) -- as the measured ceiling the library
+// stream is held against.
+constexpr int kStreamRows = 16;
 __global__ void __launch_bounds__(512)
 k_stream_read(const uint4* __restrict__ src, long long n16, unsigned* __restrict__ sink) {
-    extern __shared__ uint4 lds_stream[];          // [8 waves][8 rows][64]
+    extern __shared__ uint4 lds_stream[];          // [8 waves][kStreamRows rows][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned base = (unsigned)(unsigned long long)(lds_ptr_t)lds_stream + (unsigned)wave * 8u * 1024u;
+    const unsigned base = (unsigned)(unsigned long long)(lds_ptr_t)lds_stream + (unsigned)wave * (unsigned)kStreamRows * 1024u;
     const long long rows = n16 / 64;
     const long long stride = (long long)gridDim.x * 8;
     long long row = (long long)blockIdx.x * 8 + wave;
-    for (; row + 7 * stride < rows; row += 8 * stride) {
+    for (; row + (kStreamRows - 1) * stride < rows; row += kStreamRows * stride) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lds_dma_16_nt(src + (row + i * stride) * 64 + lane, __builtin_amdgcn_readfirstlane(base + (unsigned)i * 1024u));
+        for (int i = 0; i < kStreamRows; ++i) lds_dma_16_nt(src + (row + i * stride) * 64 + lane, __builtin_amdgcn_readfirstlane(base + (unsigned)i * 1024u));
         wait_vmcnt_le<0>();
     }
     for (; row < rows; row += stride) {
