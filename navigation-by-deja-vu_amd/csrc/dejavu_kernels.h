@@ -2177,51 +2177,70 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
            int A, int npass, uint4* __restrict__ coef4, unsigned* __restrict__ offlevel, int slot) {
     const int NKT = b.NK[0] + b.NK[1];
     const int ncoef = NKT * npass;
-    if (coef4 && blockIdx.x == 0 && threadIdx.x == 0) offlevel[slot ^ 1] = 0;      // the next prep's word starts clean
+    if (coef4 && blockIdx.x == 0 && threadIdx.x == 0) offlevel[slot ^ 1] = 0;
+    // the plane tables are indexed per K-element: out of LDS, not out of the kernel-argument segment (a dependent load per
+    // access there: the per-heading blocks took 23 us and the image blocks 16 us of a 100-us agent step)
+    __shared__ unsigned char t_pl[kMaxBitPlanes], t_lo[kMaxBitPlanes], t_w[kMaxBitPlanes], t_lmin[kMaxHues + 1], t_lmax[kMaxHues + 1];
+    if (threadIdx.x < kMaxBitPlanes) { t_pl[threadIdx.x] = b.pl[threadIdx.x]; t_lo[threadIdx.x] = b.lo[threadIdx.x]; t_w[threadIdx.x] = b.w[threadIdx.x]; }
+    if (threadIdx.x < kMaxHues + 1) { t_lmin[threadIdx.x] = b.lmin[threadIdx.x]; t_lmax[threadIdx.x] = b.lmax[threadIdx.x]; }
+    __syncthreads();      // the next prep's word starts clean
     if ((int)blockIdx.x < ncoef) {
+        // One K-step of both images.  Thread (lane, g) owns bits 4g .. 4g+3 of the lane's four library dwords: 16 K-elements,
+        // each looked at ONCE (one division per dword to find its pixel and plane, then counting up), and its coefficient goes
+        // to both images through LDS -- a byte of row s = bit % 8 of the int8 image, a nibble of row b = bit % 4 of the fp4
+        // image (+1.0 = 0x2, -1.0 = 0xA; a byte strictly inside a gap has no such coefficient and flags the prep).
+        __shared__ unsigned img8[8 * 64 * 4];
+        __shared__ unsigned img4[4 * 64 * 4];
         const int pass = blockIdx.x / NKT, ks = blockIdx.x % NKT;
-        const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
         const int a = pass * 32 + (lane & 31), half = lane >> 5;
         const int seg = ks >= b.NK[0] ? 1 : 0;
         const int ksl = ks - (seg ? b.NK[0] : 0);
-        unsigned w[4] = {0, 0, 0, 0};
-        if (a < A) {
-            const unsigned char* p = raw + (long long)a * c.P * 3;
+        for (int i = threadIdx.x; i < 8 * 64 * 4; i += blockDim.x) img8[i] = 0;
+        for (int i = threadIdx.x; i < 4 * 64 * 4; i += blockDim.x) img4[i] = 0;
+        const int T = b.T[seg], first = seg ? b.T[0] : 0;
+        // the pixels this K-step touches (256 consecutive K-elements = at most 257 pixels), of all 32 headings, staged in LDS
+        // with coalesced reads: a lane is a heading here, and lanes reading their own heading's bytes from HBM touch 32
+        // cache lines per instruction (the kernel took 23 us of a 100-us agent step that way)
+        __shared__ unsigned char pix[32][257 * 3 + 1];
+        const int px_lo = T > 0 ? (int)(((long long)ksl * 256) / T) : 0;
+        int px_hi = T > 0 ? (int)(((long long)ksl * 256 + 255) / T) : -1;
+        if (px_hi >= c.P) px_hi = c.P - 1;
+        const int nbytes = px_hi >= px_lo ? (px_hi - px_lo + 1) * 3 : 0;
+        for (int i = threadIdx.x; i < 32 * nbytes; i += blockDim.x) {
+            const int h = i / nbytes, o = i - h * nbytes;
+            const int ah = pass * 32 + h;
+            pix[h][o] = ah < A ? raw[(long long)ah * c.P * 3 + (long long)px_lo * 3 + o] : (unsigned char)0;
+        }
+        __syncthreads();
+        bool off = false;
+        if (a < A && T > 0) {
+            const unsigned char* p = &pix[lane & 31][0] - (long long)px_lo * 3;      // p[px * 3 + channel] as before
+            unsigned char* img8b = reinterpret_cast<unsigned char*>(img8);
             for (int j = 0; j < 4; ++j) {
-                const long long n0 = (((long long)ksl * 2 + half) * 4 + j) * 32;
-                for (int bb = 0; bb < 4; ++bb) {
-                    int plane, px;
-                    if (!bit_element(b, c.P, seg, n0 + s + 8 * bb, plane, px)) continue;
-                    const int av = (int)plane_byte(c, b.pl[plane], p[px * 3], p[px * 3 + 1], p[px * 3 + 2]);
-                    int alpha = av - (int)b.lo[plane];
-                    alpha = alpha < 0 ? 0 : (alpha > (int)b.w[plane] ? (int)b.w[plane] : alpha);
-                    w[j] |= ((unsigned)((int)b.w[plane] - 2 * alpha) & 0xffu) << (8 * bb);
+                const unsigned n = (unsigned)((ksl * 2 + half) * 4 + j) * 32u + 4u * (unsigned)g;     // < T * P + 256: fits 32 bits
+                int px = (int)(n / (unsigned)T), r = (int)(n - (unsigned)px * (unsigned)T);
+                for (int e = 0; e < 4; ++e) {
+                    if (px >= c.P) break;                              // zero beyond the last pixel
+                    const int plane = first + r;
+                    const int av = (int)plane_byte(c, t_pl[plane], p[px * 3], p[px * 3 + 1], p[px * 3 + 2]);
+                    const int wd = (int)t_w[plane];
+                    const int al = av - (int)t_lo[plane];
+                    const int alpha = al < 0 ? 0 : (al > wd ? wd : al);
+                    img8b[((4 * (g & 1) + e) * 64 + lane) * 16 + j * 4 + (g >> 1)] = (unsigned char)((wd - 2 * alpha) & 0xff);
+                    if (coef4) {
+                        if (al <= 0) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0x2u << (4 * g));
+                        else if (al >= wd) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0xAu << (4 * g));
+                        else off = true;
+                    }
+                    if (++r == T) { r = 0; ++px; }
                 }
             }
         }
-        coef[((long long)blockIdx.x * 8 + s) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
-        if (coef4 && s < 4) {
-            // fp4 (E2M1) image of the same K-step: nibble i of dword j = sign of the coefficient of library bit 4i + s of
-            // that dword, +1.0 (0x2) or -1.0 (0xA); the magnitude is the segment's one gap width, multiplied in at the end.
-            // A patch byte strictly inside a gap has no such coefficient: the step then takes the int8 image.
-            unsigned v[4] = {0, 0, 0, 0};
-            bool off = false;
-            if (a < A) {
-                const unsigned char* p = raw + (long long)a * c.P * 3;
-                for (int j = 0; j < 4; ++j) {
-                    const long long n0 = (((long long)ksl * 2 + half) * 4 + j) * 32;
-                    for (int i = 0; i < 8; ++i) {
-                        int plane, px;
-                        if (!bit_element(b, c.P, seg, n0 + 4 * i + s, plane, px)) continue;
-                        const int av = (int)plane_byte(c, b.pl[plane], p[px * 3], p[px * 3 + 1], p[px * 3 + 2]);
-                        const int alpha = av - (int)b.lo[plane];
-                        if (alpha <= 0) v[j] |= 0x2u << (4 * i);
-                        else if (alpha >= (int)b.w[plane]) v[j] |= 0xAu << (4 * i);
-                        else off = true;
-                    }
-                }
-            }
-            coef4[((long long)blockIdx.x * 4 + s) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+        __syncthreads();
+        coef[((long long)blockIdx.x * 8 + g) * 64 + lane] = reinterpret_cast<const uint4*>(img8)[g * 64 + lane];
+        if (coef4) {
+            if (g < 4) coef4[((long long)blockIdx.x * 4 + g) * 64 + lane] = reinterpret_cast<const uint4*>(img4)[g * 64 + lane];
             if (off) atomicOr(&offlevel[slot], 1u);
         }
         return;
@@ -2231,17 +2250,28 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
     int k_hs = 0, k_v = 0;
     const unsigned char* p = raw + (long long)a * c.P * 3;
     const int nplanes = b.T[0] + b.T[1];
-    for (int px = threadIdx.x; px < c.P; px += blockDim.x) {
-        const unsigned H = p[px * 3], S = p[px * 3 + 1], V = p[px * 3 + 2];
+    // eight pixels per round, their 24 byte loads issued together (one round trip per round instead of one per pixel)
+    for (int px0 = threadIdx.x; px0 < c.P; px0 += 8 * blockDim.x) {
+      unsigned hsv[8][3];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+          const int px = px0 + i * blockDim.x;
+          const int pc = px < c.P ? px : c.P - 1;
+          hsv[i][0] = p[pc * 3]; hsv[i][1] = p[pc * 3 + 1]; hsv[i][2] = p[pc * 3 + 2];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (px0 + i * (int)blockDim.x >= c.P) break;
+        const unsigned H = hsv[i][0], S = hsv[i][1], V = hsv[i][2];
         for (int bp = 0; bp < b.nbp; ++bp) {
             const int av = (int)plane_byte(c, bp, H, S, V);
             int k = 0;
-            if (av < (int)b.lmin[bp]) k += (int)b.lmin[bp] - av;
-            if (av > (int)b.lmax[bp]) k += av - (int)b.lmax[bp];
+            if (av < (int)t_lmin[bp]) k += (int)t_lmin[bp] - av;
+            if (av > (int)t_lmax[bp]) k += av - (int)t_lmax[bp];
             for (int t = 0; t < nplanes; ++t) {
-                if (b.pl[t] != bp) continue;
-                const int al = av - (int)b.lo[t];
-                k += al < 0 ? 0 : (al > (int)b.w[t] ? (int)b.w[t] : al);
+                if (t_pl[t] != bp) continue;
+                const int al = av - (int)t_lo[t];
+                k += al < 0 ? 0 : (al > (int)t_w[t] ? (int)t_w[t] : al);
             }
             if (bp < c.nhs) k_hs += k; else k_v += k;
         }
@@ -2252,6 +2282,7 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
             if (!in_set) k_hs += (int)S;
             else if (c.signed_s && S > 127u) k_hs += (int)S - 127;
         }
+      }
     }
     red[0][threadIdx.x] = k_hs;
     red[1][threadIdx.x] = k_v;
