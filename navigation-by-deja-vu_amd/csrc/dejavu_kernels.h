@@ -2051,6 +2051,8 @@ struct BitCfg {
     unsigned char pl[kMaxBitPlanes];   // byte plane of bit plane t (HS planes first, then V)
     unsigned char lo[kMaxBitPlanes];   // lower level of its gap
     unsigned char w[kMaxBitPlanes];    // width of the gap (<= 127)
+    unsigned char wfull[kMaxBitPlanes];   // fp4 form: whole distance to the next library level for the FIRST plane of a gap that was
+                                          // split to fit int8 coefficients (its copies carry the same bits: they get 0 here and no sign)
     unsigned char lmin[kMaxHues + 1], lmax[kMaxHues + 1];   // per byte plane: smallest / largest library value
 };
 
@@ -2181,7 +2183,8 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
     // the plane tables are indexed per K-element: out of LDS, not out of the kernel-argument segment (a dependent load per
     // access there: the per-heading blocks took 23 us and the image blocks 16 us of a 100-us agent step)
     __shared__ unsigned char t_pl[kMaxBitPlanes], t_lo[kMaxBitPlanes], t_w[kMaxBitPlanes], t_lmin[kMaxHues + 1], t_lmax[kMaxHues + 1];
-    if (threadIdx.x < kMaxBitPlanes) { t_pl[threadIdx.x] = b.pl[threadIdx.x]; t_lo[threadIdx.x] = b.lo[threadIdx.x]; t_w[threadIdx.x] = b.w[threadIdx.x]; }
+    __shared__ unsigned char t_wfull[kMaxBitPlanes];
+    if (threadIdx.x < kMaxBitPlanes) { t_pl[threadIdx.x] = b.pl[threadIdx.x]; t_lo[threadIdx.x] = b.lo[threadIdx.x]; t_w[threadIdx.x] = b.w[threadIdx.x]; t_wfull[threadIdx.x] = b.wfull[threadIdx.x]; }
     if (threadIdx.x < kMaxHues + 1) { t_lmin[threadIdx.x] = b.lmin[threadIdx.x]; t_lmax[threadIdx.x] = b.lmax[threadIdx.x]; }
     __syncthreads();      // the next prep's word starts clean
     if ((int)blockIdx.x < ncoef) {
@@ -2229,9 +2232,12 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
                     const int alpha = al < 0 ? 0 : (al > wd ? wd : al);
                     img8b[((4 * (g & 1) + e) * 64 + lane) * 16 + j * 4 + (g >> 1)] = (unsigned char)((wd - 2 * alpha) & 0xff);
                     if (coef4) {
-                        if (al <= 0) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0x2u << (4 * g));
-                        else if (al >= wd) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0xAu << (4 * g));
-                        else off = true;
+                        const int wf = (int)t_wfull[plane];            // 0: a copy of a split gap's first plane
+                        if (wf) {
+                            if (al <= 0) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0x2u << (4 * g));
+                            else if (al >= wf) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0xAu << (4 * g));
+                            else off = true;
+                        }
                     }
                     if (++r == T) { r = 0; ++px; }
                 }
@@ -2837,7 +2843,8 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
 // reference's patches come through the quantiser the library came through, NavBySceneFamiliarity.py:176-186), every
 // coefficient w_t - 2 alpha_t is +w_t or -w_t; and when the planes that land on bit position b of a nibble all have one
 // gap width w_b (K-element n = plane n % T sits on bit n % 4: always so for 1, 2 or 4 planes per pixel, else when the
-// widths agree), the sum over the K-elements on bit b is
+// widths agree; a gap wider than 127 was split for the int8 form into planes with the same bits: its first plane
+// stands for the whole gap here and the copies get coefficient 0), the sum over the K-elements on bit b is
 //     sum B (w - 2 alpha) = w_b * sum B * (+-1):
 // the signs are exact in fp4 (E2M1: +-1.0), the library bits too (bit 0/1/2 of a nibble ARE the E2M1 values 0.5/1/2, bit 3
 // comes down by a shift), and v_mfma_f32_32x32x64_f8f6f4 multiplies 64 K-elements in the time the int8 form takes for 32

@@ -1134,10 +1134,12 @@ def test_off_level_patches_take_the_int8_form_in_the_same_launch():
 def test_fp4_form_needs_one_gap_width_per_nibble_bit():
     """K-element n = plane n % T sits on bit n % 4 of a nibble.  Five V levels (four planes) put ONE plane on each bit, so
     the widths 63, 64, 64, 64 of the reference's five-level quantiser are fine; four levels with unequal gaps (three
-    planes: every plane lands on every bit) are not, and keep the int8 form; equal gaps are fine again."""
+    planes: every plane lands on every bit) are not, and keep the int8 form; equal gaps are fine again, and so is a gap wider
+    than 127 that the int8 form had to split into copies."""
     F, h, w = 700, 8, 8
     rng = np.random.default_rng(3)
-    for levels, ok in (([0, 63, 127, 191, 255], True), ([0, 60, 130, 255], False), ([0, 85, 170, 255], True), ([0, 255], False), ([0, 100], True)):
+    for levels, ok in (([0, 63, 127, 191, 255], True), ([0, 60, 130, 255], False), ([0, 85, 170, 255], True), ([0, 255], True), ([0, 100], True),
+                       ([0, 127, 255], False), ([3, 200], True)):
         lib = np.zeros((F, h, w, 3), np.uint8)
         lib[..., 2] = np.array(levels, np.uint8)[rng.integers(0, len(levels), (F, h, w))]
         pat = np.zeros((3, h, w, 3), np.uint8)
@@ -1146,7 +1148,9 @@ def test_fp4_form_needs_one_gap_width_per_nibble_bit():
         try:
             e.set_library(lib, 0.0)
             info = e.library_info()
-            assert info["has_bit_planes"] and info["fp4_form"] == ok, levels      # (0, 255: one gap split 127 + 127 + 1)
+            # (0, 255: one gap split 127 + 127 + 1 for int8 -- its first plane stands for all 255 in the fp4 form; 0, 127, 255:
+            #  widths 127 and 128 meet on every bit position)
+            assert info["has_bit_planes"] and info["fp4_form"] == ok, levels
             got = e.step(pat, want_scene=True)
             want = oracle.step(lib, pat, 0.0)
             assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]), levels
