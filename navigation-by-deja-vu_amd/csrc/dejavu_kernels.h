@@ -2210,10 +2210,10 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
         int px_hi = T > 0 ? (int)(((long long)ksl * 256 + 255) / T) : -1;
         if (px_hi >= c.P) px_hi = c.P - 1;
         const int nbytes = px_hi >= px_lo ? (px_hi - px_lo + 1) * 3 : 0;
-        for (int i = threadIdx.x; i < 32 * nbytes; i += blockDim.x) {
-            const int h = i / nbytes, o = i - h * nbytes;
+        for (int h = g; h < 32; h += 8) {                               // wave g copies headings g, g + 8, ...
             const int ah = pass * 32 + h;
-            pix[h][o] = ah < A ? raw[(long long)ah * c.P * 3 + (long long)px_lo * 3 + o] : (unsigned char)0;
+            const unsigned char* src = raw + (long long)ah * c.P * 3 + (long long)px_lo * 3;
+            for (int o = lane; o < nbytes; o += 64) pix[h][o] = ah < A ? src[o] : (unsigned char)0;
         }
         __syncthreads();
         bool off = false;
@@ -2252,7 +2252,7 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
         return;
     }
     const int a = blockIdx.x - ncoef;
-    __shared__ int red[2][512];
+    __shared__ int red[2][8];
     int k_hs = 0, k_v = 0;
     const unsigned char* p = raw + (long long)a * c.P * 3;
     const int nplanes = b.T[0] + b.T[1];
@@ -2290,14 +2290,16 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
         }
       }
     }
-    red[0][threadIdx.x] = k_hs;
-    red[1][threadIdx.x] = k_v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { k_hs += __shfl_xor(k_hs, o); k_v += __shfl_xor(k_v, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = k_hs; red[1][threadIdx.x >> 6] = k_v; }
     __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        int s_hs = 0, s_v = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { s_hs += red[0][i]; s_v += red[1][i]; }
+        bconst[a] = s_hs;
+        bconst[kMaxHeadings + a] = s_v;
     }
-    if (threadIdx.x == 0) { bconst[a] = red[0][0]; bconst[kMaxHeadings + a] = red[1][0]; }
 }
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
