@@ -2220,18 +2220,22 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
         if (a < A && T > 0) {
             const unsigned char* p = &pix[lane & 31][0] - (long long)px_lo * 3;      // p[px * 3 + channel] as before
             unsigned char* img8b = reinterpret_cast<unsigned char*>(img8);
+            // (unrolled, no early exit: the LDS reads of the sixteen elements go out together instead of one round trip each)
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned n = (unsigned)((ksl * 2 + half) * 4 + j) * 32u + 4u * (unsigned)g;     // < T * P + 256: fits 32 bits
                 int px = (int)(n / (unsigned)T), r = (int)(n - (unsigned)px * (unsigned)T);
+#pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (px >= c.P) break;                              // zero beyond the last pixel
+                    const bool real = px < c.P;                        // zero beyond the last pixel
+                    const int pxc = real ? px : c.P - 1;
                     const int plane = first + r;
-                    const int av = (int)plane_byte(c, t_pl[plane], p[px * 3], p[px * 3 + 1], p[px * 3 + 2]);
+                    const int av = (int)plane_byte(c, t_pl[plane], p[pxc * 3], p[pxc * 3 + 1], p[pxc * 3 + 2]);
                     const int wd = (int)t_w[plane];
                     const int al = av - (int)t_lo[plane];
                     const int alpha = al < 0 ? 0 : (al > wd ? wd : al);
-                    img8b[((4 * (g & 1) + e) * 64 + lane) * 16 + j * 4 + (g >> 1)] = (unsigned char)((wd - 2 * alpha) & 0xff);
-                    if (coef4) {
+                    if (real) img8b[((4 * (g & 1) + e) * 64 + lane) * 16 + j * 4 + (g >> 1)] = (unsigned char)((wd - 2 * alpha) & 0xff);
+                    if (coef4 && real) {
                         const int wf = (int)t_wfull[plane];            // 0: a copy of a split gap's first plane
                         if (wf) {
                             if (al <= 0) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0x2u << (4 * g));
@@ -2269,15 +2273,19 @@ k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int*
       for (int i = 0; i < 8; ++i) {
         if (px0 + i * (int)blockDim.x >= c.P) break;
         const unsigned H = hsv[i][0], S = hsv[i][1], V = hsv[i][2];
-        for (int bp = 0; bp < b.nbp; ++bp) {
+        // (constant trip counts: the plane tables are then scalar registers, not a memory access per use)
+#pragma unroll
+        for (int bp = 0; bp < kMaxHues + 1; ++bp) {
+            if (bp >= b.nbp) break;
             const int av = (int)plane_byte(c, bp, H, S, V);
             int k = 0;
-            if (av < (int)t_lmin[bp]) k += (int)t_lmin[bp] - av;
-            if (av > (int)t_lmax[bp]) k += av - (int)t_lmax[bp];
-            for (int t = 0; t < nplanes; ++t) {
-                if (t_pl[t] != bp) continue;
-                const int al = av - (int)t_lo[t];
-                k += al < 0 ? 0 : (al > (int)t_w[t] ? (int)t_w[t] : al);
+            if (av < (int)b.lmin[bp]) k += (int)b.lmin[bp] - av;
+            if (av > (int)b.lmax[bp]) k += av - (int)b.lmax[bp];
+#pragma unroll
+            for (int t = 0; t < kMaxBitPlanes; ++t) {
+                if (t >= nplanes || b.pl[t] != bp) continue;
+                const int al = av - (int)b.lo[t];
+                k += al < 0 ? 0 : (al > (int)b.w[t] ? (int)b.w[t] : al);
             }
             if (bp < c.nhs) k_hs += k; else k_v += k;
         }
