@@ -491,6 +491,9 @@ static int build_bit_planes(dv_ctx* c) {
     for (int seg = 0; seg < 2; ++seg)
         if ((double)b.T[seg] * g.P * 127.0 > 1.9e9) return DV_OK;
     for (int seg = 0; seg < 2; ++seg) b.NK[seg] = (int)(((long long)b.T[seg] * g.P + 255) / 256);
+    // the HS K-steps in whole stages of the fp4 ring (2 or 4 K-steps): the item then runs as one loop through both segments
+    // (fp4_segment's kflush); the padding K-steps hold no bits and no coefficients
+    b.NK[0] = (b.NK[0] + 3) / 4 * 4;
     // Five value levels (four planes of the one value byte plane): the fp4 form may read them as 3-bit codes (k_bitpack_code)
     const bool five_levels = c->fp4_env != 0 && c->vcode_env != 0 && g.hasv && b.T[1] == 4;
     const int nkt = b.NK[0] + b.NK[1];
@@ -1569,15 +1572,15 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
         // <int8 stage, ring | fp4 stage, ring (thermometer rows) | fp4 stage, ring (code rows), view groups per wave>
         if (tiles == 2) {
             switch (v4) {                                      // 500 000 views x 128x128 x 32 headings, bit tiles: 0.96 / 1.07 ms
-                case 1: launch_mfma_dual<1, 3, 2, 3, 4, 2, 2>(c, nchunk, has_hs); break;
-                case 2: launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs); break;
-                default: launch_mfma_dual<1, 3, 2, 3, 2, 4, 2>(c, nchunk, has_hs);
+                case 1: launch_mfma_dual<1, 3, 2, 3, 2, 2, 2>(c, nchunk, has_hs); break;
+                case 2: launch_mfma_dual<1, 3, 2, 2, 2, 3, 2>(c, nchunk, has_hs); break;
+                default: launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs);
             }
         } else {
             switch (v4) {                                      // 50 000 views x 64x64 x 16 headings, bit tiles: 38.6 / 40.6 / 41.4 us
                 case 1: launch_mfma_dual<4, 2, 4, 3, 4, 3, 1>(c, nchunk, has_hs); break;
-                case 2: launch_mfma_dual<4, 2, 2, 6, 2, 4, 1>(c, nchunk, has_hs); break;
-                default: launch_mfma_dual<4, 2, 2, 4, 2, 6, 1>(c, nchunk, has_hs);
+                case 2: launch_mfma_dual<4, 2, 2, 6, 2, 6, 1>(c, nchunk, has_hs); break;
+                default: launch_mfma_dual<4, 2, 2, 4, 2, 4, 1>(c, nchunk, has_hs);
             }
         }
         return;

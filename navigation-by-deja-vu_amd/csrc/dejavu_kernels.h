@@ -2132,7 +2132,7 @@ k_bitpack(const uint4* __restrict__ tiles, uint4* __restrict__ btiles, LibCfg c,
 // three stored bits decode back to them with two or three VALU operations per plane --
 //     level 0..4  ->  code b2 b1 b0 = 000, 001, 010, 110, 111:   t1 = b0 | b1,  t2 = b1,  t3 = b2,  t4 = b0 & b2.
 // The HS rows are the bit tiles' (1 KB: thermometer bits as they are).  A V row is THREE dwords per lane (768 B, moved
-// by 48 lanes of a global_load_lds_dwordx4) for the same K-step whose bit-tile row has four: nibble i of dword w (w = 0, 1, 2) holds in
+// by global_load_lds_dwordx3) for the same K-step whose bit-tile row has four: nibble i of dword w (w = 0, 1, 2) holds in
 // bits 0..2 the code of the pixel whose thermometer bits are nibble i of dword w of the bit-tile row, and in bit 3 bit w
 // of the code of the pixel at nibble i of dword 3.  5 bits per pixel where the bit tiles take 6; the K-elements, hence
 // the coefficient image and the sums, are the same.  One thread per (view group of 32, K-step, lane).
@@ -2478,14 +2478,14 @@ __device__ __forceinline__ void lds_dma_16(const uint4* gsrc, unsigned lds_byte_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
-// A 768-byte row: lanes 0..47 move 16 bytes each, so the row lands in LDS without holes (global_load_lds_dwordx3 would put
-// every lane's 12 bytes 16 apart: tools/exp/lds_dma3.hip).  gsrc: row + 16 * lane (lanes 48..63 are masked off).
-__device__ __forceinline__ void lds_dma_768_nt(const unsigned char* gsrc, unsigned lds_byte_addr) {
+// A 768-byte code row: 12 bytes per lane.  global_load_lds_dwordx3 puts every lane's 12 bytes 16 apart in LDS
+// (tools/exp/lds_dma3.hip), so the row takes 1 KB there and is read back with one ds_read_b128 per lane like any other.
+// (Moving it with 48 lanes of a dwordx4 packs it into 768 B of LDS, but the three ds_read_b32 per lane that then read it
+// cannot be tied to a counted wait as one register tuple: the compiler copied them out early in one build.)
+__device__ __forceinline__ void lds_dma_12_nt(const unsigned char* gsrc, unsigned lds_byte_addr) {
     unsigned keep;
-    unsigned long long keep_exec;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_lshr_b64 exec, -1, 16\n\t"
-                 "global_load_lds_dwordx4 %2, off nt\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep), "=&s"(keep_exec) : "v"(gsrc), "s"(lds_byte_addr) : "memory", "scc");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ void lds_dma_16_nt(const uint4* gsrc, unsigned lds_byte_addr) {  // library rows: used once per step
     unsigned keep;
@@ -2869,17 +2869,14 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 // LDS operand reads of the fp4 loop, written out: hipcc sinks ordinary LDS loads to their first use when registers are
 // tight (254 of 256 here), which put a full LDS round trip in front of every second MFMA (0.94 ms at 500 000 views whatever
 // the ring depth, stage length or HBM bytes).  The reads below stay where they are issued -- one K-step ahead of their use --
-// and lds_wait ties the registers to the counted wait, so nothing that uses them can move above it.
+// and lds_tie after the counted wait keeps everything that uses them below it.  What the compiler must NOT do is copy or spill
+// such a register between the read and its wait (it believes the value is there): whole-register outputs into locals are
+// not copied, and tools/kernel_resources.py shows the scratch size (0 bytes in the loops; three ds_read_b32 into the
+// elements of one vector WERE copied out early in one build, which is why code rows are read as b128 too).
 template <int OFF>
 __device__ __forceinline__ void lds_read16(v4u_t& dst, unsigned addr) {
     static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read12(v4u_t& dst, unsigned addr) {      // three dwords, 4-byte aligned
-    static_assert(OFF >= 0 && OFF + 8 < 65536, "ds offset field");
-    asm volatile("ds_read_b32 %0, %3 offset:%4\n\tds_read_b32 %1, %3 offset:%5\n\tds_read_b32 %2, %3 offset:%6"
-                 : "=&v"(dst.x), "=&v"(dst.y), "=&v"(dst.z) : "v"(addr), "n"(OFF), "n"(OFF + 4), "n"(OFF + 8));
 }
 template <int N>
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
@@ -2896,14 +2893,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 //                 t1 = (x | x >> 1) & m, t2 = x & 2m, t3 = x & 4m, t4 = x & (x >> 2) & m per code dword, m = 0x11111111.
 // [k0, k1): K-steps of the coefficient image (absolute); lib[t]: this lane's place in the library row of K-step k0
 // (row pitch 1024 or 768 bytes).  w[b]: gap width of the planes on bit b.
+// kflush in (k0, k1), a whole number of stages past k0: the range covers BOTH segments (HS rows then V rows, consecutive
+// in the bit tiles and in the coefficient image) -- at K-step kflush the accumulators leave the HS sums in totf (widths wf)
+// and start over, so the ring streams through the boundary and an item has one pipeline fill, not two.
 template <int SK, int TILES, int RD, bool FUSE, bool CODE>
 __device__ __forceinline__ void
 fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ coef4, int k0, int k1, const int (&w)[4],
-            int lane, int wave, int (&tot)[TILES][16]) {
+            int lane, int wave, int (&tot)[TILES][16], int kflush, const int (&wf)[4], int (&totf)[TILES][16]) {
     extern __shared__ uint4 lds_ring[];
     constexpr int NW = 8;
-    constexpr int ROWB = CODE ? 768 : 1024;       // bytes of a library row, in HBM and in LDS
-    constexpr int LROWB = ROWB;
+    constexpr int ROWB = CODE ? 768 : 1024;       // bytes of a library row in HBM
+    constexpr int LROWB = 1024;                   // and in LDS (a code row keeps a 4-byte hole per lane there)
     constexpr int COEF_ROWS = SK * 4;
     constexpr int LIB_ROWS = NW * SK * TILES;
     constexpr int SLOTB = COEF_ROWS * 1024 + LIB_ROWS * LROWB;
@@ -2936,7 +2936,7 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
                 int lr = st * SK + k;
                 lr = lr < k1 - k0 ? lr : k1 - k0 - 1;                 // clamped: masked below
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)(COEF_ROWS * 1024 + row * LROWB));
-                if constexpr (CODE) lds_dma_768_nt(lib[t] + (long long)lr * ROWB, dst);
+                if constexpr (CODE) lds_dma_12_nt(lib[t] + (long long)lr * ROWB, dst);
                 else lds_dma_16_nt(reinterpret_cast<const uint4*>(lib[t] + (long long)lr * ROWB), dst);
             }
         };
@@ -2953,6 +2953,20 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
             // burst: eight waves leaving the barrier together queue 8 x NDMA wave-instructions on the CU's one vector-memory
             // path (16 cycles each) while every matrix pipe waits.  One instruction goes out after every few MFMAs instead,
             // behind matrix work that is already running.
+            if (k0 + st * SK == kflush && st > 0) {                      // segment boundary (uniform, once per item)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        totf[t][r] = __mul24(wf[0], (int)(2.f * acc[t][0][r])) + __mul24(wf[1], (int)acc[t][1][r]) + __mul24(wf[2], (int)(0.5f * acc[t][2][r])) +
+                                     __mul24(wf[3], (int)((CODE ? 2.f : 1.f) * acc[t][3][r]));
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
+            }
             int dma_next = 0;
             constexpr int MFMAS = SK * TILES * 4;
             constexpr int EVERY = MFMAS / NDMA > 0 ? MFMAS / NDMA : 1;
@@ -2960,7 +2974,7 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
             const int kb = k0 + st * SK;
             const unsigned sad = lds_base + (unsigned)((st % RD) * SLOTB);
             const unsigned cad = sad + (unsigned)lane * 16u;                                              // coefficient row r: + 1024 r
-            const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * SK * TILES * LROWB) + (unsigned)lane * (CODE ? 12u : 16u);
+            const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * SK * TILES * LROWB) + (unsigned)lane * 16u;
             auto mfma = [&](int t, int s, const v4u_t& av, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
                 const v8i_t bo = v8i_t{(int)b0, (int)b1, (int)b2, (int)b3, 0, 0, 0, 0};
                 const v8i_t ao = v8i_t{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
@@ -2969,15 +2983,14 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
                 if (++mfma_count % EVERY == 0 && dma_next < NDMA) issue_one(st + RD - 1, dma_next++);
             };
             // operands of K-step k of the stage: 4 coefficient rows, TILES library rows (READS instructions in all)
-            constexpr int READS = 4 + TILES * (CODE ? 3 : 1);
+            constexpr int READS = 4 + TILES;
             v4u_t a[2][4], xl[2][TILES];
             auto fetch = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * 4 + s_) * 1024>(a[k & 1][s_], cad); });
                 static_for<TILES>([&](auto tc) {
                     constexpr int t_ = decltype(tc)::value;
-                    if constexpr (CODE) lds_read12<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);
-                    else lds_read16<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);
+                    lds_read16<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);          // (CODE: the fourth dword is the hole)
                 });
             };
             fetch(IntC<0>{});
@@ -3036,7 +3049,7 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
 }
 
 // LDS the rings of fp4_segment take (the FUSE scratch sits behind the larger of a kernel's two).
-constexpr int fp4_ring_bytes(int SK, int TILES, int RD, bool code) { return RD * (SK * 4 * 1024 + 8 * SK * TILES * (code ? 768 : 1024)); }
+constexpr int fp4_ring_bytes(int SK, int TILES, int RD, bool code) { (void)code; return RD * (SK * 4 * 1024 + 8 * SK * TILES * 1024); }
 
 template <int SK, int TILES, int RD, int SKC, int RDC, bool FUSE>
 __device__ __forceinline__ void
@@ -3071,24 +3084,32 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
         int tot_hs[TILES][16], tot_v[TILES][16];
         (void)tot_hs;
         (void)tot_v;
-        if (has_hs_sum) {
+        // one chunk, both sums, thermometer rows throughout, HS K-steps a whole number of stages: ONE ring loop for the item
+        const bool merged = nchunk == 1 && has_hs_sum && c.hasv && !b.vcode && b.NK[0] % SK == 0 && b.NK[0] > 0 && b.NK[1] > 0;
+        if (merged) {
+            const unsigned char* lib[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + lane * 16;
+            fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, 0, b.NK[0] + b.NK[1], b.wacc[1], lane, wave, tot_v, b.NK[0], b.wacc[0], tot_hs);
+        }
+        if (!merged && has_hs_sum) {
             const int k0 = (int)(((long long)ch * b.NK[0]) / nchunk), k1 = (int)(((long long)(ch + 1) * b.NK[0]) / nchunk);
             const unsigned char* lib[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)k0 * 1024 + lane * 16;
-            fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, k0, k1, b.wacc[0], lane, wave, tot_hs);
+            fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, k0, k1, b.wacc[0], lane, wave, tot_hs, -1, b.wacc[0], tot_hs);
         }
-        if (c.hasv) {
+        if (!merged && c.hasv) {
             const int r0 = (int)(((long long)ch * b.NK[1]) / nchunk), r1 = (int)(((long long)(ch + 1) * b.NK[1]) / nchunk);
             const unsigned char* lib[TILES];
             if (b.vcode) {
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)b.NK[0] * 1024 + (long long)r0 * 768 + lane * 16;   // (lanes 0..47 move the row)
-                fp4_segment<SKC, TILES, RDC, FUSE, true>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v);
+                for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)b.NK[0] * 1024 + (long long)r0 * 768 + lane * 12;
+                fp4_segment<SKC, TILES, RDC, FUSE, true>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
             } else {
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)(b.NK[0] + r0) * 1024 + lane * 16;
-                fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v);
+                fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
             }
         }
         if constexpr (!FUSE) {

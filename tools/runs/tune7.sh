@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/tune gpurun_out/suite
-timeout -k 10 1100 python -m pytest tests -m gpu -q -x -k "fp4 or off_level or mfma or fold" > gpurun_out/suite/pytest.log 2>&1
+timeout -k 10 1100 python -m pytest tests -m gpu -q -x > gpurun_out/suite/pytest.log 2>&1
 rc=$?
 tail -25 gpurun_out/suite/pytest.log
 if [ $rc -ne 0 ]; then exit $rc; fi
@@ -14,7 +14,8 @@ print('%-28s step %.4f ms  kernel %.4f ms  rest %.1f us value %.3e  %s' % ('$nam
 "
 }
 BARGS="--steps 50 --warmup 5"
-run c2_code_v0 X=1
-run c2_code_v1 DEJAVU_FP4_VARIANT=1
-run c2_code_v2 DEJAVU_FP4_VARIANT=2
-run c2_nocode DEJAVU_VCODE=0
+run c2 X=1
+BARGS="--views 50000 --sensor 64 --headings 16 --steps 300 --warmup 30 --event-every 4"
+run c1 X=1
+BARGS="--views 100000 --sensor 64 --headings 64 --steps 100 --warmup 10"
+run b64 X=1
