@@ -2944,15 +2944,42 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
 #pragma unroll
             for (int d = 0; d < NDMA; ++d) issue_one(st, d);
         };
+        static_assert(SK % 2 == 0, "operand buffers alternate by K-step across stages");
+        // Operand registers of two K-steps: (stage, k) lives in buffer k & 1 (SK is even), read from LDS one K-step ahead.
+        // XSTAGE (one view group per wave) -- ALSO across stages: the wait + barrier that publish stage st + 1 sit in front
+        // of the LAST K-step of stage st, whose operands are in registers by then, so the first operands of stage st + 1
+        // are on their way while that K-step runs and the matrix pipes do not idle behind every barrier for an LDS round
+        // trip of all eight waves (100 000 views x 64x64 x 64 headings: 146 -> 133 us).  With two view groups per wave the
+        // registers do not reach: the compiler then reloads an LDS address from scratch in the loop, and the vmcnt(0) it puts
+        // behind that reload drains the ring every stage (500 000 views x 128x128: 0.975 instead of 0.95 ms) -- so there the
+        // barrier stays at the top of the stage.
+        constexpr bool XSTAGE = TILES == 1;
+        constexpr int READS = 4 + TILES;              // LDS reads per K-step: 4 coefficient rows, TILES library rows
+        v4u_t a[2][4], xl[2][TILES];
+        auto fetch = [&](int st, auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const unsigned sad = lds_base + (unsigned)((st % RD) * SLOTB);
+            const unsigned cad = sad + (unsigned)lane * 16u;                                              // coefficient row r: + 1024 r
+            const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * SK * TILES * LROWB) + (unsigned)lane * 16u;
+            static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * 4 + s_) * 1024>(a[k & 1][s_], cad); });
+            static_for<TILES>([&](auto tc) {
+                constexpr int t_ = decltype(tc)::value;
+                lds_read16<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);              // (CODE: the fourth dword is the hole)
+            });
+        };
 #pragma unroll
         for (int r = 0; r < RD - 1; ++r) issue_stage(r);
-        for (int st = 0; st < nst; ++st) {
-            wait_vmcnt_le<NDMA * (RD - 2)>();
+        if constexpr (XSTAGE) {
+            wait_vmcnt_le<NDMA * (RD - 2)>();         // stage 0 has landed once at most the younger stages' DMA is outstanding
             __builtin_amdgcn_s_barrier();
-            // The DMA of stage st + RD - 1 (into the slot everybody finished with a barrier ago) is NOT issued here in one
-            // burst: eight waves leaving the barrier together queue 8 x NDMA wave-instructions on the CU's one vector-memory
-            // path (16 cycles each) while every matrix pipe waits.  One instruction goes out after every few MFMAs instead,
-            // behind matrix work that is already running.
+            fetch(0, IntC<0>{});
+        }
+        for (int st = 0; st < nst; ++st) {
+            if constexpr (!XSTAGE) {
+                wait_vmcnt_le<NDMA * (RD - 2)>();     // stage st has landed ...
+                __builtin_amdgcn_s_barrier();         // ... for everybody, and everybody is done with the slot refilled below
+                fetch(st, IntC<0>{});
+            }
             if (k0 + st * SK == kflush && st > 0) {                      // segment boundary (uniform, once per item)
 #pragma unroll
                 for (int t = 0; t < TILES; ++t)
@@ -2967,14 +2994,14 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
             }
+            // The DMA of stage st + RD - 1 goes into the slot everybody finished with at the previous barrier, one instruction
+            // after every few MFMAs (a burst of 8 x NDMA wave-instructions behind a barrier queues on the CU's one
+            // vector-memory path while every matrix pipe waits); XSTAGE: all of it before the last K-step.
             int dma_next = 0;
-            constexpr int MFMAS = SK * TILES * 4;
+            constexpr int MFMAS = (XSTAGE ? SK - 1 : SK) * TILES * 4;
             constexpr int EVERY = MFMAS / NDMA > 0 ? MFMAS / NDMA : 1;
             int mfma_count = 0;
             const int kb = k0 + st * SK;
-            const unsigned sad = lds_base + (unsigned)((st % RD) * SLOTB);
-            const unsigned cad = sad + (unsigned)lane * 16u;                                              // coefficient row r: + 1024 r
-            const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * SK * TILES * LROWB) + (unsigned)lane * 16u;
             auto mfma = [&](int t, int s, const v4u_t& av, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
                 const v8i_t bo = v8i_t{(int)b0, (int)b1, (int)b2, (int)b3, 0, 0, 0, 0};
                 const v8i_t ao = v8i_t{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
@@ -2982,25 +3009,24 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
                 else acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[t][s], 4, 4, 0, 0, 0, 0);
                 if (++mfma_count % EVERY == 0 && dma_next < NDMA) issue_one(st + RD - 1, dma_next++);
             };
-            // operands of K-step k of the stage: 4 coefficient rows, TILES library rows (READS instructions in all)
-            constexpr int READS = 4 + TILES;
-            v4u_t a[2][4], xl[2][TILES];
-            auto fetch = [&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * 4 + s_) * 1024>(a[k & 1][s_], cad); });
-                static_for<TILES>([&](auto tc) {
-                    constexpr int t_ = decltype(tc)::value;
-                    lds_read16<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);          // (CODE: the fourth dword is the hole)
-                });
-            };
-            fetch(IntC<0>{});
             static_for<SK>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 if constexpr (k + 1 < SK) {
-                    fetch(IntC<k + 1>{});                 // one K-step ahead
+                    fetch(st, IntC<k + 1>{});             // one K-step ahead
                     lds_wait<READS>();                    // all but the newest READS reads have landed: K-step k's
                 } else {
-                    lds_wait<0>();
+                    lds_wait<0>();                        // this wave holds everything it will use of slot st % RD
+                    if constexpr (XSTAGE) {
+#pragma unroll
+                        for (int d = 0; d < NDMA; ++d)
+                            if (d >= dma_next) issue_one(st + RD - 1, d);     // (none left when the MFMAs divide evenly)
+                        dma_next = NDMA;
+                        if (st + 1 < nst) {
+                            wait_vmcnt_le<NDMA * (RD - 2)>(); // stage st + 1 has landed (this wave's rows) ...
+                            __builtin_amdgcn_s_barrier();     // ... for everybody, and everybody is done reading slot st % RD
+                            fetch(st + 1, IntC<0>{});
+                        }
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) lds_tie(a[k & 1][s]);
@@ -3031,9 +3057,11 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
                     }
                 }
             });
+            if constexpr (!XSTAGE) {
 #pragma unroll
-            for (int d = 0; d < NDMA; ++d)
-                if (d >= dma_next) issue_one(st + RD - 1, d);         // (none left when the MFMAs divide evenly)
+                for (int d = 0; d < NDMA; ++d)
+                    if (d >= dma_next) issue_one(st + RD - 1, d);         // (none left when the MFMAs divide evenly)
+            }
         }
         wait_vmcnt_le<0>();
         __builtin_amdgcn_s_barrier();
