@@ -1800,7 +1800,14 @@ static void launch_fold(dv_ctx* c, int nb, StepResultDev* outp, double* recp, in
         sums = c->d_bsum2;
         nb = slices;
     }
-    hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3(1024), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state,
+    // threads: enough that every thread walks at most 16 summaries of its heading in one round trip (fold_and_decide), no more
+    // -- a 1024-thread workgroup spends its time in its own barriers when 32 summaries are left
+    static const int threads_env = getenv("DEJAVU_FOLD_THREADS") ? atoi(getenv("DEJAVU_FOLD_THREADS")) : 0;
+    int threads = 1024;
+    if (threads_env == 256 || threads_env == 512 || threads_env == 1024) threads = threads_env;
+    else if ((long long)nb * c->A_agent <= 256ll * 16) threads = 256;
+    else if ((long long)nb * c->A_agent <= 512ll * 16) threads = 512;
+    hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3((unsigned)threads), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state,
                        outp, recp, c->cfg, c->A_agent, c->delta, force, seq, serr, nb);
 }
 

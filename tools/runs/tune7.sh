@@ -14,8 +14,9 @@ print('%-28s step %.4f ms  kernel %.4f ms  rest %.1f us value %.3e  %s' % ('$nam
 "
 }
 BARGS="--steps 50 --warmup 5"
-run c2 X=1
+run c2_fold_auto X=1
+run c2_fold_1024 DEJAVU_FOLD_THREADS=1024
 BARGS="--views 50000 --sensor 64 --headings 16 --steps 300 --warmup 30 --event-every 4"
-run c1 X=1
-BARGS="--views 100000 --sensor 64 --headings 64 --steps 100 --warmup 10"
-run b64 X=1
+run c1_fold_auto X=1
+run c1_fold_1024 DEJAVU_FOLD_THREADS=1024
+run c1_fold_512 DEJAVU_FOLD_THREADS=512
