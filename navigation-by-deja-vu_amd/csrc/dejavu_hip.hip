@@ -1485,12 +1485,12 @@ static void launch_mfma_ring_f(dv_ctx* c, int nchunk, int has_hs, const FuseArgs
     const unsigned grid = (unsigned)(items < 256 ? items : 256);
     const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
     FuseArgs fz = fz_in;
-    fz.nb = (int)items;
+    fz.nb = (int)grid;
     for (int a_off = 0; a_off < c->APAD; a_off += 32)
         hipLaunchKernelGGL((k_sad_mfma_ring<SK, TILES, RD, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->d_coef + (size_t)(a_off / 32) * nkt * 512, reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk,
                            c->APAD, a_off, has_hs, fz);
-    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)items; }
+    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }            // one summary per workgroup
 }
 
 template <int SK, int TILES, int RD>
@@ -1523,13 +1523,13 @@ static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     const unsigned grid = (unsigned)(items < 256 ? items : 256);
     const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
     FuseArgs fz{};
-    if (FUSE) { fz = fuse_args(c); fz.nb = (int)items; }
+    if (FUSE) { fz = fuse_args(c); fz.nb = (int)grid; }
     for (int a_off = 0; a_off < c->APAD; a_off += 32)
         hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->bcfg.vcode ? c->d_ctiles : c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
                            c->d_coef4 + (size_t)(a_off / 32) * nkt * 256, c->d_offlevel + (c->prep_seq & 1), reinterpret_cast<int*>(c->d_part),
                            c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz);
-    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)items; }
+    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }            // one summary per workgroup
 }
 
 template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES>

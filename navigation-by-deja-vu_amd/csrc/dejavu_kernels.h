@@ -2525,7 +2525,8 @@ struct FuseArgs {
 // `scratch`: LDS, kFuseScratchBytes.  hs / v: the integer sums of this lane (register r = view
 // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of view group t).
 constexpr int kFuseQueue = 256;
-constexpr int kFuseScratchBytes = (2 * 8 * 32 + 5 * 32 + 2 * kFuseQueue) * 8 + 16;
+constexpr int kFuseBlk = 2 * 8 * 32 + 4 * 32 + 2 * kFuseQueue + 2;      // 8-byte words in front of the workgroup's running summary
+constexpr int kFuseScratchBytes = (kFuseBlk + 2 * 32) * 8;
 
 template <int TILES, int NW, typename HsOf, typename VOf>
 __device__ __forceinline__ void
@@ -2541,6 +2542,8 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     unsigned long long* q_sc = loose_sc + 32;                  // [kFuseQueue] bits of sc
     unsigned long long* q_id = q_sc + kFuseQueue;              // [kFuseQueue] heading of the pass << 40 | view
     unsigned* q_n = reinterpret_cast<unsigned*>(q_id + kFuseQueue);
+    unsigned long long* blk_key = scratch + kFuseBlk;          // [32] the workgroup's best per heading over its items so far
+    unsigned long long* blk_view = blk_key + 32;               // [32] (fused_block_begin / fused_block_end)
     // The lane index is made opaque here: everything below that depends on it is loop-invariant, and the compiler
     // would otherwise compute it once per kernel and hold it in registers through the scoring loop (48 64-bit values
     // per lane: the kernel then spills several hundred bytes per lane and reloads them entry by entry).
@@ -2635,12 +2638,33 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
                 if (k < is || (k == is && w < iv)) { is = k; iv = w; }
             }
             const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
-            unsigned long long* bsm = fz.bsum + ((long long)agent * fz.nb + gq) * 2 * fz.A_agent;
             const bool any = is != kNone;
-            bsm[kk] = any ? ordered_key((double)c.P - __longlong_as_double((long long)is) / 255.) : 0ull;
-            bsm[fz.A_agent + kk] = any ? iv : ~0ull;
-            if (any) atomicMin(&abest[agent - agent0], is);
-            if (!any) iv = ~0ull;
+            if (any) {
+                atomicMin(&abest[agent - agent0], is);
+                // The workgroup keeps ONE summary per heading over all its items (256 summaries per step instead of one per
+                // item): the item's representative against the workgroup's so far.  The loser is listed when it is within
+                // delta of the winner -- a superset of "within delta of the step's best", which is no smaller than the winner.
+                const unsigned long long ck = ordered_key((double)c.P - __longlong_as_double((long long)is) / 255.), cv = iv;
+                const unsigned long long bk = blk_key[n], bv = blk_view[n];
+                if (bk == 0) {
+                    blk_key[n] = ck; blk_view[n] = cv;
+                } else {
+                    const bool cur_wins = ck > bk || (ck == bk && cv < bv);
+                    const unsigned long long wk = cur_wins ? ck : bk, lk = cur_wins ? bk : ck, lv = cur_wins ? bv : cv;
+                    if (key_to_double(lk) >= key_to_double(wk) - fz.delta) {
+                        const unsigned pos = __hip_atomic_fetch_add(&fz.st[agent].ntmp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (pos < (unsigned)kTmpCap) {
+                            unsigned long long* ct = fz.ctmp + (long long)agent * kTmpCap * 2;
+                            ct[2 * pos] = ((unsigned long long)kk << 40) | lv;
+                            ct[2 * pos + 1] = lk;
+                        }
+                    }
+                    if (cur_wins) { blk_key[n] = ck; blk_view[n] = cv; }
+                }
+            } else {
+                iv = ~0ull;
+            }
+            (void)gq;
         }
         item_view[n] = iv;
     }
@@ -2681,6 +2705,25 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     __syncthreads();               // the scratch is reused by the next item
 }
 
+// The workgroup's running summary (fused_finish): cleared before its first item, written after its last --
+// bsum[agent][workgroup][2][A_agent], nb = gridDim.x summaries per agent.
+__device__ __forceinline__ void fused_block_begin(unsigned long long* scratch) {
+    unsigned long long* blk_key = scratch + kFuseBlk;
+    if (threadIdx.x < 32) { blk_key[threadIdx.x] = 0; blk_key[32 + threadIdx.x] = ~0ull; }
+    __syncthreads();
+}
+__device__ __forceinline__ void fused_block_end(const unsigned long long* scratch, const FuseArgs& fz, int a_off) {
+    const unsigned long long* blk_key = scratch + kFuseBlk;
+    __syncthreads();
+    const int n = threadIdx.x, a = a_off + n;
+    if (n < 32 && a < fz.A_real) {
+        const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
+        unsigned long long* bsm = fz.bsum + ((long long)agent * gridDim.x + blockIdx.x) * 2 * fz.A_agent;
+        bsm[kk] = blk_key[n];
+        bsm[fz.A_agent + kk] = blk_key[n] ? blk_key[32 + n] : ~0ull;
+    }
+}
+
 template <int SK, int TILES, int RD, bool FUSE>
 __device__ __forceinline__ void
 sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
@@ -2701,6 +2744,7 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
     const long long n_items = GQ * nchunk;
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
     const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
+    if constexpr (FUSE) fused_block_begin(reinterpret_cast<unsigned long long*>(lds_ring + RD * SLOT16));
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / GQ);
         const long long gq = item - (long long)ch * GQ;
@@ -2840,6 +2884,7 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
             }
         }
     }
+    if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(lds_ring + RD * SLOT16), fz, a_off);
 }
 
 template <int SK, int TILES, int RD, bool FUSE>
@@ -3095,6 +3140,7 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
     const long long n_items = GQ * nchunk;
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
     const long long gbytes = b.vcode ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
+    if constexpr (FUSE) fused_block_begin(reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING));
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / GQ);
         const long long gq = item - (long long)ch * GQ;
@@ -3165,6 +3211,7 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
             fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
         }
     }
+    if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING), fz, a_off);
 }
 
 // One launch, both forms: `offlevel` (k_bit_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form
