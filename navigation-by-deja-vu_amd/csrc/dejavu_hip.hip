@@ -152,6 +152,15 @@ struct dv_ctx {
     int last_form = 0;                        // DV_FORM_* of the last integer scoring pass (fp4 bit: the dual kernel was launched)                  // DEJAVU_FP4_VARIANT: A/B of the ring shapes
     int fuse_env = 1;                         // DEJAVU_FUSE=0: one-chunk matrix-core passes leave their sums to k_finish instead of finishing them
     int fused_nb = 0;                         // summaries per agent it left
+    // the fused epilogue may also fold and decide (one agent, one launch): what it needs of the step, set by enqueue_step
+    bool fold_request = false, epilogue_folded = false;
+    // DEJAVU_FOLD_IN_KERNEL=1: off by default -- measured: the ticket's release fence in every workgroup and the last one's fold on
+    // cold caches cost the kernel +7 us at 500 000 views (tail 25 -> 10 us: step 1.002 -> 0.994 ms) and +8.7 us at 50 000
+    // views x 16 headings (tail 14.2 -> 6.2: step 53.5 -> 54.1 us); k_fold as its own launch takes 6-8 us.
+    int fold_force = 0, fold_env = 0;
+    StepResultDev* fold_out = nullptr;
+    double* fold_rec = nullptr;
+    const unsigned long long* fold_serr = nullptr;
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -285,6 +294,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_FINISH_VB", c->finish_vb_env, 0, 16);
     env_int("DEJAVU_FUSE", c->fuse_env, 0, 1);
     env_int("DEJAVU_FP4", c->fp4_env, 0, 1);
+    env_int("DEJAVU_FOLD_IN_KERNEL", c->fold_env, 0, 1);
     env_int("DEJAVU_VCODE", c->vcode_env, 0, 1);
     env_int("DEJAVU_FP4_VARIANT", c->fp4_variant_env, 0, 8);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
@@ -1468,6 +1478,15 @@ static FuseArgs fuse_args(const dv_ctx* c) {
     fz.A_real = c->A;
     fz.A_agent = c->A_agent;
     fz.delta = c->delta;
+    if (c->fold_request && c->n_agents == 1 && c->APAD <= 32 && c->fold_env) {
+        fz.fold_here = 1;
+        fz.force = c->fold_force;
+        fz.seq = c->seq + 1;
+        fz.cand = c->d_cand;
+        fz.out = c->fold_out;
+        fz.rec = c->fold_rec;
+        fz.sense_err = c->fold_serr;
+    }
     return fz;
 }
 
@@ -1490,7 +1509,7 @@ static void launch_mfma_ring_f(dv_ctx* c, int nchunk, int has_hs, const FuseArgs
         hipLaunchKernelGGL((k_sad_mfma_ring<SK, TILES, RD, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->d_coef + (size_t)(a_off / 32) * nkt * 512, reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk,
                            c->APAD, a_off, has_hs, fz);
-    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }            // one summary per workgroup
+    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; c->epilogue_folded = fz.fold_here != 0; }   // one summary per workgroup
 }
 
 template <int SK, int TILES, int RD>
@@ -1529,7 +1548,7 @@ static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
                            c->bcfg.vcode ? c->d_ctiles : c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
                            c->d_coef4 + (size_t)(a_off / 32) * nkt * 256, c->d_offlevel + (c->prep_seq & 1), reinterpret_cast<int*>(c->d_part),
                            c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz);
-    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }            // one summary per workgroup
+    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; c->epilogue_folded = fz.fold_here != 0; }   // one summary per workgroup
 }
 
 template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES>
@@ -1847,14 +1866,22 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     // partial sums never reach HBM and the step ends in k_fold alone.  Not with scene_fam: its minimum over headings
     // runs across the lanes there.
     c->fuse_request = c->metric == 0 && !c->exact && !want_scene;
+    c->fold_request = c->fuse_request;
+    c->fold_force = force;
+    c->fold_out = c->d_result + c->result_slot;
+    c->fold_rec = c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings);
+    c->fold_serr = c->patches_sensed ? c->d_err + c->sense_parity : nullptr;
     c->epilogue_fused = false;
+    c->epilogue_folded = false;
     int rc = launch_scoring(c, !fused);
     c->fuse_request = false;
+    c->fold_request = false;
     if (rc) return rc;
     Range range("dv:finish");
-    if (c->epilogue_fused) {
-        launch_fold(c, c->fused_nb, c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), force,
-                    ++c->seq, c->patches_sensed ? c->d_err + c->sense_parity : nullptr);
+    if (c->epilogue_fused && c->epilogue_folded) {
+        ++c->seq;                                              // the scoring kernel's last workgroup folded and decided
+    } else if (c->epilogue_fused) {
+        launch_fold(c, c->fused_nb, c->fold_out, c->fold_rec, force, ++c->seq, c->fold_serr);
     } else if (fused) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
         else launch_finish<2>(c, scene_on, force);

@@ -2505,8 +2505,17 @@ struct FuseArgs {
     StepState* st;                  // [agents]
     int A_real;                     // resident headings
     int A_agent;                    // headings per agent
-    int nb;                         // items = summaries per agent
+    int nb;                         // summaries per agent (one per workgroup)
     double delta;
+    // fold_here: one agent, one launch -- the last workgroup to arrive folds the summaries and decides (fold_and_decide),
+    // so no launch at all follows the scoring kernel
+    int fold_here;
+    int force;
+    int seq;
+    unsigned long long* cand;
+    StepResultDev* out;
+    double* rec;
+    const unsigned long long* sense_err;
 };
 
 // Fused finishing of one item (FUSE forms).  The accumulators are transposed there (library bits as the A operand of the
@@ -2712,16 +2721,29 @@ __device__ __forceinline__ void fused_block_begin(unsigned long long* scratch) {
     if (threadIdx.x < 32) { blk_key[threadIdx.x] = 0; blk_key[32 + threadIdx.x] = ~0ull; }
     __syncthreads();
 }
-__device__ __forceinline__ void fused_block_end(const unsigned long long* scratch, const FuseArgs& fz, int a_off) {
+__device__ __forceinline__ void fused_block_end(const unsigned long long* scratch, const FuseArgs& fz, const LibCfg& c, int a_off) {
     const unsigned long long* blk_key = scratch + kFuseBlk;
     __syncthreads();
     const int n = threadIdx.x, a = a_off + n;
     if (n < 32 && a < fz.A_real) {
         const int agent = a / fz.A_agent, kk = a - agent * fz.A_agent;
         unsigned long long* bsm = fz.bsum + ((long long)agent * gridDim.x + blockIdx.x) * 2 * fz.A_agent;
-        bsm[kk] = blk_key[n];
-        bsm[fz.A_agent + kk] = blk_key[n] ? blk_key[32 + n] : ~0ull;
+        __hip_atomic_store(&bsm[kk], blk_key[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&bsm[fz.A_agent + kk], blk_key[n] ? blk_key[32 + n] : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (!fz.fold_here) return;                    // k_fold, launched behind this kernel, does the rest
+    // ---- arrival ticket, as in k_finish, always with the release / acquire pair (once per workgroup and step here)
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = (atomicAdd(&fz.st->done, 1u) == gridDim.x - 1) ? 1 : 0;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    fold_and_decide(fz.bsum, fz.ctmp, fz.cand, fz.st, fz.out, fz.rec, c, fz.A_agent, fz.delta, fz.force, fz.seq, fz.sense_err, 0, (int)gridDim.x);
 }
 
 template <int SK, int TILES, int RD, bool FUSE>
@@ -2884,7 +2906,7 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
             }
         }
     }
-    if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(lds_ring + RD * SLOT16), fz, a_off);
+    if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(lds_ring + RD * SLOT16), fz, c, a_off);
 }
 
 template <int SK, int TILES, int RD, bool FUSE>
@@ -3211,7 +3233,7 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
             fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
         }
     }
-    if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING), fz, a_off);
+    if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING), fz, c, a_off);
 }
 
 // One launch, both forms: `offlevel` (k_bit_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/tune gpurun_out/suite
-true
+timeout -k 10 1100 python -m pytest tests -m gpu -q -x > gpurun_out/suite/pytest.log 2>&1
 rc=$?
 tail -25 gpurun_out/suite/pytest.log
 if [ $rc -ne 0 ]; then exit $rc; fi
@@ -14,7 +14,8 @@ print('%-28s step %.4f ms  kernel %.4f ms  rest %.1f us value %.3e  %s' % ('$nam
 "
 }
 BARGS="--steps 80 --warmup 8"
-run c2_a X=1
-run c2_b X=1
-run c2_c DEJAVU_FUSE=0
-run c2_d X=1
+run c2_fold_in X=1
+run c2_fold_out DEJAVU_FOLD_IN_KERNEL=0
+BARGS="--views 50000 --sensor 64 --headings 16 --steps 300 --warmup 30 --event-every 4"
+run c1_fold_in X=1
+run c1_fold_out DEJAVU_FOLD_IN_KERNEL=0
