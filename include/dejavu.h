@@ -141,6 +141,14 @@ int dv_get_library_info(const dv_ctx *ctx, dv_lib_info *out);
  * (0 for a single level), -1 when more than `cap` would be needed.
  */
 int dv_bitplane_plan(const uint32_t *presence, int cap, uint8_t *lo, uint8_t *w, int *lmin, int *lmax);
+/*
+ * Host arithmetic of the fp4 form of the matrix-core kernel for the n_planes planes dv_bitplane_plan gave one byte plane
+ * (presence: the same 256-bit map): wfull[t] = the whole gap a plane stands for when it starts at a library level (its
+ * int8 copies inside a gap wider than 127 get 0), wacc[bit] = the one width of the planes that land on bit `bit` of a
+ * nibble (K-element n = plane n % n_planes sits on bit n % 4).  Returns 1 when every bit position has one width (the
+ * exact fp4 coefficients +-1 exist for on-level patches), 0 when not, negative on bad arguments.
+ */
+int dv_fp4_plan(const uint32_t *presence, int n_planes, const uint8_t *lo, const uint8_t *w, uint8_t *wfull, int *wacc);
 /* Copy the stored planes of local views [v0, v0+n) back as uint8[n, n_planes, h*w] (layout check). */
 int dv_read_planes(dv_ctx *ctx, int64_t v0, int64_t n, uint8_t *out);
 

@@ -511,31 +511,13 @@ static int build_bit_planes(dv_ctx* c) {
     // fp4 form of the kernel.  A gap wider than 127 was split for the int8 coefficients into planes that carry the same bits
     // (library bytes sit on levels): there the first plane stands for the whole gap and its copies for nothing.  The planes
     // that land on bit b of a nibble (K-element n = plane n % T on bit n % 4) and stand for something must share a width.
-    for (int k = 0; k < total; ++k) {
-        const uint32_t* pres = presence + (int)b.pl[k] * 8;
-        const int lo = b.lo[k];
-        const bool starts_at_level = (pres[lo >> 5] >> (lo & 31)) & 1u;
-        int wf = 0;
-        if (starts_at_level) {
-            int nxt = lo + 1;
-            while (nxt < 256 && !((pres[nxt >> 5] >> (nxt & 31)) & 1u)) ++nxt;
-            wf = nxt < 256 ? nxt - lo : (int)b.w[k];
-        }
-        b.wfull[k] = (unsigned char)wf;
-    }
     bool one_width = true;
     for (int seg = 0; seg < 2; ++seg) {
         const int first = seg ? b.T[0] : 0, T = b.T[seg];
-        for (int bit = 0; bit < 4; ++bit) {
-            int wb = 0;
-            for (int k = 0; k < T; ++k) {                                // (bit + 4k) % T runs through every plane on this bit
-                const int wf = b.wfull[first + (bit + 4 * k) % T];
-                if (!wf) continue;
-                if (wb && wf != wb) one_width = false;
-                wb = wf;
-            }
-            b.wacc[seg][bit] = wb;
-        }
+        const uint32_t* pres[kMaxBitPlanes];
+        for (int k = 0; k < T; ++k) pres[k] = presence + (int)b.pl[first + k] * 8;
+        for (int bit = 0; bit < 4; ++bit) b.wacc[seg][bit] = 0;
+        if (T > 0 && !plan_fp4_segment(T, pres, b.lo + first, b.w + first, b.wfull + first, b.wacc[seg])) one_width = false;
     }
     c->fp4_ok = one_width && c->fp4_env != 0;
     const long long G32 = g.Fpad / 32;

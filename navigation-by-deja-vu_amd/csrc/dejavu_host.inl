@@ -158,6 +158,49 @@ static int plan_byte_plane(const uint32_t presence[8], int cap, uint8_t* lo, uin
     return t;
 }
 
+// fp4 form of the matrix-core kernel: which planes stand for something and with which width.
+//   planes t = 0 .. n-1 of ONE segment (HS or V), in K-element order; presence[t]: 256-bit map of the byte plane that plane
+//   t belongs to; lo/w as dv_bitplane_plan left them.  A plane that starts at a library level is the first of its gap and
+//   stands for the WHOLE distance to the next level (wfull); a plane that starts between levels is a copy the int8 form
+//   needed (gap wider than 127: same bits) and stands for nothing (wfull = 0).  K-element n = plane n % T sits on bit n % 4
+//   of a nibble: the planes on one bit position that stand for something must share their width (wacc[bit], 0 if none).
+// Returns 1 if the segment qualifies, 0 if widths differ on a bit position.
+static int plan_fp4_segment(int T, const uint32_t* const* presence, const uint8_t* lo, const uint8_t* w, uint8_t* wfull, int* wacc) {
+    for (int t = 0; t < T; ++t) {
+        const uint32_t* pres = presence[t];
+        const int l = lo[t];
+        int wf = 0;
+        if ((pres[l >> 5] >> (l & 31)) & 1u) {
+            int nxt = l + 1;
+            while (nxt < 256 && !((pres[nxt >> 5] >> (nxt & 31)) & 1u)) ++nxt;
+            wf = nxt < 256 ? nxt - l : (int)w[t];
+        }
+        wfull[t] = (uint8_t)wf;
+    }
+    int ok = 1;
+    for (int bit = 0; bit < 4; ++bit) {
+        int wb = 0;
+        for (int k = 0; k < T; ++k) {                                    // (bit + 4k) % T runs through every plane on this bit
+            const int wf = wfull[(bit + 4 * k) % T];
+            if (!wf) continue;
+            if (wb && wf != wb) ok = 0;
+            wb = wf;
+        }
+        wacc[bit] = wb;
+    }
+    return ok;
+}
+
+// One byte plane's segment (all its planes from dv_bitplane_plan) through plan_fp4_segment: the CPU-testable face of it.
+extern "C" int dv_fp4_plan(const uint32_t* presence, int n_planes, const uint8_t* lo, const uint8_t* w, uint8_t* wfull, int* wacc) {
+    if (!presence || !lo || !w || !wfull || !wacc || n_planes < 0 || n_planes > 64) return DV_ERR_INVALID;
+    const uint32_t* pres[64];
+    for (int t = 0; t < n_planes; ++t) pres[t] = presence;
+    for (int b = 0; b < 4; ++b) wacc[b] = 0;
+    if (n_planes == 0) return 1;
+    return plan_fp4_segment(n_planes, pres, lo, w, wfull, wacc);
+}
+
 extern "C" int dv_bitplane_plan(const uint32_t* presence, int cap, uint8_t* lo, uint8_t* w, int* lmin, int* lmax) {
     if (!presence || !lo || !w || !lmin || !lmax || cap < 0 || cap > 255) return DV_ERR_INVALID;
     return plan_byte_plane(presence, cap, lo, w, lmin, lmax);

@@ -159,6 +159,8 @@ PROTOTYPES = {
     "dv_range_push": (ctypes.c_int, [ctypes.c_char_p]),
     "dv_range_pop": (ctypes.c_int, []),
     "dv_patches_on_level": (ctypes.c_int, [ctypes.c_void_p]),
+    "dv_fp4_plan": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8),
+                    ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int)]),
     "dv_scoring_form": (ctypes.c_int, [ctypes.c_void_p]),
     "dv_version": (ctypes.c_char_p, []),
 }

@@ -239,6 +239,62 @@ def test_bit_plane_decomposition_is_exact():
     assert lib.dv_bitplane_plan(presence, 16, lo, w, ctypes.byref(lmin), ctypes.byref(lmax)) == -1
 
 
+def test_fp4_form_identity_and_plan():
+    """The fp4 form of the matrix-core kernel (csrc/dejavu_kernels.h, fp4_segment), on the CPU: for a patch byte ON a level
+    (or outside the library's range) every coefficient w_t - 2 alpha_t is +w_t or -w_t, so with the library bit of a plane on
+    bit b of a nibble read as the E2M1 value 0.5 / 1 / 2 (bit 3: shifted to 1) and the coefficient as E2M1 +-1,
+        sum_t bit_t (w_t - 2 alpha_t) = sum_b wacc[b] * scale_b * (fp32 sum of E2M1 products on bit b)
+    exactly -- with the widths dv_fp4_plan derives (the first plane of a gap the int8 form split stands for the whole gap)."""
+    import ctypes
+    from navsim_amd import _native as N
+    lib = N.load()
+    e2m1 = {0x0: 0.0, 0x1: 0.5, 0x2: 1.0, 0x4: 2.0, 0xA: -1.0}
+    cases = [([0, 63, 127, 191, 255], True), ([0, 85, 170, 255], True), ([0, 255], True), ([1, 128, 255], True), ([0, 60, 130, 255], False),
+             ([0, 127, 255], False), ([3, 200], True), ([5], True), ([0, 10, 20, 30, 40, 50, 60, 70, 80], True)]
+    for levels, ok in cases:
+        presence = (ctypes.c_uint32 * 8)()
+        for v in levels:
+            presence[v >> 5] |= 1 << (v & 31)
+        lo = (ctypes.c_uint8 * 64)()
+        w = (ctypes.c_uint8 * 64)()
+        lmin, lmax = ctypes.c_int(), ctypes.c_int()
+        T = lib.dv_bitplane_plan(presence, 64, lo, w, ctypes.byref(lmin), ctypes.byref(lmax))
+        wfull = (ctypes.c_uint8 * 64)()
+        wacc = (ctypes.c_int * 4)()
+        assert lib.dv_fp4_plan(presence, T, lo, w, wfull, wacc) == (1 if ok else 0), levels
+        firsts = [t for t in range(T) if wfull[t]]
+        assert [lo[t] for t in firsts] == levels[:-1] and [wfull[t] for t in firsts] == [b - a for a, b in zip(levels, levels[1:])]
+        if not ok or T == 0:
+            continue
+        scale = {0: 2.0, 1: 1.0, 2: 0.5, 3: 1.0}                    # bit 0 stands for 0.5, bit 1 for 1, bit 2 for 2, bit 3 (shifted) for 1
+        on_level = sorted(set(levels) | {0, 255, max(levels[0] - 1, 0), min(levels[-1] + 1, 255)} - set(range(levels[0] + 1, levels[-1])) | set(levels))
+        for a in on_level:                                          # patch byte: a level, or outside [lmin, lmax]
+            if levels[0] < a < levels[-1] and a not in levels:
+                continue
+            for b in levels:                                        # library byte
+                n_px = 5                                            # a few pixels so that planes land on every bit position
+                acc = [0.0, 0.0, 0.0, 0.0]
+                want = 0
+                for n in range(n_px * T):
+                    t, bit = n % T, n % 4
+                    lib_bit = 1 if b >= lo[t] + w[t] else 0
+                    alpha = min(max(a - lo[t], 0), w[t])
+                    want += lib_bit * (w[t] - 2 * alpha)            # the int8 form's term
+                    if not wfull[t]:
+                        continue                                    # a copy of a split gap: coefficient 0 in the fp4 image
+                    assert a <= lo[t] or a >= lo[t] + wfull[t]
+                    sign = e2m1[0x2] if a <= lo[t] else e2m1[0xA]
+                    value = {0: e2m1[0x1], 1: e2m1[0x2], 2: e2m1[0x4], 3: e2m1[0x2]}[bit] if lib_bit else 0.0
+                    acc[bit] += sign * value
+                got = sum(int(wacc[bit]) * int(scale[bit] * acc[bit]) for bit in range(4))
+                assert got == want, (levels, a, b)
+    # the 3-bit level code of a five-level plane (k_bitpack_code) and its decode in the kernel
+    code = {0: 0b000, 1: 0b001, 2: 0b010, 3: 0b110, 4: 0b111}
+    for level, cbits in code.items():
+        b0, b1, b2 = cbits & 1, (cbits >> 1) & 1, (cbits >> 2) & 1
+        assert [b0 | b1, b1, b2, b0 & b2] == [int(level >= t) for t in (1, 2, 3, 4)]
+
+
 def test_experiment_helpers_match_the_reference(manifest, golden):
     """scripts/run_experiment.py's helpers, pinned by the reference's own outputs (tests/golden/make_golden.py imports
     the script; t7_experiment.npz): training-path generator and path chopping bit for bit, the result row of

@@ -134,6 +134,16 @@ static void plan_cases() {
             for (int k = 0; k < t; ++k) { REQUIRE(lo[k] == at && w[k] >= 1 && w[k] <= 127); at += w[k]; }
             REQUIRE(at == lmax);
         }
+        if (t >= 0) {                                          // fp4 plan of the same planes: exactly-sized buffers
+            uint8_t* wfull = (uint8_t*)std::malloc(t ? t : 1);
+            int wacc[4] = {-1, -1, -1, -1};
+            const int ok = dv_fp4_plan(presence, t, lo, w, wfull, wacc);
+            REQUIRE(ok == 0 || ok == 1);
+            int span = 0;
+            for (int k = 0; k < t; ++k) { REQUIRE(wfull[k] == 0 || wfull[k] >= w[k]); span += wfull[k]; }
+            REQUIRE(span == lmax - lmin);                      // the first planes of the gaps cover the level range once
+            std::free(wfull);
+        }
         std::free(lo);
         std::free(w);
     }
@@ -143,6 +153,6 @@ int main() {
     oracle_cases();
     merge_cases();
     plan_cases();
-    std::puts("asan_driver: ok (oracle C, dv_merge_records, dv_merge_keys, dv_bitplane_plan under ASan + UBSan)");
+    std::puts("asan_driver: ok (oracle C, dv_merge_records, dv_merge_keys, dv_bitplane_plan, dv_fp4_plan under ASan + UBSan)");
     return 0;
 }
