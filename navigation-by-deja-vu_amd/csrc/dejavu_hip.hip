@@ -9,6 +9,7 @@
 #include "dejavu_kernels.h"
 #include "../../include/dejavu.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -100,8 +101,10 @@ struct dv_ctx {
     // per-step buffers (sized at set_library)
     unsigned char* d_raw_patches = nullptr;   // [64][P][3]
     unsigned* d_prep = nullptr;               // [npl][Q][4][64]
-    int* d_hsconst_pair = nullptr;            // [2][64]: the sensed path alternates (k_sense_prep clears the other one)
-    int* d_hsconst = nullptr;                 // the buffer of the resident patches
+    PrepAcc* d_acc = nullptr;                 // [2] per-heading constants, off-level word and sensor-error mask of a patch preparation:
+    int acc_parity = 0;                       //   the sets alternate (k_patch_prep clears the other one); d_acc[acc_parity] is the resident patches'
+    PrepBits pbits{};                         // what k_patch_prep needs of the bit planes (smallest level, on-level bitmaps)
+    unsigned* d_one = nullptr;                // a word that holds 1: the "off level" word of libraries without an fp4 form
     unsigned long long* d_bsum2 = nullptr;    // k_fold_reduce: [agents][kFoldSlices][2][headings per agent]
     unsigned long long* d_bsum = nullptr;     // k_finish: per-block, per-heading (maximum, first view) [blocks][2][headings]
     unsigned long long* d_ctmp = nullptr;     // k_finish: shared extra-candidate list [agents][kTmpCap][2]
@@ -126,11 +129,9 @@ struct dv_ctx {
     uint4* d_btiles = nullptr;                // [Fpad/32][GS][64]
     size_t btile_bytes = 0;                   // of which streamed per pass: (Fpad/32) * (NK_hs + NK_v) KB
     uint4* d_coef = nullptr;                  // [2 passes][NK][8][64] int8 coefficient image of the resident patches
-    int* d_bconst = nullptr;                  // [2][64] per-heading constants of the two sums
-    bool coef_ready = false;                  // d_coef / d_bconst describe the resident patches
+    bool coef_ready = false;                  // d_coef / d_coef4 describe the resident patches
     int bits_env = 1;                         // DEJAVU_BITS: 0 never build the bit planes, 1 when they save bytes, 2 whenever possible
     int mfma_tiles_env = 0, mfma_chunk_env = 0;   // DEJAVU_MFMA_TILES / DEJAVU_MFMA_CHUNK (0 = by library size)
-    int mfma_variant_env = 0;                 // DEJAVU_MFMA_VARIANT: other forms of the matrix-core kernel (A/B runs), see launch_mfma
     const int* int_hsconst = nullptr;         // constants that go with the partial sums of the last integer scoring pass
     const int* int_vconst = nullptr;
     bool fuse_request = false;                // enqueue_step: this pass may finish its scores inside the scoring kernel
@@ -138,9 +139,7 @@ struct dv_ctx {
     // fp4 form of the matrix-core kernel (sad_ring_fp4): possible when every plane of a segment has one gap width
     bool fp4_ok = false;                      // this library's planes qualify (build_bit_planes)
     int fp4_env = 1;                          // DEJAVU_FP4=0: never
-    uint4* d_coef4 = nullptr;                 // [pass][K-step][4][64] E2M1 sign images (k_bit_prep)
-    unsigned* d_offlevel = nullptr;           // [2]: nonzero = the patches of that prep have a byte strictly inside a gap
-    int prep_seq = 0;                         // preps so far: word prep_seq & 1 belongs to the latest
+    uint4* d_coef4 = nullptr;                 // [pass][K-step][4][64] E2M1 sign images (k_coef_image)
     uint4* d_ctiles = nullptr;                // [Fpad/32][GSC][64] code tiles (k_bitpack_code), when bcfg.vcode
     size_t ctile_bytes = 0;
     // DEJAVU_VCODE=1: the fp4 form reads five-level value planes as 3-bit codes (k_bitpack_code: a third copy of the library, 5
@@ -148,19 +147,9 @@ struct dv_ctx {
     // 0.94 ms -- with the library stream out of the way the loop is bound by its LDS operand traffic and the matrix pipe
     // (tools/exp/fp4_ladder.hip), so the copy would cost 5 GB and buy nothing yet.
     int vcode_env = 0;
-    int fp4_variant_env = 0;
-    int last_form = 0;                        // DV_FORM_* of the last integer scoring pass (fp4 bit: the dual kernel was launched)                  // DEJAVU_FP4_VARIANT: A/B of the ring shapes
+    int last_form = 0;                        // DV_FORM_* of the last integer scoring pass (fp4 bit: the fp4 image existed)
     int fuse_env = 1;                         // DEJAVU_FUSE=0: one-chunk matrix-core passes leave their sums to k_finish instead of finishing them
     int fused_nb = 0;                         // summaries per agent it left
-    // the fused epilogue may also fold and decide (one agent, one launch): what it needs of the step, set by enqueue_step
-    bool fold_request = false, epilogue_folded = false;
-    // DEJAVU_FOLD_IN_KERNEL=1: off by default -- measured: the ticket's release fence in every workgroup and the last one's fold on
-    // cold caches cost the kernel +7 us at 500 000 views (tail 25 -> 10 us: step 1.002 -> 0.994 ms) and +8.7 us at 50 000
-    // views x 16 headings (tail 14.2 -> 6.2: step 53.5 -> 54.1 us); k_fold as its own launch takes 6-8 us.
-    int fold_force = 0, fold_env = 0;
-    StepResultDev* fold_out = nullptr;
-    double* fold_rec = nullptr;
-    const unsigned long long* fold_serr = nullptr;
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
     double* d_fam = nullptr;                  // [64][Fpad]
@@ -199,9 +188,7 @@ struct dv_ctx {
     size_t poses_cap = 0;
     unsigned char* d_sense = nullptr;         // [n][sh][sw][3] scratch for dv_sense
     size_t sense_cap = 0;
-    unsigned long long* d_err = nullptr;      // [3]: [0],[1] alternate with d_hsconst_pair (one bit per agent of the pass), [2] is k_sense's
-    int sense_parity = 0;
-    bool hsconst_dirty = false;               // k_prep (uploaded patches) wrote constants into d_hsconst
+    unsigned long long* d_sense_err = nullptr;   // k_sense's out-of-bounds flag (dv_sense, ingest from poses)
     std::vector<Pose> h_poses;
 
     // error / coverage metrics of the agent (training path resident; answers collected one step later)
@@ -241,10 +228,11 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
 
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_hsconst_pair); c->d_hsconst = nullptr; F(c->d_fam); F(c->d_scene);
+    F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_acc); F(c->d_one); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
-    F(c->d_btiles); F(c->d_coef); F(c->d_bconst); F(c->d_coef4); F(c->d_offlevel); F(c->d_ctiles); c->ctile_bytes = 0;
+    F(c->d_btiles); F(c->d_coef); F(c->d_coef4); F(c->d_ctiles); c->ctile_bytes = 0;
+    c->pbits = PrepBits{};
     c->bits_ok = false; c->coef_ready = false; c->btile_bytes = 0;
     c->metric = 0;
     F(c->d_state); F(c->d_cand); F(c->d_cand_exact);
@@ -288,15 +276,12 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_BITS", c->bits_env, 0, 2);
     env_int("DEJAVU_MFMA_TILES", c->mfma_tiles_env, 0, 2);
     env_int("DEJAVU_MFMA_CHUNK", c->mfma_chunk_env, 0, 32);
-    env_int("DEJAVU_MFMA_VARIANT", c->mfma_variant_env, 0, 4);
     env_int("DEJAVU_FINISH", c->finish_fused, 0, 2);
     env_int("DEJAVU_FENCED", c->fenced_env, 0, 1);
     env_int("DEJAVU_FINISH_VB", c->finish_vb_env, 0, 16);
     env_int("DEJAVU_FUSE", c->fuse_env, 0, 1);
     env_int("DEJAVU_FP4", c->fp4_env, 0, 1);
-    env_int("DEJAVU_FOLD_IN_KERNEL", c->fold_env, 0, 1);
     env_int("DEJAVU_VCODE", c->vcode_env, 0, 1);
-    env_int("DEJAVU_FP4_VARIANT", c->fp4_variant_env, 0, 8);
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
@@ -313,7 +298,7 @@ extern "C" void dv_destroy(dv_ctx* c) {
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_poses) (void)hipFree(c->d_poses);
     if (c->d_sense) (void)hipFree(c->d_sense);
-    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_sense_err) (void)hipFree(c->d_sense_err);
     if (c->d_path) (void)hipFree(c->d_path);
     if (c->d_cover) (void)hipFree(c->d_cover);
     if (c->d_errstate) (void)hipFree(c->d_errstate);
@@ -522,19 +507,28 @@ static int build_bit_planes(dv_ctx* c) {
     c->fp4_ok = one_width && c->fp4_env != 0;
     const long long G32 = g.Fpad / 32;
     c->btile_bytes = (size_t)G32 * nkt * 1024;
-    if (hipMalloc(&c->d_btiles, (size_t)G32 * b.GS * 1024) != hipSuccess || hipMalloc(&c->d_coef, (size_t)2 * nkt * 8192) != hipSuccess ||
-        hipMalloc(&c->d_bconst, 2 * kMaxHeadings * sizeof(int)) != hipSuccess) {
+    if (hipMalloc(&c->d_btiles, (size_t)G32 * b.GS * 1024) != hipSuccess || hipMalloc(&c->d_coef, (size_t)2 * nkt * 8192) != hipSuccess) {
         (void)hipGetLastError();                                        // not enough memory for the second copy: byte path
         if (c->d_btiles) { (void)hipFree(c->d_btiles); c->d_btiles = nullptr; }
         if (c->d_coef) { (void)hipFree(c->d_coef); c->d_coef = nullptr; }
-        if (c->d_bconst) { (void)hipFree(c->d_bconst); c->d_bconst = nullptr; }
         return DV_OK;
     }
-    if (c->fp4_ok && (hipMalloc(&c->d_coef4, (size_t)2 * nkt * 4096) != hipSuccess || hipMalloc(&c->d_offlevel, 2 * sizeof(unsigned)) != hipSuccess ||
-                      hipMemsetAsync(c->d_offlevel, 0, 2 * sizeof(unsigned), c->stream) != hipSuccess)) {
+    if (c->fp4_ok && hipMalloc(&c->d_coef4, (size_t)2 * nkt * 4096) != hipSuccess) {
         (void)hipGetLastError();
         c->fp4_ok = false;                                              // the int8 form alone
     }
+    // what the patch preparation needs of all this: per stored byte plane its smallest level (the patch-only terms of a
+    // byte add up to |a - l_0|) and the bytes that have fp4 coefficients -- on a level, or outside the library's range
+    PrepBits pb{};
+    pb.enabled = 1;
+    for (int bp = 0; bp < g.npl; ++bp) {
+        pb.lmin[bp] = b.lmin[bp];
+        for (int v = 0; v < 256; ++v) {
+            const bool level = (presence[bp * 8 + (v >> 5)] >> (v & 31)) & 1u;
+            if (level || v <= (int)b.lmin[bp] || v >= (int)b.lmax[bp]) pb.ok[bp][v >> 5] |= 1u << (v & 31);
+        }
+    }
+    c->pbits = pb;
     b.vcode = 0;
     b.GSC = b.GS;
     if (c->fp4_ok && five_levels) {
@@ -567,14 +561,19 @@ static int build_bit_planes(dv_ctx* c) {
 
 // Coefficient image + constants of the resident patches (raw bytes in d_raw_patches), when the MFMA path may score them.
 static bool mfma_path_possible(const dv_ctx* c);
+static const unsigned* offlevel_word(const dv_ctx* c) {                 // the scoring kernel's form switch for the resident patches
+    return c->fp4_ok ? &c->d_acc[c->acc_parity].off : c->d_one;
+}
 static int enqueue_bit_prep(dv_ctx* c, bool force = false) {
     c->coef_ready = false;
     if (!c->bits_ok || !(force || mfma_path_possible(c))) return DV_OK;
     const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
     const int npass = c->APAD > 32 ? 2 : 1;
-    ++c->prep_seq;
-    hipLaunchKernelGGL(k_bit_prep, dim3((unsigned)(nkt * npass + c->A)), dim3(512), 0, c->stream, c->d_raw_patches, c->d_coef,
-                       c->d_bconst, c->cfg, c->bcfg, c->A, npass, c->fp4_ok ? c->d_coef4 : nullptr, c->d_offlevel, c->prep_seq & 1);
+    // one block per (pass, K-step) of the fp4 image and two of the int8 image; the blocks of the image that will not be
+    // read return at once (k_coef_image)
+    const unsigned blocks = (unsigned)(nkt * npass * (c->fp4_ok ? 3 : 2));
+    hipLaunchKernelGGL(k_coef_image, dim3(blocks), dim3(256), 0, c->stream, c->d_prep, c->d_coef, c->fp4_ok ? c->d_coef4 : nullptr,
+                       offlevel_word(c), c->cfg, c->bcfg, c->A, c->APAD, npass);
     HIP_TRY(c, hipGetLastError());
     c->coef_ready = true;
     return DV_OK;
@@ -614,8 +613,10 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_tiles, c->tile_bytes));
     HIP_TRY(c, hipMalloc(&c->d_raw_patches, (size_t)kMaxHeadings * g.P * 3));
     HIP_TRY(c, hipMalloc(&c->d_prep, (size_t)g.npl * g.Q * 4 * kMaxHeadings * sizeof(unsigned)));
-    HIP_TRY(c, hipMalloc(&c->d_hsconst_pair, 2 * kMaxHeadings * sizeof(int)));
-    c->d_hsconst = c->d_hsconst_pair;
+    HIP_TRY(c, hipMalloc(&c->d_acc, 2 * sizeof(PrepAcc)));
+    HIP_TRY(c, hipMalloc(&c->d_one, sizeof(unsigned)));
+    c->acc_parity = 0;
+    c->pbits = PrepBits{};
     // Work items = (pixel chunk, view group).  The chunk count is chosen per launch (scoring_grid); the partial-sum
     // buffer is sized for the most chunks a launch can ask for.
     {
@@ -633,7 +634,8 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipMalloc(&c->d_scene, (size_t)g.Fpad * sizeof(double)));
     // per-agent state of a batched pass: up to kMaxHeadings agents (one heading each)
     HIP_TRY(c, hipMalloc(&c->d_state, kMaxHeadings * sizeof(StepState)));
-    HIP_TRY(c, hipMalloc(&c->d_bsum, (size_t)((g.F + 255) / 256) * 2 * kMaxHeadings * sizeof(unsigned long long)));
+    // summaries per agent: one per 256 views (k_finish) or one per workgroup of a fused scoring pass (at most 256: launch_mfma_dual_f)
+    HIP_TRY(c, hipMalloc(&c->d_bsum, (size_t)std::max<long long>((g.F + 255) / 256, 256) * 2 * kMaxHeadings * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_bsum2, (size_t)kFoldSlices * 2 * kMaxHeadings * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_ctmp, (size_t)kMaxHeadings * kTmpCap * 2 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand, (size_t)kMaxHeadings * kCandCap * sizeof(unsigned long long)));
@@ -644,7 +646,11 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_result, c->h_result, 0));
     memset(c->h_result, 0, kMaxHeadings * sizeof(StepResultDev));
     HIP_TRY(c, hipHostMalloc(&c->h_scene, (size_t)g.Fpad * sizeof(double)));
-    HIP_TRY(c, hipMemsetAsync(c->d_hsconst_pair, 0, 2 * kMaxHeadings * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, 2 * sizeof(PrepAcc), c->stream));
+    {
+        static const unsigned one = 1u;
+        HIP_TRY(c, hipMemcpyAsync(c->d_one, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_state, 0, kMaxHeadings * sizeof(StepState), c->stream));
     c->have_lib = true;
     return DV_OK;
@@ -928,9 +934,9 @@ extern "C" int dv_configure_sensor(dv_ctx* c, int sw, int sh, int pw, int ph, co
     if (mask_n < 0 || mask_n > sw / 2) return fail(c, DV_ERR_INVALID, "mask_middle_n %d outside [0, %d]", mask_n, sw / 2);
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->d_lut) HIP_TRY(c, hipMalloc(&c->d_lut, 768));
-    if (!c->d_err) {
-        HIP_TRY(c, hipMalloc(&c->d_err, 3 * sizeof(unsigned long long)));
-        HIP_TRY(c, hipMemsetAsync(c->d_err, 0, 3 * sizeof(unsigned long long), c->stream));
+    if (!c->d_sense_err) {
+        HIP_TRY(c, hipMalloc(&c->d_sense_err, sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->d_sense_err, 0, sizeof(unsigned long long), c->stream));
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_lut, lut, 768, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -954,18 +960,18 @@ static int enqueue_sense(dv_ctx* c, const double* x, const double* y, const doub
         const double rot = -(0.5 * M_PI - angle[i]);
         c->h_poses[(size_t)i] = Pose{x[i], y[i], std::cos(rot), std::sin(rot)};
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_err + 2, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_sense_err, 0, sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), (size_t)n * sizeof(Pose), hipMemcpyHostToDevice, c->stream));
     const long long total = n * c->sensor.sh * c->sensor.sw;
     hipLaunchKernelGGL(k_sense, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, c->d_poses, (int)n,
-                       c->sensor, c->d_lut, d_out, reinterpret_cast<int*>(c->d_err + 2));
+                       c->sensor, c->d_lut, d_out, reinterpret_cast<int*>(c->d_sense_err));
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
 
 static int check_sense_error(dv_ctx* c) {
     int err = 0;
-    HIP_TRY(c, hipMemcpyAsync(&err, c->d_err + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // k_sense's flag: low word
+    HIP_TRY(c, hipMemcpyAsync(&err, c->d_sense_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // k_sense's flag: low word
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (err) return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)");
     return DV_OK;
@@ -997,27 +1003,34 @@ extern "C" int dv_sense(dv_ctx* c, const double* x, const double* y, const doubl
 
 // Senses the patches of A_total headings (poses by value) straight into the scoring kernel's operand layout: ONE
 // kernel, no copy and no memset on the way (see k_sense_prep).  n_agents agents of A_agent headings each.
-static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int A_agent) {
-    Range range("dv:sense");
+static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_agents, int A_agent, unsigned long long seed) {
+    Range range(mode == 1 ? "dv:sense" : "dv:prep");
     const int A = n_agents * A_agent;
     c->A = A; c->n_agents = n_agents; c->A_agent = A_agent;
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
-    if (c->hsconst_dirty) {
-        // uploaded patches left their constants in the buffer this step would add into
-        HIP_TRY(c, hipMemsetAsync(c->d_hsconst_pair, 0, 2 * kMaxHeadings * sizeof(int), c->stream));
-        c->hsconst_dirty = false;
-    }
-    c->sense_parity ^= 1;
-    const int cur = c->sense_parity, nxt = cur ^ 1;
-    c->d_hsconst = c->d_hsconst_pair + cur * kMaxHeadings;
+    c->acc_parity ^= 1;
+    PrepAcc* cur = c->d_acc + c->acc_parity;
+    PrepAcc* nxt = c->d_acc + (c->acc_parity ^ 1);
     // (prep entries of the padded headings A..APAD-1 are left as they are: their sums are never read)
     const long long total = (long long)A * c->cfg.Q * 4;
-    hipLaunchKernelGGL(k_sense_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_land, poses, A,
-                       c->sensor, c->d_lut, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, c->APAD, c->d_err + cur,
-                       c->d_hsconst_pair + nxt * kMaxHeadings, c->d_err + nxt, A_agent);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    static const PoseSet no_poses{};
+    const PrepBits pb = c->bits_ok ? c->pbits : PrepBits{};
+    if (mode == 1)
+        hipLaunchKernelGGL(k_patch_prep<1>, grid, block, 0, c->stream, c->d_land, *poses, A, c->sensor, c->d_lut, c->d_raw_patches, c->d_prep,
+                           c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull);
+    else if (mode == 2)
+        hipLaunchKernelGGL(k_patch_prep<2>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, seed);
+    else
+        hipLaunchKernelGGL(k_patch_prep<0>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull);
     HIP_TRY(c, hipGetLastError());
-    c->patches_sensed = true;      // no host synchronisation here: the step's result record carries the error flag
+    c->patches_sensed = mode == 1;     // no host synchronisation here: the step's result record carries the sensor's error flag
     return enqueue_bit_prep(c);
+}
+static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int A_agent) {
+    return launch_patch_prep(c, 1, &poses, n_agents, A_agent, 0ull);
 }
 
 static int check_sense_args(dv_ctx* c, int A) {
@@ -1171,7 +1184,7 @@ extern "C" int dv_patches_on_level(dv_ctx* c) {
     if (!c->coef_ready) return fail(c, DV_ERR_STATE, "no coefficient image of the resident patches yet");
     HIP_TRY(c, hipSetDevice(c->device));
     unsigned word = 0;
-    HIP_TRY(c, hipMemcpyAsync(&word, c->d_offlevel + (c->prep_seq & 1), sizeof word, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&word, offlevel_word(c), sizeof word, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return word == 0 ? 1 : 0;
 }
@@ -1182,7 +1195,7 @@ extern "C" int dv_scoring_form(dv_ctx* c) {
     if (form & DV_FORM_FP4) {                              // the dual kernel ran: which image it took is on the device
         HIP_TRY(c, hipSetDevice(c->device));
         unsigned word = 0;
-        HIP_TRY(c, hipMemcpyAsync(&word, c->d_offlevel + (c->prep_seq & 1), sizeof word, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&word, offlevel_word(c), sizeof word, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (word != 0) form &= ~DV_FORM_FP4;
     }
@@ -1244,20 +1257,7 @@ extern "C" int dv_read_planes(dv_ctx* c, int64_t v0, int64_t n, uint8_t* out) {
 }
 
 // ------------------------------------------------------------------ patches
-static int prep_patches(dv_ctx* c, int A) {
-    c->A = A;
-    c->n_agents = 1;
-    c->A_agent = A;
-    c->patches_sensed = false;
-    c->hsconst_dirty = true;                  // k_prep writes this step's constants where the sensed path accumulates
-    c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
-    const long long total = (long long)c->cfg.npl * c->cfg.Q * 4 * c->APAD;
-    const unsigned nb = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(k_prep, dim3(nb + A), dim3(256), 0, c->stream, c->d_raw_patches, c->d_prep, c->d_hsconst, c->cfg, A,
-                       c->APAD);
-    HIP_TRY(c, hipGetLastError());
-    return enqueue_bit_prep(c);
-}
+static int prep_patches(dv_ctx* c, int A) { return launch_patch_prep(c, 0, nullptr, 1, A, 0ull); }
 
 static int check_step_args(dv_ctx* c, int A) {
     if (!c) return DV_ERR_INVALID;
@@ -1280,11 +1280,7 @@ extern "C" int dv_generate_patches(dv_ctx* c, uint64_t seed, int A) {
     int rc = check_step_args(c, A);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    const long long n = (long long)A * c->cfg.P;
-    hipLaunchKernelGGL(k_generate_patches, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_raw_patches, A,
-                       c->cfg.P, (unsigned long long)seed);
-    HIP_TRY(c, hipGetLastError());
-    return prep_patches(c, A);
+    return launch_patch_prep(c, 2, nullptr, 1, A, (unsigned long long)seed);     // generated straight into the operand layouts
 }
 
 // ------------------------------------------------------------------ scoring launches
@@ -1432,80 +1428,35 @@ static bool mfma_path_possible(const dv_ctx* c) {
     return t == 0 || t == 6;
 }
 
-template <int SK, int TILES>
-static void launch_mfma_variant(dv_ctx* c, int nchunk, int has_hs) {
-    static bool attr_set = false;
-    const size_t lds = (size_t)2 * SK * 8 * 1024;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_sad_mfma<SK, TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const long long G32 = c->cfg.Fpad / 32;
-    const long long items = ((G32 + 8 * TILES - 1) / (8 * TILES)) * nchunk;
-    const unsigned grid = (unsigned)(items < 256 ? items : 256);          // one 8-wave workgroup per CU, grid-stride
-    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
-    for (int a_off = 0; a_off < c->APAD; a_off += 32)
-        hipLaunchKernelGGL((k_sad_mfma<SK, TILES>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
-                           c->d_coef + (size_t)(a_off / 32) * nkt * 512, reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk,
-                           c->APAD, a_off, has_hs);
-}
-
 static FuseArgs fuse_args(const dv_ctx* c) {
     FuseArgs fz{};
-    fz.hsconst = c->d_bconst;
-    fz.vconst = c->d_bconst + kMaxHeadings;
+    fz.hsconst = c->d_acc[c->acc_parity].bhs;
+    fz.vconst = c->d_acc[c->acc_parity].bv;
     fz.bsum = c->d_bsum;
     fz.ctmp = c->d_ctmp;
     fz.st = c->d_state;
     fz.A_real = c->A;
     fz.A_agent = c->A_agent;
     fz.delta = c->delta;
-    if (c->fold_request && c->n_agents == 1 && c->APAD <= 32 && c->fold_env) {
-        fz.fold_here = 1;
-        fz.force = c->fold_force;
-        fz.seq = c->seq + 1;
-        fz.cand = c->d_cand;
-        fz.out = c->fold_out;
-        fz.rec = c->fold_rec;
-        fz.sense_err = c->fold_serr;
-    }
     return fz;
 }
 
-template <int SK, int TILES, int RD, bool FUSE>
-static void launch_mfma_ring_f(dv_ctx* c, int nchunk, int has_hs, const FuseArgs& fz_in) {
-    static bool attr_set = false;
-    size_t lds = (size_t)RD * (SK * 8 + 8 * SK * TILES) * 1024;
-    if (FUSE) lds += (size_t)kFuseScratchBytes;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_sad_mfma_ring<SK, TILES, RD, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const long long G32 = c->cfg.Fpad / 32;
-    const long long items = ((G32 + 8 * TILES - 1) / (8 * TILES)) * nchunk;
-    const unsigned grid = (unsigned)(items < 256 ? items : 256);
-    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
-    FuseArgs fz = fz_in;
-    fz.nb = (int)grid;
-    for (int a_off = 0; a_off < c->APAD; a_off += 32)
-        hipLaunchKernelGGL((k_sad_mfma_ring<SK, TILES, RD, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
-                           c->d_coef + (size_t)(a_off / 32) * nkt * 512, reinterpret_cast<int*>(c->d_part), c->cfg, c->bcfg, nchunk,
-                           c->APAD, a_off, has_hs, fz);
-    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; c->epilogue_folded = fz.fold_here != 0; }   // one summary per workgroup
+// View-group ranges (items per chunk) the library is cut into for a workgroup of 8 waves x TILES groups: as few as hold it,
+// ceil(G32 / VW), of equal size to within one group.  DEJAVU_BALANCE=1 (A/B) cuts finer -- one range per CU for small
+// libraries, whole rounds of the 256 resident workgroups for large ones -- which measured SLOWER (50 000 views x 64x64: ring
+// loop 28.7 -> 30.3 us; 500 000 x 128x128: 1.026 -> 1.035 ms): a workgroup's time per K-step does not depend on how many of
+// its waves have a group (tools/exp/stamps.py), so idle CUs cost less than waves that only keep the ring's bookkeeping going.
+static long long item_groups(long long G32, int VW) {
+    const long long n = (G32 + VW - 1) / VW;
+    static const int balance = getenv("DEJAVU_BALANCE") ? atoi(getenv("DEJAVU_BALANCE")) : 0;
+    if (!balance) return n;
+    if (n < 256) return G32 < 256 ? G32 : 256;
+    const long long up = (n + 255) / 256 * 256;
+    return n * 4 >= up * 3 ? up : n;
 }
 
-template <int SK, int TILES, int RD>
-static void launch_mfma_ring(dv_ctx* c, int nchunk, int has_hs) {
-    // One chunk and a step that may end in k_fold: the kernel finishes its scores itself.
-    if (c->fuse_request && nchunk == 1 && c->fuse_env) {
-        const FuseArgs fz = fuse_args(c);
-        launch_mfma_ring_f<SK, TILES, RD, true>(c, nchunk, has_hs, fz);
-    } else {
-        launch_mfma_ring_f<SK, TILES, RD, false>(c, nchunk, has_hs, FuseArgs{});
-    }
-}
-
-// Both forms in one launch (k_sad_mfma_dual): the fp4 form when this prep's patches sit on the library's levels.
+// Both forms in one launch (k_sad_mfma_dual): the fp4 form when this prep's patches sit on the library's levels (the
+// device decides, offlevel_word); libraries without an fp4 form point that word at a constant 1 and pass no fp4 image.
 template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE>
 static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     static bool attr_set = false;
@@ -1520,41 +1471,42 @@ static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
         attr_set = true;
     }
     const long long G32 = c->cfg.Fpad / 32;
-    const long long items = ((G32 + 8 * TILES - 1) / (8 * TILES)) * nchunk;
-    const unsigned grid = (unsigned)(items < 256 ? items : 256);
+    const long long n_gq = item_groups(G32, 8 * TILES);
+    const long long items = n_gq * nchunk;
+    const unsigned grid = (unsigned)(items < 256 ? items : 256);          // one 8-wave workgroup per CU, grid-stride
     const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
     FuseArgs fz{};
     if (FUSE) { fz = fuse_args(c); fz.nb = (int)grid; }
     for (int a_off = 0; a_off < c->APAD; a_off += 32)
         hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->bcfg.vcode ? c->d_ctiles : c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
-                           c->d_coef4 + (size_t)(a_off / 32) * nkt * 256, c->d_offlevel + (c->prep_seq & 1), reinterpret_cast<int*>(c->d_part),
-                           c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz);
-    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; c->epilogue_folded = fz.fold_here != 0; }   // one summary per workgroup
+                           c->fp4_ok ? c->d_coef4 + (size_t)(a_off / 32) * nkt * 256 : nullptr, offlevel_word(c), reinterpret_cast<int*>(c->d_part),
+                           c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz, (int)n_gq);
+    if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }     // one summary per workgroup
 }
 
 template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES>
 static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
+    // One chunk and a step that may end in k_fold: the kernel finishes its scores itself.
     if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, true>(c, nchunk, has_hs);
     else launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, false>(c, nchunk, has_hs);
 }
 
-// Work items of k_sad_mfma = (chunk of K-steps, 8*TILES view groups of 32).  Two view groups per wave halve the
-// coefficient traffic (every A operand serves both) once the library is large enough to keep every CU busy that way;
-// small libraries cut the K-steps into chunks instead so that there are at least as many items as CUs.
+// Work items of k_sad_mfma_dual = (chunk of K-steps, range of at most 8*TILES view groups of 32).  Two view groups per wave
+// halve the coefficient traffic (every A operand serves both) once the library is large enough to keep every CU busy that
+// way; very small libraries also cut the K-steps into chunks so that there are about as many items as CUs.
 static void launch_mfma(dv_ctx* c, int has_hs) {
     const long long G32 = c->cfg.Fpad / 32;
     // two view groups per wave once there are about 1.25 such items per CU (200 000 views x 128x128 x 32 headings, 391 items:
     // 0.432 ms with two, 0.474 ms with one; 500 000 views: two)
     int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (G32 >= 16ll * 320 ? 2 : 1);
-    const long long GQ = (G32 + 8 * tiles - 1) / (8 * tiles);
+    const long long GQ = item_groups(G32, 8 * tiles);
     int nchunk = 1;
     if (c->mfma_chunk_env) {
         nchunk = c->mfma_chunk_env;
     } else if (GQ < 160) {
-        // Fewer items than ~60 % of the CUs: cut the K-steps so that every CU has one.  (Measured on 50 000 views x 64x64,
-        // 196 items: 1 chunk 59.6 us, 2 chunks 65.3, 3 chunks 74.1, 5 chunks 71.2 -- more chunks mean more partial sums
-        // and more pipeline fills than the idle CUs cost.)
+        // Fewer view groups than ~60 % of the CUs: cut the K-steps too.  (More chunks mean partial sums through HBM, k_finish
+        // behind the kernel and more pipeline fills: only where CUs would otherwise have nothing at all.)
         nchunk = (int)((256 + GQ - 1) / GQ);
     }
     const int nk_min = c->bcfg.NK[1] > 0 ? (c->bcfg.NK[0] > 0 && c->bcfg.NK[0] < c->bcfg.NK[1] ? c->bcfg.NK[0] : c->bcfg.NK[1]) : c->bcfg.NK[0];
@@ -1562,47 +1514,14 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     if (nchunk > c->nchunk_cap) nchunk = c->nchunk_cap;
     if (nchunk < 1) nchunk = 1;
     c->nchunk = nchunk;
-    // Forms of the kernel (DEJAVU_MFMA_VARIANT, A/B runs).  Default: both operands through LDS rings by LDS-DMA with
-    // counted waits (k_sad_mfma_ring).  Measured, 500 000 views x 128x128 x 32 headings, two view groups per wave:
-    // register-staged library bits, stage of 4 K-steps 1.48-1.51 ms; rings <SK,TILES,RD> = <2,2,3> 1.38, <2,2,2> 1.37,
-    // <1,2,3..6> 1.29 ms.  50 000 views x 64x64 x 16 headings, one view group per wave: register-staged, stage of 8
-    // K-steps 56.7 us; rings <2,1,4> 50.2, <4,1,2> 46.7, <1,1,6> 50.9 us.
-    const int var = c->mfma_variant_env;
-    if (c->fp4_ok && var == 0) {
-        const int v4 = c->fp4_variant_env;
-        // <int8 stage, ring | fp4 stage, ring (thermometer rows) | fp4 stage, ring (code rows), view groups per wave>
-        if (tiles == 2) {
-            switch (v4) {                                      // 500 000 views x 128x128 x 32 headings, bit tiles: 0.96 / 1.07 ms
-                case 1: launch_mfma_dual<1, 3, 2, 3, 2, 2, 2>(c, nchunk, has_hs); break;
-                case 2: launch_mfma_dual<1, 3, 2, 2, 2, 3, 2>(c, nchunk, has_hs); break;
-                default: launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs);
-            }
-        } else {
-            switch (v4) {                                      // 50 000 views x 64x64 x 16 headings, bit tiles: 38.6 / 40.6 / 41.4 us
-                case 1: launch_mfma_dual<4, 2, 4, 3, 4, 3, 1>(c, nchunk, has_hs); break;
-                case 2: launch_mfma_dual<4, 2, 2, 6, 2, 6, 1>(c, nchunk, has_hs); break;
-                default: launch_mfma_dual<4, 2, 2, 4, 2, 4, 1>(c, nchunk, has_hs);
-            }
-        }
-        return;
-    }
-    if (tiles == 2) {
-        switch (var) {
-            case 1: launch_mfma_variant<2, 2>(c, nchunk, has_hs); break;
-            case 2: launch_mfma_variant<4, 2>(c, nchunk, has_hs); break;
-            case 3: launch_mfma_ring<2, 2, 3>(c, nchunk, has_hs); break;
-            case 4: launch_mfma_ring<1, 2, 5>(c, nchunk, has_hs); break;
-            default: launch_mfma_ring<1, 2, 3>(c, nchunk, has_hs);
-        }
-    } else {
-        switch (var) {
-            case 1: launch_mfma_variant<4, 1>(c, nchunk, has_hs); break;
-            case 2: launch_mfma_variant<8, 1>(c, nchunk, has_hs); break;
-            case 3: launch_mfma_ring<2, 1, 4>(c, nchunk, has_hs); break;
-            case 4: launch_mfma_ring<1, 1, 6>(c, nchunk, has_hs); break;
-            default: launch_mfma_ring<4, 1, 2>(c, nchunk, has_hs);
-        }
-    }
+    // <int8 stage, ring | fp4 stage, ring (thermometer rows) | fp4 stage, ring (code rows), view groups per wave>.  Measured in
+    // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
+    // x 64x64 x 16 headings <4, 2> 46.7 us; fp4 <2, 3> 0.95 ms and <2, 4> 34.5 us.
+    static const int ring = getenv("DEJAVU_RING") ? atoi(getenv("DEJAVU_RING")) : 0;                // A/B of ring shapes
+    if (tiles == 2) launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs);
+    else if (ring == 1) launch_mfma_dual<4, 2, 2, 6, 2, 6, 1>(c, nchunk, has_hs);
+    else if (ring == 2) launch_mfma_dual<4, 2, 4, 3, 4, 3, 1>(c, nchunk, has_hs);
+    else launch_mfma_dual<4, 2, 2, 4, 2, 4, 1>(c, nchunk, has_hs);
 }
 
 // The integer path of one scoring pass: k_sad_tiles / k_sad_generic, then k_combine.  `after_tiles` (optional) is
@@ -1610,7 +1529,7 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
 static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial, bool with_combine = true) {
     const LibCfg& g = c->cfg;
     int has_hs_sum, has_v_sum = g.hasv;
-    c->int_hsconst = c->d_hsconst;
+    c->int_hsconst = c->d_acc[c->acc_parity].hs;
     c->int_vconst = nullptr;
     c->epilogue_fused = false;                           // set again below by a pass that finishes its own scores
     c->last_form = 0;
@@ -1618,9 +1537,9 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial,
         if (!c->coef_ready) { const int rc = enqueue_bit_prep(c, true); if (rc) return rc; }
         has_hs_sum = g.nhs > 0 ? 1 : 0;
         launch_mfma(c, has_hs_sum);
-        c->last_form = DV_FORM_MATRIX_CORES | ((c->fp4_ok && c->mfma_variant_env == 0) ? DV_FORM_FP4 : 0) | (c->epilogue_fused ? DV_FORM_FUSED_FINISH : 0);
-        c->int_hsconst = c->d_bconst;
-        c->int_vconst = c->d_bconst + kMaxHeadings;
+        c->last_form = DV_FORM_MATRIX_CORES | (c->fp4_ok ? DV_FORM_FP4 : 0) | (c->epilogue_fused ? DV_FORM_FUSED_FINISH : 0);
+        c->int_hsconst = c->d_acc[c->acc_parity].bhs;
+        c->int_vconst = c->d_acc[c->acc_parity].bv;
     } else if (g.generic) {
         has_hs_sum = 1;
         if (g.hasv) launch_generic_apad<1, 1>(c); else launch_generic_apad<1, 0>(c);
@@ -1789,11 +1708,10 @@ static int step_fenced(const dv_ctx* c) {
 // One step on the resident patches: scoring (2 launches) + k_tail.  The result record lands in mapped host memory.
 // k_fold behind summaries left by k_finish or by a fused scoring epilogue.  Long lists (more than 512 summaries per
 // agent) are first cut down to kFoldSlices by k_fold_reduce on as many workgroups: one workgroup walking 977 summaries x
-// 32 headings took 23.5 us at 500 000 views (DEJAVU_FOLD2=0 keeps that form).
+// 32 headings took 23.5 us at 500 000 views.
 static void launch_fold(dv_ctx* c, int nb, StepResultDev* outp, double* recp, int force, int seq, const unsigned long long* serr) {
-    static const int two_level = getenv("DEJAVU_FOLD2") ? atoi(getenv("DEJAVU_FOLD2")) : 1;
     unsigned long long* sums = c->d_bsum;
-    if (two_level && nb > 512) {
+    if (nb > 512) {
         const int per = (nb + kFoldSlices - 1) / kFoldSlices;
         const int slices = (nb + per - 1) / per;
         hipLaunchKernelGGL(k_fold_reduce, dim3((unsigned)slices, (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_bsum, c->d_bsum2,
@@ -1803,10 +1721,8 @@ static void launch_fold(dv_ctx* c, int nb, StepResultDev* outp, double* recp, in
     }
     // threads: enough that every thread walks at most 16 summaries of its heading in one round trip (fold_and_decide), no more
     // -- a 1024-thread workgroup spends its time in its own barriers when 32 summaries are left
-    static const int threads_env = getenv("DEJAVU_FOLD_THREADS") ? atoi(getenv("DEJAVU_FOLD_THREADS")) : 0;
     int threads = 1024;
-    if (threads_env == 256 || threads_env == 512 || threads_env == 1024) threads = threads_env;
-    else if ((long long)nb * c->A_agent <= 256ll * 16) threads = 256;
+    if ((long long)nb * c->A_agent <= 256ll * 16) threads = 256;
     else if ((long long)nb * c->A_agent <= 512ll * 16) threads = 512;
     hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3((unsigned)threads), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state,
                        outp, recp, c->cfg, c->A_agent, c->delta, force, seq, serr, nb);
@@ -1822,7 +1738,7 @@ static void launch_finish(dv_ctx* c, int want_scene, int force) {
     const long long per_block = 256 * vb;
     const unsigned nb = (unsigned)((g.F + per_block - 1) / per_block);
     const int separate = nb > 256 ? 1 : 0;
-    const unsigned long long* serr = c->patches_sensed ? c->d_err + c->sense_parity : nullptr;
+    const unsigned long long* serr = c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr;
     StepResultDev* outp = c->d_result + c->result_slot;
     double* recp = c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings);
     ++c->seq;
@@ -1848,22 +1764,14 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     // partial sums never reach HBM and the step ends in k_fold alone.  Not with scene_fam: its minimum over headings
     // runs across the lanes there.
     c->fuse_request = c->metric == 0 && !c->exact && !want_scene;
-    c->fold_request = c->fuse_request;
-    c->fold_force = force;
-    c->fold_out = c->d_result + c->result_slot;
-    c->fold_rec = c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings);
-    c->fold_serr = c->patches_sensed ? c->d_err + c->sense_parity : nullptr;
     c->epilogue_fused = false;
-    c->epilogue_folded = false;
     int rc = launch_scoring(c, !fused);
     c->fuse_request = false;
-    c->fold_request = false;
     if (rc) return rc;
     Range range("dv:finish");
-    if (c->epilogue_fused && c->epilogue_folded) {
-        ++c->seq;                                              // the scoring kernel's last workgroup folded and decided
-    } else if (c->epilogue_fused) {
-        launch_fold(c, c->fused_nb, c->fold_out, c->fold_rec, force, ++c->seq, c->fold_serr);
+    if (c->epilogue_fused) {
+        launch_fold(c, c->fused_nb, c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), force, ++c->seq,
+                    c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr);
     } else if (fused) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
         else launch_finish<2>(c, scene_on, force);
@@ -1872,7 +1780,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
                            c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result + c->result_slot,
                            c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,
                            c->A_agent, c->delta, scene_on, c->exact, force, ++c->seq,
-                           c->patches_sensed ? c->d_err + c->sense_parity : nullptr, c->metric == 1 ? 3e-6 : 0.0, step_fenced(c));
+                           c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr, c->metric == 1 ? 3e-6 : 0.0, step_fenced(c));
     }
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
@@ -1896,7 +1804,7 @@ static int enqueue_resolve(dv_ctx* c, int agent = 0) {
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state + agent, c->d_cand + co, c->d_cand_exact + co,
                        c->d_result + agent, c->d_record + (size_t)agent * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta,
-                       c->patches_sensed ? c->d_err + c->sense_parity : nullptr, agent);
+                       c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr, agent);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
@@ -2185,6 +2093,16 @@ extern "C" int dv_path_reset(dv_ctx* c) {
 }
 
 // ------------------------------------------------------------------ measurement
+#ifdef DEJAVU_STAMPS
+extern "C" int dv_debug_stamps(dv_ctx* c, unsigned long long* out) {       // diagnostic builds only (tools/exp/stamps.py)
+    if (!c || !out) return DV_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dv_stamps), 256 * 8 * sizeof(unsigned long long)));
+    return DV_OK;
+}
+#endif
+
 extern "C" int dv_timer_start(dv_ctx* c) {
     if (!c) return DV_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));

@@ -27,6 +27,15 @@
 
 namespace dv {
 
+// Diagnostic builds only (tools/exp/stamps.py compiles a copy with -DDEJAVU_STAMPS): wall-clock stamps (100 MHz counter)
+// of the matrix-core kernel's phases per workgroup, in a buffer nothing else reads.  The product build has no stamps.
+#ifdef DEJAVU_STAMPS
+__device__ unsigned long long g_dv_stamps[256 * 8];
+#define DV_STAMP(i) do { if (threadIdx.x == 0) g_dv_stamps[(blockIdx.x & 255) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DV_STAMP(i) do { } while (0)
+#endif
+
 constexpr int kMaxHeadings = 64;
 constexpr int kMaxHues = 4;
 constexpr int kCandCap = 4096;
@@ -241,17 +250,6 @@ __global__ void k_generate_tiles(uint4* __restrict__ tiles, LibCfg c, unsigned l
     tiles[g * c.gstride + ((long long)pl * c.Q + q) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// Raw synthetic patches uint8[A][P][3] (stream seed+1, like synth.synth_patches).
-__global__ void k_generate_patches(unsigned char* __restrict__ raw, int A, int P, unsigned long long seed) {
-    const long long n = (long long)A * P;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned H, S, V;
-    synth_hsv(splitmix64((unsigned long long)i + (seed + 1ull) * 0x9E3779B97F4A7C15ull), H, S, V);
-    raw[i * 3 + 0] = (unsigned char)H;
-    raw[i * 3 + 1] = (unsigned char)S;
-    raw[i * 3 + 2] = (unsigned char)V;
-}
 
 // tiles -> planes uint8[n][npl][P] for local views [v0, v0+n)   (layout read-back)
 __global__ void k_read_planes(const uint4* __restrict__ tiles, unsigned char* __restrict__ out, LibCfg c,
@@ -266,55 +264,6 @@ __global__ void k_read_planes(const uint4* __restrict__ tiles, unsigned char* __
     const long long idx = (f >> 6) * c.gstride + ((long long)pl * c.Q + (px >> 4)) * 64 + (f & 63);
     const unsigned char* b = reinterpret_cast<const unsigned char*>(tiles + idx);
     out[t] = b[px & 15];
-}
-
-// ------------------------------------------------------------------ per-step patch preparation
-// raw patches uint8[A][P][3] -> prep[pl][q][j][APAD] dwords (byte b of dword j = pixel 16q+4j+b),
-// hsconst[a] = sum over pixels whose hue is outside the library's hue set of S  (one-hot layout).
-__global__ void k_prep(const unsigned char* __restrict__ raw, unsigned* __restrict__ prep,
-                       int* __restrict__ hsconst, LibCfg c, int A, int APAD) {
-    const int nprep_blocks = gridDim.x - A;
-    if ((int)blockIdx.x < nprep_blocks) {
-        const long long total = (long long)c.npl * c.Q * 4 * APAD;
-        const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        if (t >= total) return;
-        const int a = (int)(t % APAD);
-        long long r = t / APAD;
-        const int j = (int)(r & 3); r >>= 2;
-        const int q = (int)(r % c.Q);
-        const int pl = (int)(r / c.Q);
-        unsigned w = 0;
-        if (a < A) {
-            const unsigned char* p = raw + (long long)a * c.P * 3;
-            for (int b = 0; b < 4; ++b) {
-                const int px = q * 16 + j * 4 + b;
-                if (px < c.P) w |= plane_byte(c, pl, p[px * 3], p[px * 3 + 1], p[px * 3 + 2]) << (8 * b);
-            }
-        }
-        prep[t] = w;
-    } else {
-        const int a = blockIdx.x - nprep_blocks;
-        __shared__ int part[256];
-        int s = 0;
-        if (!c.generic && c.cw > 0.0) {
-            const unsigned char* p = raw + (long long)a * c.P * 3;
-            const int nk = c.signed_s ? 2 : c.nhs;
-            for (int px = threadIdx.x; px < c.P; px += blockDim.x) {
-                const unsigned H = p[px * 3], S = p[px * 3 + 1];
-                bool in_set = false;
-                for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
-                if (!in_set) s += S;
-                else if (c.signed_s && S > 127u) s += S - 127u;       // excess over the clamped plane byte
-            }
-        }
-        part[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) hsconst[a] = part[0];
-    }
 }
 
 // ------------------------------------------------------------------ the scoring kernel
@@ -1900,10 +1849,7 @@ __global__ void k_sense(const unsigned char* __restrict__ land, const Pose* __re
     o[0] = (unsigned char)oh; o[1] = (unsigned char)os; o[2] = (unsigned char)ov;
 }
 
-// Sensing fused with the per-step patch preparation (dv_sense_patches): one thread per (heading, group of 4 sensor
-// pixels) senses its 4 pixels, stores them raw (uint8[A][P][3], needed by the exact kernels) and writes the prep
-// dword of every stored plane; the per-heading constant is folded per wave and added with one integer atomic.
-// hsconst[0..A) must be zero on entry (hipMemsetAsync).
+// One sensor pixel of one pose (k_patch_prep senses the headings' patches with it, four pixels per thread).
 __device__ __forceinline__ bool sense_pixel(const unsigned char* __restrict__ land, const SensorCfg& g, const Pose& p,
                                             const unsigned char* __restrict__ lut, int bi, int bj,
                                             unsigned& oh, unsigned& os, unsigned& ov) {
@@ -1938,88 +1884,161 @@ __device__ __forceinline__ bool sense_pixel(const unsigned char* __restrict__ la
     return true;
 }
 
+// ------------------------------------------------------------------ per-step patch preparation
+// ONE kernel makes the resident patches of a step, whatever their source (MODE): uploaded raw bytes (0), the sensor
+// model at the headings' poses (1: dv_sense_patches, dv_sense_step*), or the synthetic stream of the benchmarks (2).
+// One thread per (heading, group of 4 sensor pixels):
+//   raw[a][P][3]            the patches' bytes (written for MODE 1 and 2; the exact kernels and the tie resolver read them);
+//   prep[pl][q][j][APAD]    dword = 4 pixels (16q + 4j ..) of heading a in stored byte plane pl: the SGPR operands of
+//                           v_sad_u8 (byte path) and the source of the coefficient images (k_coef_image);
+//   acc->hs[a]              byte path: sum over pixels whose hue is outside the library's hue set of S (+ the excess of a
+//                           clamped signed-saturation byte), see plane_byte;
+//   acc->bhs[a], bv[a]      bit-plane path: everything of the two sums that does not depend on the view.  With the
+//                           thermometer identity (below, "bit-plane library") the patch-only terms of one byte add up to
+//                           (l_0 - a)+ + (a - l_max)+ + sum_t alpha_t = |a - l_0|, l_0 the plane's smallest library value;
+//   acc->off                nonzero when some patch byte lies strictly inside a gap between two library levels: the
+//                           scoring kernel then takes its int8 form (k_sad_mfma_dual) and k_coef_image writes that image;
+//   acc->err                bit per agent of the pass: its sensor footprint reached past the end of the landscape.
+// The sums are folded per wave and added with one integer atomic each, so they must start at zero: `next` is the OTHER
+// set of the pair, which nothing uses during this step -- block 0 clears it for the next preparation, and no memset
+// sits on a step's path.
+struct PrepAcc {
+    int hs[kMaxHeadings];
+    int bhs[kMaxHeadings];
+    int bv[kMaxHeadings];
+    unsigned long long err;
+    unsigned off;
+    unsigned pad;
+};
+struct PrepBits {
+    int enabled;                              // the library has bit planes (build_bit_planes)
+    unsigned char lmin[kMaxHues + 1];         // smallest library value of each stored byte plane
+    unsigned ok[kMaxHues + 1][8];             // bit v of plane pl: patch byte v has fp4 coefficients (on a level, or outside the range)
+};
 // The headings' poses travel as a kernel argument (64 x 32 bytes): no host-to-device copy on the step's path.
 struct PoseSet { Pose p[kMaxHeadings]; };
 
-// hsconst / err are this step's accumulators (added into with atomics, so they must start at zero; err is a mask with one
-// bit per agent of the pass, A_agent headings each); next_hsconst / next_err are the OTHER buffers of their pairs, which nothing uses during this step: block 0 clears them for the
-// next sensed step, so that no memset sits on a step's path.
+template <int MODE>
 __global__ void __launch_bounds__(256)
-k_sense_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A, SensorCfg g,
-             const unsigned char* __restrict__ lut, unsigned char* __restrict__ raw, unsigned* __restrict__ prep,
-             int* __restrict__ hsconst, LibCfg c, int APAD, unsigned long long* __restrict__ err, int* __restrict__ next_hsconst,
-             unsigned long long* __restrict__ next_err, int A_agent) {
+k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A, SensorCfg g, const unsigned char* __restrict__ lut,
+             unsigned char* __restrict__ raw, unsigned* __restrict__ prep, LibCfg c, int APAD, PrepAcc* __restrict__ acc,
+             PrepAcc* __restrict__ next, int A_agent, PrepBits pb, unsigned long long seed) {
     if (blockIdx.x == 0) {
-        if (threadIdx.x < kMaxHeadings) next_hsconst[threadIdx.x] = 0;
-        if (threadIdx.x == 0) *next_err = 0;
+        if (threadIdx.x < kMaxHeadings) { next->hs[threadIdx.x] = 0; next->bhs[threadIdx.x] = 0; next->bv[threadIdx.x] = 0; }
+        if (threadIdx.x == 0) { next->err = 0; next->off = 0; }
     }
-    // the level tables (3 x 256 bytes) go to LDS: the lookups then cost no second trip to memory
+    // the level tables of the sensor (3 x 256 bytes) and the on-level bitmaps go to LDS: per-lane lookups
     __shared__ unsigned char s_lut[768];
-    if (threadIdx.x < 192) reinterpret_cast<unsigned*>(s_lut)[threadIdx.x] = reinterpret_cast<const unsigned*>(lut)[threadIdx.x];
+    __shared__ unsigned s_ok[(kMaxHues + 1) * 8];
+    if (MODE == 1 && threadIdx.x < 192) reinterpret_cast<unsigned*>(s_lut)[threadIdx.x] = reinterpret_cast<const unsigned*>(lut)[threadIdx.x];
+    if (threadIdx.x < (kMaxHues + 1) * 8) s_ok[threadIdx.x] = pb.ok[threadIdx.x >> 3][threadIdx.x & 7];
     __syncthreads();
     const int ngroups = c.Q * 4;                           // groups of 4 pixels, incl. the zero padding
     const long long total = (long long)A * ngroups;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int konst = 0;
+    int k_hs = 0, k_bhs = 0, k_bv = 0;
+    bool off = false;
     int a = 0;
     if (t < total) {
         a = (int)(t / ngroups);                            // heading-major: a wave never straddles two headings
         const int grp = (int)(t % ngroups);                //   when ngroups is a multiple of 64; handled below otherwise
-        const Pose p = poses.p[a];
+        unsigned Hs[4] = {0, 0, 0, 0}, Ss[4] = {0, 0, 0, 0}, Vs[4] = {0, 0, 0, 0};
+        const long long roff = ((long long)a * c.P + (long long)grp * 4) * 3;
+        const bool whole = (roff & 3) == 0 && grp * 4 + 3 < c.P;      // the group's 12 raw bytes are three aligned dwords
+        if (MODE == 1) {
+            const Pose p = poses.p[a];
+            bool okp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                  // four independent fetches in flight
+                const int px = grp * 4 + i;
+                okp[i] = true;
+                if (px < c.P) okp[i] = sense_pixel(land, g, p, s_lut, px / g.sw, px % g.sw, Hs[i], Ss[i], Vs[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (!okp[i]) { atomicOr(&acc->err, 1ull << (a / A_agent)); Hs[i] = Ss[i] = Vs[i] = 0; }     // bit = agent of the pass
+        } else if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = grp * 4 + i;
+                if (px < c.P)
+                    synth_hsv(splitmix64((unsigned long long)((long long)a * c.P + px) + (seed + 1ull) * 0x9E3779B97F4A7C15ull), Hs[i], Ss[i], Vs[i]);
+            }
+        } else {
+            unsigned char rb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (whole) {
+                const unsigned* s = reinterpret_cast<const unsigned*>(raw + roff);
+                const unsigned d0 = s[0], d1 = s[1], d2 = s[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rb[k] = (unsigned char)(d0 >> (8 * k)); rb[4 + k] = (unsigned char)(d1 >> (8 * k)); rb[8 + k] = (unsigned char)(d2 >> (8 * k)); }
+            } else {
+                for (int i = 0; i < 12 && grp * 4 + i / 3 < c.P; ++i) rb[i] = raw[roff + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Hs[i] = rb[3 * i]; Ss[i] = rb[3 * i + 1]; Vs[i] = rb[3 * i + 2]; }
+        }
         unsigned w[kMaxHues + 1];
         for (int pl = 0; pl < c.npl; ++pl) w[pl] = 0;
-        unsigned Hs[4], Ss[4], Vs[4];
-        unsigned char rawb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        bool okp[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                      // four independent fetches in flight
-            const int px = grp * 4 + i;
-            okp[i] = true;
-            Hs[i] = Ss[i] = Vs[i] = 0;
-            if (px < c.P) okp[i] = sense_pixel(land, g, p, s_lut, px / g.sw, px % g.sw, Hs[i], Ss[i], Vs[i]);
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = grp * 4 + i;
             if (px >= c.P) break;
-            unsigned H = Hs[i], S = Ss[i], V = Vs[i];
-            if (!okp[i]) { atomicOr(err, 1ull << (a / A_agent)); H = S = V = 0; }     // bit = agent of the pass
-            rawb[3 * i] = (unsigned char)H; rawb[3 * i + 1] = (unsigned char)S; rawb[3 * i + 2] = (unsigned char)V;
-            for (int pl = 0; pl < c.npl; ++pl) w[pl] |= plane_byte(c, pl, H, S, V) << (8 * i);
+            const unsigned H = Hs[i], S = Ss[i], V = Vs[i];
+            int konst = 0;
             if (!c.generic && c.cw > 0.0) {
                 const int nk = c.signed_s ? 2 : c.nhs;
                 bool in_set = false;
                 for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
-                if (!in_set) konst += (int)S;
-                else if (c.signed_s && S > 127u) konst += (int)S - 127;
+                if (!in_set) konst = (int)S;
+                else if (c.signed_s && S > 127u) konst = (int)S - 127;       // excess over the clamped plane byte
+            }
+            k_hs += konst;
+            k_bhs += konst;
+            for (int pl = 0; pl < c.npl; ++pl) {
+                const unsigned av = plane_byte(c, pl, H, S, V);
+                w[pl] |= av << (8 * i);
+                if (pb.enabled) {
+                    const int d = abs((int)av - (int)pb.lmin[pl]);
+                    if (pl < c.nhs) k_bhs += d; else k_bv += d;
+                    off |= ((s_ok[pl * 8 + (av >> 5)] >> (av & 31)) & 1u) == 0u;
+                }
             }
         }
-        // the group's raw bytes (for the exact kernels): three dword stores when the 12 bytes are aligned and all there
-        const long long roff = ((long long)a * c.P + (long long)grp * 4) * 3;
-        if ((roff & 3) == 0 && grp * 4 + 3 < c.P) {
-            unsigned* o = reinterpret_cast<unsigned*>(raw + roff);
+        if (MODE != 0) {                                   // the group's raw bytes, for the exact kernels
+            unsigned char rawb[12];
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
-                o[d] = (unsigned)rawb[4 * d] | ((unsigned)rawb[4 * d + 1] << 8) | ((unsigned)rawb[4 * d + 2] << 16) | ((unsigned)rawb[4 * d + 3] << 24);
-        } else {
-            for (int i = 0; i < 12 && grp * 4 + i / 3 < c.P; ++i) raw[roff + i] = rawb[i];
+            for (int i = 0; i < 4; ++i) { rawb[3 * i] = (unsigned char)Hs[i]; rawb[3 * i + 1] = (unsigned char)Ss[i]; rawb[3 * i + 2] = (unsigned char)Vs[i]; }
+            if (whole) {
+                unsigned* o = reinterpret_cast<unsigned*>(raw + roff);
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    o[d] = (unsigned)rawb[4 * d] | ((unsigned)rawb[4 * d + 1] << 8) | ((unsigned)rawb[4 * d + 2] << 16) | ((unsigned)rawb[4 * d + 3] << 24);
+            } else {
+                for (int i = 0; i < 12 && grp * 4 + i / 3 < c.P; ++i) raw[roff + i] = rawb[i];
+            }
         }
         const int q = grp >> 2, j = grp & 3;
         for (int pl = 0; pl < c.npl; ++pl) prep[(((long long)pl * c.Q + q) * 4 + j) * APAD + a] = w[pl];
     }
-    // per-heading constant: lanes of a wave may belong to two headings when ngroups is not a multiple of 64
+    if (__any(off) && (threadIdx.x & 63) == 0) atomicOr(&acc->off, 1u);
+    // per-heading constants: lanes of a wave may belong to two headings when ngroups is not a multiple of 64
     const int a_first = __shfl(a, 0);
     const bool uniform = __all(t >= total || a == a_first);
     if (uniform) {
-        int sum = (t < total) ? konst : 0;
+        int s0 = (t < total) ? k_hs : 0, s1 = (t < total) ? k_bhs : 0, s2 = (t < total) ? k_bv : 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if ((threadIdx.x & 63) == 0 && sum != 0) atomicAdd(&hsconst[a_first], sum);
-    } else if (t < total && konst != 0) {
-        atomicAdd(&hsconst[a], konst);
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if ((threadIdx.x & 63) == 0) {
+            if (s0 != 0) atomicAdd(&acc->hs[a_first], s0);
+            if (s1 != 0) atomicAdd(&acc->bhs[a_first], s1);
+            if (s2 != 0) atomicAdd(&acc->bv[a_first], s2);
+        }
+    } else if (t < total) {
+        if (k_hs != 0) atomicAdd(&acc->hs[a], k_hs);
+        if (k_bhs != 0) atomicAdd(&acc->bhs[a], k_bhs);
+        if (k_bv != 0) atomicAdd(&acc->bv[a], k_bv);
     }
 }
-
 // ------------------------------------------------------------------ bit-plane library + int8 MFMA scoring
 // |a - b| is not bilinear, but it becomes linear in b once b is known to come from a small level set
 // l_0 < l_1 < ... (the reference's sensor quantises V to n_sensor_levels values, NavBySceneFamiliarity.py:176-186, and
@@ -2170,291 +2189,88 @@ k_bitpack_code(const uint4* __restrict__ btiles, unsigned* __restrict__ ctiles, 
     }
 }
 
-// Per-step operand of the MFMA path, from the raw patches uint8[A][P][3] (left by k_prep / k_sense_prep):
-//   blocks [0, NKT * npass): the 8 KB coefficient image of one K-step for headings [32*pass, 32*pass + 32);
-//   blocks beyond: one per heading, its two constants bconst[0][a] (HS) and bconst[1][a] (V): everything of the sums
-//   that does not depend on the view (incl. the hue-outside-the-set and clamped-saturation terms of k_prep).
-__global__ void __launch_bounds__(512)
-k_bit_prep(const unsigned char* __restrict__ raw, uint4* __restrict__ coef, int* __restrict__ bconst, LibCfg c, BitCfg b,
-           int A, int npass, uint4* __restrict__ coef4, unsigned* __restrict__ offlevel, int slot) {
+// Per-step operands of the MFMA path, from the patches' stored-plane bytes (prep, left by k_patch_prep).  One block of 256
+// threads per (pass of 32 headings, K-step, image part); every thread makes ONE 16-byte entry of an image with its own
+// loads (no LDS staging, no atomics: the whole preparation is one round trip).  Which image the scoring kernel will read
+// is known when this kernel starts (*offp, k_patch_prep), so only that one is written:
+//   fp4 image  coef4[pass][ks][bit b][lane] : nibble i of dword j = sign of K-element ((2 ks + half) 4 + j) 32 + 4 i + b
+//              as E2M1 (+1.0 = 0x2, -1.0 = 0xA; 0 for a copy of a split gap's first plane and beyond the last pixel);
+//              part = 0: thread = (b = wave, lane);
+//   int8 image coef[pass][ks][slice s][lane] : byte bb of dword j = w_t - 2 alpha_t of K-element ((2 ks + half) 4 + j) 32 + s + 8 bb;
+//              parts 1, 2: thread = (s = 4 (part - 1) + wave, lane).
+// lane = (heading & 31) + 32 half.  Element n of a segment = plane n % T of pixel n / T.
+__global__ void __launch_bounds__(256)
+k_coef_image(const unsigned* __restrict__ prep, uint4* __restrict__ coef, uint4* __restrict__ coef4, const unsigned* __restrict__ offp,
+             LibCfg c, BitCfg b, int A, int APAD, int npass) {
+    __shared__ unsigned s_tbl[kMaxBitPlanes];              // per bit plane: byte plane | lo << 8 | w << 16 | wfull << 24
+    if (threadIdx.x < kMaxBitPlanes)
+        s_tbl[threadIdx.x] = (unsigned)b.pl[threadIdx.x] | ((unsigned)b.lo[threadIdx.x] << 8) | ((unsigned)b.w[threadIdx.x] << 16) |
+                             ((unsigned)b.wfull[threadIdx.x] << 24);
+    __syncthreads();
     const int NKT = b.NK[0] + b.NK[1];
-    const int ncoef = NKT * npass;
-    if (coef4 && blockIdx.x == 0 && threadIdx.x == 0) offlevel[slot ^ 1] = 0;
-    // the plane tables are indexed per K-element: out of LDS, not out of the kernel-argument segment (a dependent load per
-    // access there: the per-heading blocks took 23 us and the image blocks 16 us of a 100-us agent step)
-    __shared__ unsigned char t_pl[kMaxBitPlanes], t_lo[kMaxBitPlanes], t_w[kMaxBitPlanes], t_lmin[kMaxHues + 1], t_lmax[kMaxHues + 1];
-    __shared__ unsigned char t_wfull[kMaxBitPlanes];
-    if (threadIdx.x < kMaxBitPlanes) { t_pl[threadIdx.x] = b.pl[threadIdx.x]; t_lo[threadIdx.x] = b.lo[threadIdx.x]; t_w[threadIdx.x] = b.w[threadIdx.x]; t_wfull[threadIdx.x] = b.wfull[threadIdx.x]; }
-    if (threadIdx.x < kMaxHues + 1) { t_lmin[threadIdx.x] = b.lmin[threadIdx.x]; t_lmax[threadIdx.x] = b.lmax[threadIdx.x]; }
-    __syncthreads();      // the next prep's word starts clean
-    if ((int)blockIdx.x < ncoef) {
-        // One K-step of both images.  Thread (lane, g) owns bits 4g .. 4g+3 of the lane's four library dwords: 16 K-elements,
-        // each looked at ONCE (one division per dword to find its pixel and plane, then counting up), and its coefficient goes
-        // to both images through LDS -- a byte of row s = bit % 8 of the int8 image, a nibble of row b = bit % 4 of the fp4
-        // image (+1.0 = 0x2, -1.0 = 0xA; a byte strictly inside a gap has no such coefficient and flags the prep).
-        __shared__ unsigned img8[8 * 64 * 4];
-        __shared__ unsigned img4[4 * 64 * 4];
-        const int pass = blockIdx.x / NKT, ks = blockIdx.x % NKT;
-        const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-        const int a = pass * 32 + (lane & 31), half = lane >> 5;
-        const int seg = ks >= b.NK[0] ? 1 : 0;
-        const int ksl = ks - (seg ? b.NK[0] : 0);
-        for (int i = threadIdx.x; i < 8 * 64 * 4; i += blockDim.x) img8[i] = 0;
-        for (int i = threadIdx.x; i < 4 * 64 * 4; i += blockDim.x) img4[i] = 0;
-        const int T = b.T[seg], first = seg ? b.T[0] : 0;
-        // the pixels this K-step touches (256 consecutive K-elements = at most 257 pixels), of all 32 headings, staged in LDS
-        // with coalesced reads: a lane is a heading here, and lanes reading their own heading's bytes from HBM touch 32
-        // cache lines per instruction (the kernel took 23 us of a 100-us agent step that way)
-        __shared__ unsigned char pix[32][257 * 3 + 1];
-        const int px_lo = T > 0 ? (int)(((long long)ksl * 256) / T) : 0;
-        int px_hi = T > 0 ? (int)(((long long)ksl * 256 + 255) / T) : -1;
-        if (px_hi >= c.P) px_hi = c.P - 1;
-        const int nbytes = px_hi >= px_lo ? (px_hi - px_lo + 1) * 3 : 0;
-        for (int h = g; h < 32; h += 8) {                               // wave g copies headings g, g + 8, ...
-            const int ah = pass * 32 + h;
-            const unsigned char* src = raw + (long long)ah * c.P * 3 + (long long)px_lo * 3;
-            for (int o = lane; o < nbytes; o += 64) pix[h][o] = ah < A ? src[o] : (unsigned char)0;
-        }
-        __syncthreads();
-        bool off = false;
-        if (a < A && T > 0) {
-            const unsigned char* p = &pix[lane & 31][0] - (long long)px_lo * 3;      // p[px * 3 + channel] as before
-            unsigned char* img8b = reinterpret_cast<unsigned char*>(img8);
-            // (unrolled, no early exit: the LDS reads of the sixteen elements go out together instead of one round trip each)
+    const int n4 = coef4 ? NKT * npass : 0;
+    const unsigned off = (coef4 && offp) ? __builtin_amdgcn_readfirstlane(*offp) : 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool is4 = (int)blockIdx.x < n4;
+    if (is4 ? off != 0u : (coef4 != nullptr && off == 0u)) return;      // the other image is the one that will be read
+    const int idx = is4 ? (int)blockIdx.x : ((int)blockIdx.x - n4) >> 1;   // (pass, K-step)
+    const int sub = is4 ? wave : (((int)blockIdx.x - n4) & 1) * 4 + wave;   // bit position / slice
+    const int pass = idx / NKT, ks = idx - pass * NKT;
+    const int seg = ks >= b.NK[0] ? 1 : 0;
+    const int ksl = ks - (seg ? b.NK[0] : 0);
+    const int T = b.T[seg], first = seg ? b.T[0] : 0;
+    const int a = pass * 32 + (lane & 31), half = lane >> 5;
+    const int STEP = is4 ? 4 : 8;
+    unsigned out[4] = {0u, 0u, 0u, 0u};
+    if (a < A && T > 0) {
+        const unsigned uT = (unsigned)T, qs = (unsigned)STEP / uT, rs = (unsigned)STEP % uT;
+        const unsigned* pa = prep + a;
+        const long long plane_stride = (long long)c.Q * 4 * APAD;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned n = (unsigned)((ksl * 2 + half) * 4 + j) * 32u + 4u * (unsigned)g;     // < T * P + 256: fits 32 bits
-                int px = (int)(n / (unsigned)T), r = (int)(n - (unsigned)px * (unsigned)T);
+        for (int j = 0; j < 4; ++j) {
+            const unsigned n = (unsigned)((ksl * 2 + half) * 4 + j) * 32u + (unsigned)sub;     // < T * P + 256: fits 32 bits
+            unsigned px = n / uT, r = n - px * uT;
+            // the loads of a dword's elements go out together (clamped addresses: no conditional loads)
+            unsigned tb[8], dw[8], sh[8];
+            bool real[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool real = px < c.P;                        // zero beyond the last pixel
-                    const int pxc = real ? px : c.P - 1;
-                    const int plane = first + r;
-                    const int av = (int)plane_byte(c, t_pl[plane], p[pxc * 3], p[pxc * 3 + 1], p[pxc * 3 + 2]);
-                    const int wd = (int)t_w[plane];
-                    const int al = av - (int)t_lo[plane];
-                    const int alpha = al < 0 ? 0 : (al > wd ? wd : al);
-                    if (real) img8b[((4 * (g & 1) + e) * 64 + lane) * 16 + j * 4 + (g >> 1)] = (unsigned char)((wd - 2 * alpha) & 0xff);
-                    if (coef4 && real) {
-                        const int wf = (int)t_wfull[plane];            // 0: a copy of a split gap's first plane
-                        if (wf) {
-                            if (al <= 0) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0x2u << (4 * g));
-                            else if (al >= wf) atomicOr(&img4[(e * 64 + lane) * 4 + j], 0xAu << (4 * g));
-                            else off = true;
-                        }
+            for (int e = 0; e < 8; ++e) {
+                if (e < 32 / STEP) {
+                    tb[e] = s_tbl[first + (int)r];
+                    real[e] = px < (unsigned)c.P;
+                    const unsigned pxc = real[e] ? px : (unsigned)c.P - 1u;
+                    dw[e] = pa[(long long)(tb[e] & 0xffu) * plane_stride + (long long)(pxc >> 2) * APAD];
+                    sh[e] = 8u * (pxc & 3u);
+                    px += qs; r += rs;
+                    if (r >= uT) { r -= uT; ++px; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < 32 / STEP) {
+                    const int av = (int)((dw[e] >> sh[e]) & 0xffu);
+                    const int al = av - (int)((tb[e] >> 8) & 0xffu);
+                    if (is4) {
+                        const int wf = (int)(tb[e] >> 24);                 // 0: a copy of a split gap's first plane
+                        if (real[e] && wf) out[j] |= (al >= wf ? 0xAu : 0x2u) << (4 * e);
+                    } else {
+                        const int wd = (int)((tb[e] >> 16) & 0xffu);
+                        const int alpha = al < 0 ? 0 : (al > wd ? wd : al);
+                        if (real[e]) out[j] |= (unsigned)((wd - 2 * alpha) & 0xff) << (8 * e);
                     }
-                    if (++r == T) { r = 0; ++px; }
                 }
             }
         }
-        __syncthreads();
-        coef[((long long)blockIdx.x * 8 + g) * 64 + lane] = reinterpret_cast<const uint4*>(img8)[g * 64 + lane];
-        if (coef4) {
-            if (g < 4) coef4[((long long)blockIdx.x * 4 + g) * 64 + lane] = reinterpret_cast<const uint4*>(img4)[g * 64 + lane];
-            if (off) atomicOr(&offlevel[slot], 1u);
-        }
-        return;
     }
-    const int a = blockIdx.x - ncoef;
-    __shared__ int red[2][8];
-    int k_hs = 0, k_v = 0;
-    const unsigned char* p = raw + (long long)a * c.P * 3;
-    const int nplanes = b.T[0] + b.T[1];
-    // eight pixels per round, their 24 byte loads issued together (one round trip per round instead of one per pixel)
-    for (int px0 = threadIdx.x; px0 < c.P; px0 += 8 * blockDim.x) {
-      unsigned hsv[8][3];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-          const int px = px0 + i * blockDim.x;
-          const int pc = px < c.P ? px : c.P - 1;
-          hsv[i][0] = p[pc * 3]; hsv[i][1] = p[pc * 3 + 1]; hsv[i][2] = p[pc * 3 + 2];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (px0 + i * (int)blockDim.x >= c.P) break;
-        const unsigned H = hsv[i][0], S = hsv[i][1], V = hsv[i][2];
-        // (constant trip counts: the plane tables are then scalar registers, not a memory access per use)
-#pragma unroll
-        for (int bp = 0; bp < kMaxHues + 1; ++bp) {
-            if (bp >= b.nbp) break;
-            const int av = (int)plane_byte(c, bp, H, S, V);
-            int k = 0;
-            if (av < (int)b.lmin[bp]) k += (int)b.lmin[bp] - av;
-            if (av > (int)b.lmax[bp]) k += av - (int)b.lmax[bp];
-#pragma unroll
-            for (int t = 0; t < kMaxBitPlanes; ++t) {
-                if (t >= nplanes || b.pl[t] != bp) continue;
-                const int al = av - (int)b.lo[t];
-                k += al < 0 ? 0 : (al > (int)b.w[t] ? (int)b.w[t] : al);
-            }
-            if (bp < c.nhs) k_hs += k; else k_v += k;
-        }
-        if (c.cw > 0.0) {                                   // as k_prep's hsconst
-            const int nk = c.signed_s ? 2 : c.nhs;
-            bool in_set = false;
-            for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
-            if (!in_set) k_hs += (int)S;
-            else if (c.signed_s && S > 127u) k_hs += (int)S - 127;
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { k_hs += __shfl_xor(k_hs, o); k_v += __shfl_xor(k_v, o); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = k_hs; red[1][threadIdx.x >> 6] = k_v; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int s_hs = 0, s_v = 0;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { s_hs += red[0][i]; s_v += red[1][i]; }
-        bconst[a] = s_hs;
-        bconst[kMaxHeadings + a] = s_v;
-    }
+    const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
+    if (is4) coef4[((long long)idx * 4 + sub) * 64 + lane] = v;
+    else coef[((long long)idx * 8 + sub) * 64 + lane] = v;
 }
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-// The scoring kernel of the bit-plane path.  Workgroup = 8 waves (two per SIMD), wave w scores TILES view groups of 32
-// views against 32 headings; item = (chunk of K-steps, 8*TILES view groups), grid-stride over a resident grid.
-//   * coefficients of a stage (SK K-steps, SK*8 KB) go global -> LDS by LDS-DMA one stage ahead (two buffers, one
-//     barrier per stage; they are the same for every workgroup and come out of L2);
-//   * library bits are loaded one stage ahead into registers (non-temporal: each byte is used once per step);
-//   * the four A operands of the next half K-step are read from LDS before the current half's MFMAs start;
-//   * every A operand serves the wave's TILES view groups.
-// Output: part[(ch*nsum + type_row)*APADtot + a_off + m][f], the same integer sums k_sad_tiles leaves (minus the
-// per-heading constants, which k_finish / k_combine add), so a chunk's sum may be negative: consumers read int32.
-template <int SK, int TILES>
-__global__ void __launch_bounds__(512, 2)
-k_sad_mfma(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, LibCfg c, BitCfg b,
-           int nchunk, int apad_total, int a_off, int has_hs_sum) {
-    extern __shared__ uint4 lds_coef[];           // [2][SK][8][64]
-    constexpr int NW = 8;
-    constexpr int VW = NW * TILES;
-    constexpr int STAGE16 = SK * 8 * 64;
-    constexpr int PER_W = STAGE16 / (64 * NW);    // 1-KB rows each wave fetches per stage
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long G32 = c.Fpad / 32;
-    const long long GQ = (G32 + VW - 1) / VW;
-    const long long n_items = GQ * nchunk;
-    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;      // headings this pass owns
-    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int ch = (int)(item / GQ);
-        const long long gq = item - (long long)ch * GQ;
-        const uint4* lib[TILES];
-        long long gidx[TILES];
-        bool live[TILES];
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            long long g = gq * VW + wave * TILES + t;
-            live[t] = g < G32;
-            if (!live[t]) g = G32 - 1;
-            gidx[t] = g;
-            lib[t] = btiles + (g * b.GS) * 64 + lane;
-        }
-#pragma unroll 1
-        for (int seg = 0; seg < 2; ++seg) {
-            if (seg == 0 && !has_hs_sum) continue;
-            if (seg == 1 && !c.hasv) continue;
-            const int kbase = seg ? b.NK[0] : 0;
-            const int k0 = kbase + (int)(((long long)ch * b.NK[seg]) / nchunk);
-            const int k1 = kbase + (int)(((long long)(ch + 1) * b.NK[seg]) / nchunk);
-            const int nst = (k1 - k0 + SK - 1) / SK;
-            v16i_t acc[TILES][4];
-#pragma unroll
-            for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][s][r] = 0;
-            if (nst > 0) {
-                v4u_t ring[2][TILES][SK];
-                auto kclamp = [&](int k) { return k < k1 ? k : k1 - 1; };
-                auto dma_stage = [&](int st) {
-                    const int kb = k0 + st * SK;
-#pragma unroll
-                    for (int i = 0; i < PER_W; ++i) {
-                        const int row = wave * PER_W + i;                 // (K-step, slice) row of the stage
-                        long long src = ((long long)kb * 8 + row) * 64 + lane;
-                        const long long lim = (long long)k1 * 512;
-                        if (src >= lim) src = lim - 64 + lane;            // past the chunk: any valid row (masked below)
-                        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(coef + src),
-                                                         (lds_ptr_t)(lds_coef + (st & 1) * STAGE16 + row * 64), 16, 0, 0);
-                    }
-                };
-                dma_stage(0);
-#pragma unroll
-                for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                    for (int k = 0; k < SK; ++k)
-                        ring[0][t][k] = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(lib[t] + (long long)kclamp(k0 + k) * 64));
-                for (int st0 = 0; st0 < nst; st0 += 2) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {           // register set of stage st is st & 1
-                        const int st = st0 + u;
-                        if (st < nst) {
-                            const int kb = k0 + st * SK;
-                            __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's DMA rows and library bits are in
-                            __syncthreads();                          // everybody's are, and nobody still reads the other buffer
-                            if (st + 1 < nst) dma_stage(st + 1);
-#pragma unroll
-                            for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                                for (int k = 0; k < SK; ++k)
-                                    ring[u ^ 1][t][k] = __builtin_nontemporal_load(
-                                        reinterpret_cast<const v4u_t*>(lib[t] + (long long)kclamp(kb + SK + k) * 64));
-                            __builtin_amdgcn_sched_barrier(0);
-                            const uint4* buf = lds_coef + (st & 1) * STAGE16 + lane;
-                            v4i_t a[2][4];
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) { const uint4 w = buf[s * 64]; a[0][s] = v4i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
-#pragma unroll
-                            for (int hs = 0; hs < 2 * SK; ++hs) {
-                                if (hs + 1 < 2 * SK) {
-#pragma unroll
-                                    for (int s = 0; s < 4; ++s) {
-                                        const uint4 w = buf[((hs + 1) * 4 + s) * 64];
-                                        a[(hs + 1) & 1][s] = v4i_t{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
-                                    }
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                                const int k = hs >> 1;
-                                const bool on = kb + k < k1;
-#pragma unroll
-                                for (int t = 0; t < TILES; ++t) {
-                                    const v4u_t x = ring[u][t][k];
-                                    const v4u_t src = (hs & 1) ? v4u_t{x.x >> 4, x.y >> 4, x.z >> 4, x.w >> 4} : x;
-#pragma unroll
-                                    for (int s = 0; s < 4; ++s) {
-                                        const unsigned m = on ? (0x01010101u << s) : 0u;
-                                        const v4i_t bo = v4i_t{(int)(src.x & m), (int)(src.y & m), (int)(src.z & m), (int)(src.w & m)};
-                                        acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[hs & 1][s], bo, acc[t][s], 0, 0, 0);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                __syncthreads();                  // the next segment / item refills LDS buffer 0
-            }
-            const int type_row = seg ? has_hs_sum : 0;
-            const int nsum = has_hs_sum + c.hasv;
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                if (live[t]) {
-                    int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int tot = acc[t][0][r] + (acc[t][1][r] >> 1) + (acc[t][2][r] >> 2) + (acc[t][3][r] >> 3);
-                        if (m < rows) dst[(long long)m * c.Fpad] = tot;
-                    }
-                }
-            }
-        }
-    }
-}
 
 // The same scoring with BOTH operands streamed through LDS rings by LDS-DMA (global_load_lds, no destination
 // registers) RD stages deep, and every vector-memory wait counted by hand:
@@ -2498,24 +2314,15 @@ __device__ __forceinline__ void lds_dma_16_nt(const uint4* gsrc, unsigned lds_by
 // lists candidates against the item's own best (the superset rule of k_finish); k_fold behind the kernel folds the
 // summaries and decides.  The partial sums then cross HBM not at all, and k_finish / k_combine + k_tail drop out of the step.
 struct FuseArgs {
-    const int* hsconst;             // per-heading constants of the two sums (k_bit_prep)
+    const int* hsconst;             // per-heading constants of the two sums (k_patch_prep: PrepAcc::bhs, bv)
     const int* vconst;
-    unsigned long long* bsum;       // [agents][nb][2][A_agent] item summaries
+    unsigned long long* bsum;       // [agents][nb][2][A_agent] workgroup summaries
     unsigned long long* ctmp;       // [agents][kTmpCap][2] shared extra-candidate lists
     StepState* st;                  // [agents]
     int A_real;                     // resident headings
     int A_agent;                    // headings per agent
     int nb;                         // summaries per agent (one per workgroup)
     double delta;
-    // fold_here: one agent, one launch -- the last workgroup to arrive folds the summaries and decides (fold_and_decide),
-    // so no launch at all follows the scoring kernel
-    int fold_here;
-    int force;
-    int seq;
-    unsigned long long* cand;
-    StepResultDev* out;
-    double* rec;
-    const unsigned long long* sense_err;
 };
 
 // Fused finishing of one item (FUSE forms).  The accumulators are transposed there (library bits as the A operand of the
@@ -2731,28 +2538,15 @@ __device__ __forceinline__ void fused_block_end(const unsigned long long* scratc
         __hip_atomic_store(&bsm[kk], blk_key[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&bsm[fz.A_agent + kk], blk_key[n] ? blk_key[32 + n] : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!fz.fold_here) return;                    // k_fold, launched behind this kernel, does the rest
-    // ---- arrival ticket, as in k_finish, always with the release / acquire pair (once per workgroup and step here)
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        s_last = (atomicAdd(&fz.st->done, 1u) == gridDim.x - 1) ? 1 : 0;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!s_last) return;
-    fold_and_decide(fz.bsum, fz.ctmp, fz.cand, fz.st, fz.out, fz.rec, c, fz.A_agent, fz.delta, fz.force, fz.seq, fz.sense_err, 0, (int)gridDim.x);
+    (void)c;                                      // k_fold, launched behind this kernel, folds the summaries and decides
 }
 
 template <int SK, int TILES, int RD, bool FUSE>
 __device__ __forceinline__ void
 sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
-            int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz) {
+            int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz, int n_gq) {
     extern __shared__ uint4 lds_ring[];           // [RD][ coefficient rows SK*8 | library rows 8 waves * SK * TILES ][64], then FUSE scratch
     constexpr int NW = 8;
-    constexpr int VW = NW * TILES;
     constexpr int COEF_ROWS = SK * 8;             // per stage
     constexpr int LIB_ROWS = NW * SK * TILES;
     constexpr int SLOT16 = (COEF_ROWS + LIB_ROWS) * 64;      // uint4 per ring slot
@@ -2762,7 +2556,7 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long G32 = c.Fpad / 32;
-    const long long GQ = (G32 + VW - 1) / VW;
+    const long long GQ = n_gq;                    // view-group ranges the library is cut into (item_groups)
     const long long n_items = GQ * nchunk;
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
     const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
@@ -2770,14 +2564,15 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / GQ);
         const long long gq = item - (long long)ch * GQ;
+        const long long g0 = (gq * G32) / GQ, g1 = ((gq + 1) * G32) / GQ;     // at most VW groups (launch_mfma)
         const uint4* lib[TILES];
         long long gidx[TILES];
         bool live[TILES];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            long long g = gq * VW + wave * TILES + t;
-            live[t] = g < G32;
-            if (!live[t]) g = G32 - 1;
+            long long g = g0 + wave * TILES + t;
+            live[t] = g < g1;
+            if (!live[t]) g = g0;                 // a slot without a group streams nothing: it re-reads one row (L2), see issue_stage
             gidx[t] = g;
             lib[t] = btiles + (g * b.GS) * 64 + lane;
         }
@@ -2817,7 +2612,9 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
 #pragma unroll
                         for (int t = 0; t < TILES; ++t) {
                             const int row = COEF_ROWS + (wave * SK + k) * TILES + t;
-                            lds_dma_16_nt(lib[t] + (long long)kclamp(kb + k) * 64, __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u));
+                            const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)(row * 64) * 16u);
+                            if (live[t]) lds_dma_16_nt(lib[t] + (long long)kclamp(kb + k) * 64, dst);
+                            else lds_dma_16(coef + (long long)k0 * 512 + lane, dst);     // a coefficient row, hot in L2: keeps this wave's vmcnt arithmetic; never used
                         }
                 };
 #pragma unroll
@@ -2909,13 +2706,6 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
     if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(lds_ring + RD * SLOT16), fz, c, a_off);
 }
 
-template <int SK, int TILES, int RD, bool FUSE>
-__global__ void __launch_bounds__(512, 2)
-k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, int* __restrict__ part, LibCfg c, BitCfg b,
-                int nchunk, int apad_total, int a_off, int has_hs_sum, FuseArgs fz) {
-    sad_ring_i8<SK, TILES, RD, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
-}
-
 // The fp4 form of the same kernel.  When every patch byte sits on a level or outside the library's range (the
 // reference's patches come through the quantiser the library came through, NavBySceneFamiliarity.py:176-186), every
 // coefficient w_t - 2 alpha_t is +w_t or -w_t; and when the planes that land on bit position b of a nibble all have one
@@ -2926,7 +2716,7 @@ k_sad_mfma_ring(const uint4* __restrict__ btiles, const uint4* __restrict__ coef
 // the signs are exact in fp4 (E2M1: +-1.0), the library bits too (bit 0/1/2 of a nibble ARE the E2M1 values 0.5/1/2, bit 3
 // comes down by a shift), and v_mfma_f32_32x32x64_f8f6f4 multiplies 64 K-elements in the time the int8 form takes for 32
 // (measured: 21.2 vs 18.3 ns per instruction and SIMD, tools/exp/mfma_fp4.hip).  The SAME bit tiles are the B operand:
-// K-element <-> (dword j, bit 4i + b) pairs with nibble i of coefficient image b of that K-step (k_bit_prep), and any
+// K-element <-> (dword j, bit 4i + b) pairs with nibble i of coefficient image b of that K-step (k_coef_image), and any
 // pairing works as long as both operands use it.  Sums of +-{0.5, 1, 2} stay exact in the fp32 accumulators (below 2^24
 // in halves); the four accumulators (one per bit position) are multiplied by their widths as integers at the end: the int32 sums are
 // the int8 form's, bit for bit.  With the coefficient image half the size, the kernel is left to the HBM stream.
@@ -2965,7 +2755,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // and start over, so the ring streams through the boundary and an item has one pipeline fill, not two.
 template <int SK, int TILES, int RD, bool FUSE, bool CODE>
 __device__ __forceinline__ void
-fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ coef4, int k0, int k1, const int (&w)[4],
+fp4_segment(const unsigned char* const (&lib)[TILES], const bool (&live)[TILES], const uint4* __restrict__ coef4, int k0, int k1, const int (&w)[4],
             int lane, int wave, int (&tot)[TILES][16], int kflush, const int (&wf)[4], int (&totf)[TILES][16]) {
     extern __shared__ uint4 lds_ring[];
     constexpr int NW = 8;
@@ -3003,7 +2793,8 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
                 int lr = st * SK + k;
                 lr = lr < k1 - k0 ? lr : k1 - k0 - 1;                 // clamped: masked below
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)(COEF_ROWS * 1024 + row * LROWB));
-                if constexpr (CODE) lds_dma_12_nt(lib[t] + (long long)lr * ROWB, dst);
+                if (!live[t]) lds_dma_16(coef4 + (long long)k0 * 256 + lane, dst);       // a slot without a group: a coefficient row, hot in L2
+                else if constexpr (CODE) lds_dma_12_nt(lib[t] + (long long)lr * ROWB, dst);     // (keeps the wave's vmcnt arithmetic; never used)
                 else lds_dma_16_nt(reinterpret_cast<const uint4*>(lib[t] + (long long)lr * ROWB), dst);
             }
         };
@@ -3039,6 +2830,7 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
         if constexpr (XSTAGE) {
             wait_vmcnt_le<NDMA * (RD - 2)>();         // stage 0 has landed once at most the younger stages' DMA is outstanding
             __builtin_amdgcn_s_barrier();
+            DV_STAMP(1);
             fetch(0, IntC<0>{});
         }
         for (int st = 0; st < nst; ++st) {
@@ -3132,6 +2924,7 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const uint4* __restrict__ 
         }
         wait_vmcnt_le<0>();
         __builtin_amdgcn_s_barrier();
+        DV_STAMP(2);
     }
     // bits stood for 0.5 / 1 / 2 / (1, CODE: 0.5): signed counts 2 acc0, acc1, acc2 / 2, acc3 (CODE: 2 acc3) -- integers --
     // each times the gap width of the planes on that bit position (widths < 256, |counts| < 2^23)
@@ -3149,31 +2942,32 @@ constexpr int fp4_ring_bytes(int SK, int TILES, int RD, bool code) { (void)code;
 template <int SK, int TILES, int RD, int SKC, int RDC, bool FUSE>
 __device__ __forceinline__ void
 sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
-             int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz) {
+             int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz, int n_gq) {
     extern __shared__ uint4 lds_ring[];           // the rings of fp4_segment, then the FUSE scratch
     constexpr int NW = 8;
-    constexpr int VW = NW * TILES;
     constexpr int RING = fp4_ring_bytes(SK, TILES, RD, false) > fp4_ring_bytes(SKC, TILES, RDC, true) ? fp4_ring_bytes(SK, TILES, RD, false)
                                                                                                          : fp4_ring_bytes(SKC, TILES, RDC, true);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long G32 = c.Fpad / 32;
-    const long long GQ = (G32 + VW - 1) / VW;
+    const long long GQ = n_gq;                    // view-group ranges the library is cut into (item_groups)
     const long long n_items = GQ * nchunk;
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
     const long long gbytes = b.vcode ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
+    DV_STAMP(0);
     if constexpr (FUSE) fused_block_begin(reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING));
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / GQ);
         const long long gq = item - (long long)ch * GQ;
+        const long long g0 = (gq * G32) / GQ, g1 = ((gq + 1) * G32) / GQ;     // at most VW groups (launch_mfma)
         const unsigned char* grp[TILES];
         long long gidx[TILES];
         bool live[TILES];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            long long g = gq * VW + wave * TILES + t;
-            live[t] = g < G32;
-            if (!live[t]) g = G32 - 1;
+            long long g = g0 + wave * TILES + t;
+            live[t] = g < g1;
+            if (!live[t]) g = g0;                 // a slot without a group streams nothing (fp4_segment: one row, re-read)
             gidx[t] = g;
             grp[t] = reinterpret_cast<const unsigned char*>(ftiles) + g * gbytes;
         }
@@ -3186,14 +2980,14 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
             const unsigned char* lib[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + lane * 16;
-            fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, 0, b.NK[0] + b.NK[1], b.wacc[1], lane, wave, tot_v, b.NK[0], b.wacc[0], tot_hs);
+            fp4_segment<SK, TILES, RD, FUSE, false>(lib, live, coef4, 0, b.NK[0] + b.NK[1], b.wacc[1], lane, wave, tot_v, b.NK[0], b.wacc[0], tot_hs);
         }
         if (!merged && has_hs_sum) {
             const int k0 = (int)(((long long)ch * b.NK[0]) / nchunk), k1 = (int)(((long long)(ch + 1) * b.NK[0]) / nchunk);
             const unsigned char* lib[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)k0 * 1024 + lane * 16;
-            fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, k0, k1, b.wacc[0], lane, wave, tot_hs, -1, b.wacc[0], tot_hs);
+            fp4_segment<SK, TILES, RD, FUSE, false>(lib, live, coef4, k0, k1, b.wacc[0], lane, wave, tot_hs, -1, b.wacc[0], tot_hs);
         }
         if (!merged && c.hasv) {
             const int r0 = (int)(((long long)ch * b.NK[1]) / nchunk), r1 = (int)(((long long)(ch + 1) * b.NK[1]) / nchunk);
@@ -3201,11 +2995,11 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
             if (b.vcode) {
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)b.NK[0] * 1024 + (long long)r0 * 768 + lane * 12;
-                fp4_segment<SKC, TILES, RDC, FUSE, true>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
+                fp4_segment<SKC, TILES, RDC, FUSE, true>(lib, live, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
             } else {
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)(b.NK[0] + r0) * 1024 + lane * 16;
-                fp4_segment<SK, TILES, RD, FUSE, false>(lib, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
+                fp4_segment<SK, TILES, RD, FUSE, false>(lib, live, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
             }
         }
         if constexpr (!FUSE) {
@@ -3230,23 +3024,26 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
             unsigned long long* scratch = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING);
             auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
             auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
+            if (item == blockIdx.x) DV_STAMP(3);
             fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
+            if (item == blockIdx.x) DV_STAMP(4);
         }
     }
     if constexpr (FUSE) fused_block_end(reinterpret_cast<const unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING), fz, c, a_off);
+    DV_STAMP(5);
 }
 
-// One launch, both forms: `offlevel` (k_bit_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form
+// One launch, both forms: `offlevel` (k_patch_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form
 // reads ftiles (the code tiles when the library has them, else the bit tiles), the int8 form the bit tiles.
 template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE>
 __global__ void __launch_bounds__(512, 2)
 k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ ftiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4,
                 const unsigned* __restrict__ offlevel, int* __restrict__ part, LibCfg c, BitCfg b, int nchunk, int apad_total, int a_off,
-                int has_hs_sum, FuseArgs fz) {
+                int has_hs_sum, FuseArgs fz, int n_gq) {
     if (__builtin_amdgcn_readfirstlane(*offlevel) == 0u)
-        sad_ring_fp4<SK4, TILES, RD4, SKC, RDC, FUSE>(ftiles, coef4, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
+        sad_ring_fp4<SK4, TILES, RD4, SKC, RDC, FUSE>(ftiles, coef4, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz, n_gq);
     else
-        sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz);
+        sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz, n_gq);
 }
 
 // ------------------------------------------------------------------ error / coverage metrics of the agent

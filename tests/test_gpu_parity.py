@@ -356,6 +356,33 @@ def test_gpu_sensor_index_errors_like_the_reference():
     nsf._engine.close()
 
 
+def _check_shipped_step_at_size(eng, seed, F, h, w, A, cw, patches, r_unfused, require_form=True, plain=True):
+    """The step as it ships -- want_scene=False, no force_resolve: the matrix-core kernel in its fp4 form, scores finished
+    in its epilogue, k_fold -- against (1) the unfused step (k_finish on the partial sums) bit for bit: every per-heading
+    maximum, its view, the decision; (2) the oracle on the reported views plus a fixed spread of the library: the sample
+    contains every heading's maximiser, so the oracle's per-heading maxima, views and decision on it must be the reported
+    ones, and no sampled view may beat them."""
+    r = eng.step(patches, want_scene=False)
+    form = eng.scoring_form()
+    if require_form:
+        assert form["matrix_cores"] and form["fp4"] and form["fused_finish"], form
+    if plain:
+        assert not (r["flags"] & 1), "a planted unique best must not need the exact resolver"
+    assert np.array_equal(r["angle_familiarity"], r_unfused["angle_familiarity"])
+    assert np.array_equal(r["angle_view"], r_unfused["angle_view"])
+    assert (r["best_idex"], r["best_view"]) == (r_unfused["best_idex"], r_unfused["best_view"])
+    assert r["step_familiarity"] == r_unfused["step_familiarity"]
+    views = np.unique(np.concatenate([np.arange(0, F, max(1, F // 97)), np.asarray(r["angle_view"], dtype=np.int64)]))
+    lib = np.stack([synth.synth_views(seed, 1, h, w, first_view=int(f))[0] for f in views])
+    want = oracle.step(lib, patches, cw)
+    np.testing.assert_allclose(r["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+    for a in range(A):                       # each heading's first maximiser on the sample is the reported view
+        fam = oracle.sads_hsv(lib, patches[a], cw)
+        assert int(views[int(np.argmax(fam))]) == int(r["angle_view"][a]), a
+    assert r["best_idex"] == want["best_idex"] and r["best_view"] == int(views[want["best_view"]])
+    return r
+
+
 def test_full_size_properties():
     """BASELINE config 1 (64x64, 50k views, 16 headings) through size-independent properties."""
     F, h, w, A, seed = 50000, 64, 64, 16, 20261004
@@ -372,6 +399,7 @@ def test_full_size_properties():
         assert r["best_idex"] == 11 and r["best_view"] == 41234
         assert r["angle_view"][2] == 77
         assert r["step_familiarity"] > 0.98 * h * w
+        _check_shipped_step_at_size(eng, seed, F, h, w, A, cw, patches, r, require_form=cw > 0)
         # sampled views against the oracle (regenerated on the host from the same seed)
         for f0 in (0, 41230, F - 8):
             sub = synth.synth_views(seed, 8, h, w, first_view=f0)
@@ -415,6 +443,15 @@ def test_large_library_properties():
         sub = synth.synth_views(seed, 4, h, w, first_view=f0)
         want = oracle.step(sub, patches, cw)
         np.testing.assert_allclose(r["scene_familiarity"][f0:f0 + 4], want["scene_familiarity"], rtol=RTOL)
+    _check_shipped_step_at_size(eng, seed, F, h, w, A, cw, patches, r)
+    # fresh patches through the on-device generator (what bench.py times), same check
+    eng.generate_patches(seed + 1, A)
+    fresh = synth.synth_patches(seed + 1, A, h, w)
+    eng.step_enqueue(want_scene=False)
+    r_gen = eng.step_wait(want_scene=False)
+    r_up = eng.step(fresh, want_scene=True)
+    assert np.array_equal(r_gen["angle_familiarity"], r_up["angle_familiarity"]) and np.array_equal(r_gen["angle_view"], r_up["angle_view"])
+    _check_shipped_step_at_size(eng, seed, F, h, w, A, cw, fresh, r_up, plain=False)
     # exact value of the winner is reproduced by the resolver when forced
     r2 = eng.step(patches, want_scene=False, force_resolve=True)
     win = synth.synth_views(seed, 1, h, w, first_view=3)
@@ -981,20 +1018,21 @@ def test_fenced_and_unfenced_arrival_tickets_decide_alike(finish):
     np.testing.assert_allclose(seen["0"][0], want["angle_familiarity"], rtol=RTOL)
 
 
-@pytest.mark.parametrize("variant", ["0", "2", "3"])
-def test_matrix_core_kernel_forms_under_repetition(variant):
-    """k_sad_mfma_ring streams both operands through LDS rings with hand-counted waits; k_sad_mfma stages the library
-    bits in registers.  A race in either would show as an occasional wrong sum: 150 steps with changing patches on a
-    library with several view groups per wave and a ragged tail, every decision, per-heading maximum and per-view minimum
-    against the oracle (the integer sums are exact, so the scores must agree to the last bit from step to step)."""
+@pytest.mark.parametrize("fp4,tiles", [("1", "1"), ("0", "1"), ("1", "2"), ("0", "2")])
+def test_matrix_core_kernel_forms_under_repetition(fp4, tiles):
+    """k_sad_mfma_dual streams both operands through LDS rings with hand-counted waits (fp4 and int8 bodies, one or two
+    view groups per wave).  A race would show as an occasional wrong sum: 150 steps with changing patches on a library
+    with ragged view-group ranges (waves without a group of their own in most items), every decision, per-heading
+    maximum and per-view minimum against the oracle (the integer sums are exact, so the scores must agree to the last
+    bit from step to step)."""
     import os
     F, h, w, A, cw = 9000 + 37, 20, 12, 13, 0.25
     lib = synth.synth_views(61, F, h, w)
-    os.environ.update(DEJAVU_SHAPE="6", DEJAVU_BITS="2", DEJAVU_MFMA_VARIANT=variant)
+    os.environ.update(DEJAVU_SHAPE="6", DEJAVU_BITS="2", DEJAVU_FP4=fp4, DEJAVU_MFMA_TILES=tiles)
     try:
         e = navsim_amd.FamiliarityEngine(0)
     finally:
-        for k in ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_MFMA_VARIANT"):
+        for k in ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FP4", "DEJAVU_MFMA_TILES"):
             os.environ.pop(k, None)
     try:
         e.set_library(lib, cw)
@@ -1003,6 +1041,9 @@ def test_matrix_core_kernel_forms_under_repetition(variant):
             pats = synth.synth_patches(1000 + it % 5, A, h, w)
             pats[it % A] = synth.near_match_patch(lib[(it * 997) % F], it, fraction=0.02)
             got = e.step(pats, want_scene=True)
+            fused = e.step(pats, want_scene=False)                   # the step as the agent runs it: finished in the kernel's epilogue
+            assert np.array_equal(fused["angle_familiarity"], got["angle_familiarity"]), it
+            assert np.array_equal(fused["angle_view"], got["angle_view"]) and fused["best_idex"] == got["best_idex"], it
             if it < 15:
                 want = oracle.step(lib, pats, cw)
                 assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]), it
@@ -1052,7 +1093,7 @@ def test_ties_inside_one_finishing_block_of_several_view_sets():
 
 def _engine_with(env):
     import os
-    keys = ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FP4", "DEJAVU_FUSE", "DEJAVU_FP4_VARIANT", "DEJAVU_MFMA_TILES", "DEJAVU_VCODE")
+    keys = ("DEJAVU_SHAPE", "DEJAVU_BITS", "DEJAVU_FP4", "DEJAVU_FUSE", "DEJAVU_MFMA_TILES", "DEJAVU_VCODE")
     before = {k: os.environ.pop(k, None) for k in keys}
     os.environ.update(env)
     try:
