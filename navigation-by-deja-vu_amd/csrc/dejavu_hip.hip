@@ -1457,17 +1457,22 @@ static long long item_groups(long long G32, int VW) {
 
 // Both forms in one launch (k_sad_mfma_dual): the fp4 form when this prep's patches sit on the library's levels (the
 // device decides, offlevel_word); libraries without an fp4 form point that word at a constant 1 and pass no fp4 image.
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE>
 static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     static bool attr_set = false;
     const size_t lds8 = (size_t)RD8 * (SK8 * 8 + 8 * SK8 * TILES) * 1024;
     const size_t lds4 = (size_t)fp4_ring_bytes(SK4, TILES, RD4, false), ldsc = (size_t)fp4_ring_bytes(SKC, TILES, RDC, true);
     size_t lds = lds8 > lds4 ? lds8 : lds4;
     if (ldsc > lds) lds = ldsc;
+    if constexpr (SKL > 0) {
+        constexpr int lcb = lc_ring_bytes<SKL, RDL>();
+        static_assert(lcb + kFuseScratchBytes <= 160 * 1024, "LDS");
+        if ((size_t)lcb > lds) lds = (size_t)lcb;
+    }
     lds += FUSE ? (size_t)kFuseScratchBytes : 0;
     static_assert(fp4_ring_bytes(SKC, TILES, RDC, true) + kFuseScratchBytes <= 160 * 1024 && fp4_ring_bytes(SK4, TILES, RD4, false) + kFuseScratchBytes <= 160 * 1024, "LDS");
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long long G32 = c->cfg.Fpad / 32;
@@ -1478,18 +1483,18 @@ static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     FuseArgs fz{};
     if (FUSE) { fz = fuse_args(c); fz.nb = (int)grid; }
     for (int a_off = 0; a_off < c->APAD; a_off += 32)
-        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->bcfg.vcode ? c->d_ctiles : c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
                            c->fp4_ok ? c->d_coef4 + (size_t)(a_off / 32) * nkt * 256 : nullptr, offlevel_word(c), reinterpret_cast<int*>(c->d_part),
                            c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz, (int)n_gq);
     if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }     // one summary per workgroup
 }
 
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, int SKL = 0, int RDL = 3, bool LCODE = false>
 static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
     // One chunk and a step that may end in k_fold: the kernel finishes its scores itself.
-    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, true>(c, nchunk, has_hs);
-    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, false>(c, nchunk, has_hs);
+    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, true, SKL, RDL, LCODE>(c, nchunk, has_hs);
+    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, false, SKL, RDL, LCODE>(c, nchunk, has_hs);
 }
 
 // Work items of k_sad_mfma_dual = (chunk of K-steps, range of at most 8*TILES view groups of 32).  Two view groups per wave
@@ -1499,7 +1504,11 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     const long long G32 = c->cfg.Fpad / 32;
     // two view groups per wave once there are about 1.25 such items per CU (200 000 views x 128x128 x 32 headings, 391 items:
     // 0.432 ms with two, 0.474 ms with one; 500 000 views: two)
-    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (G32 >= 16ll * 320 ? 2 : 1);
+    // DEJAVU_LC (A/B): 0 = every wave loads and multiplies (sad_ring_fp4); 1 = loader and consumer waves, stage of 4 K-steps, ring of 3
+    // (sad_lc_fp4; ranges of 8 view groups whatever the library's size); 2 = the same with stages of 2 K-steps, ring of 5
+    static const int lc = getenv("DEJAVU_LC") ? atoi(getenv("DEJAVU_LC")) : 1;
+    const bool use_lc = lc != 0 && c->fp4_ok && !c->mfma_tiles_env;
+    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (use_lc ? 1 : (G32 >= 16ll * 320 ? 2 : 1));
     const long long GQ = item_groups(G32, 8 * tiles);
     int nchunk = 1;
     if (c->mfma_chunk_env) {
@@ -1518,7 +1527,10 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
     // x 64x64 x 16 headings <4, 2> 46.7 us; fp4 <2, 3> 0.95 ms and <2, 4> 34.5 us.
     static const int ring = getenv("DEJAVU_RING") ? atoi(getenv("DEJAVU_RING")) : 0;                // A/B of ring shapes
-    if (tiles == 2) launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs);
+    if (use_lc && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, true>(c, nchunk, has_hs);
+    else if (use_lc && lc == 2) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 2, 5>(c, nchunk, has_hs);
+    else if (use_lc) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3>(c, nchunk, has_hs);
+    else if (tiles == 2) launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs);
     else if (ring == 1) launch_mfma_dual<4, 2, 2, 6, 2, 6, 1>(c, nchunk, has_hs);
     else if (ring == 2) launch_mfma_dual<4, 2, 4, 3, 4, 3, 1>(c, nchunk, has_hs);
     else launch_mfma_dual<4, 2, 2, 4, 2, 4, 1>(c, nchunk, has_hs);

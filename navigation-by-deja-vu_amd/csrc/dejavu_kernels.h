@@ -2347,8 +2347,16 @@ constexpr int kFuseScratchBytes = (kFuseBlk + 2 * 32) * 8;
 template <int TILES, int NW, typename HsOf, typename VOf>
 __device__ __forceinline__ void
 fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&live)[TILES],
-             unsigned long long* scratch, const LibCfg& c, const FuseArgs& fz, int a_off, int has_hs_sum, long long gq, int lane, int wave) {
+             unsigned long long* scratch, const LibCfg& c, const FuseArgs& fz, int a_off, int has_hs_sum, long long gq, int lane, int wave,
+             int n_entry_waves = NW, bool idle = false) {
     static_assert(NW == 8, "scratch layout");
+    // Waves that hold no sums (the loader waves of sad_lc_fp4) only keep the five barriers: raw ones, so that nothing waits
+    // for the LDS-DMA they have in flight for the next item.  Waves [0, n_entry_waves) hold the entries.
+    if (idle) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) __builtin_amdgcn_s_barrier();
+        return;
+    }
     unsigned long long* sum_sc = scratch;                      // [NW][32] bits of the (non-negative) sc: bit order = value order
     unsigned long long* sum_view = sum_sc + NW * 32;
     unsigned long long* item_view = sum_view + NW * 32;        // [32]
@@ -2449,7 +2457,7 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     if (threadIdx.x < 32) {                                    // thread n: the item's summary of heading a_off + n
         unsigned long long is = kNone, iv = ~0ull;
         if (valid) {
-            for (int i = 0; i < NW; ++i) {
+            for (int i = 0; i < n_entry_waves; ++i) {
                 const unsigned long long k = sum_sc[i * 32 + n], w = sum_view[i * 32 + n];
                 if (k < is || (k == is && w < iv)) { is = k; iv = w; }
             }
@@ -3033,17 +3041,286 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
     DV_STAMP(5);
 }
 
+// ------------------------------------------------------------------ fp4 body with loader and consumer waves
+// The ring loop above makes every wave do everything: issue its LDS-DMA (an M0 dance and ~100 cycles of issue each), wait on
+// vmcnt, read operands from LDS, mask, multiply.  tools/exp/stamps.py shows what that costs: a workgroup takes ~300 ns per
+// K-step whatever the bytes it moves (50 000 views x 64x64: 28.7 us of ring loop for 8 view groups, 30.3 for 6-7; deeper rings
+// and the 3-bit code rows change nothing), 2.4x the matrix pipe's time -- the loop is bound by its own instruction stream.
+// Here the roles are split.  Waves 0-3, one per SIMD, are CONSUMERS: two view groups each (so every coefficient row read from
+// LDS serves two tiles and the workgroup reads each row four times, not eight), no vector-memory instruction in the loop, only
+// ds_read_b128 one K-step ahead, the masks and the MFMAs.  Waves 4-7, their partners on the SIMDs, are LOADERS: all LDS-DMA
+// of a stage (SK K-steps: 4 coefficient rows + 8 library rows each) split four ways, counted vmcnt waits, and ONE s_barrier
+// per stage that publishes stage st and frees the slot of stage st - 1 (the consumers take it in front of their last K-step
+// of stage st - 1, whose operands are in registers by then, and fetch the first operands of stage st behind it).
+// The loaders number stages through ALL items of the workgroup: while the consumers finish an item (fused_finish, in which
+// the loaders only keep the barriers), the first RD - 1 stages of the next item are already in flight -- no pipeline fill
+// per item.  Past the workgroup's last item the loaders issue re-reads of a coefficient row (hot in L2) so that the counted
+// waits stay uniform.  One range of K-steps [0, NKT) with the accumulators flushed at the segment boundary (kflush), so one
+// chunk only; K chunks and the int8 form keep the loop above.
+template <int SK, int RD>
+constexpr int lc_ring_bytes() { return RD * SK * 12 * 1024; }
+
+template <int SK, int RD, bool FUSE, bool CODE>
+__device__ __forceinline__ void
+sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
+           int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz, int n_gq) {
+    extern __shared__ uint4 lds_ring[];
+    constexpr int TILES = 2, NW = 8, NC = 4, NL = 4;
+    constexpr int COEF_ROWS = SK * 4, LIB_ROWS = SK * NC * TILES, ROWS = COEF_ROWS + LIB_ROWS;
+    constexpr int SLOTB = ROWS * 1024;
+    constexpr int PER = ROWS / NL;                                    // LDS-DMA instructions per loader wave and stage
+    constexpr int RING = RD * SLOTB;
+    static_assert(PER == 3 * SK && PER * (RD - 1) < 64 && SK % 2 == 0 && RD >= 3, "ring shape");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= NC;
+    const long long G32 = c.Fpad / 32, GQ = n_gq;
+    const int NKT = b.NK[0] + b.NK[1];
+    const int nst = (NKT + SK - 1) / SK;
+    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
+    // code tiles (k_bitpack_code): the V rows are 768 bytes (3-bit level codes), moved by global_load_lds_dwordx3 -- every lane's
+    // 12 bytes land 16 apart in LDS, so a row is read back like any other -- and decoded in registers by the consumers
+    constexpr bool codev = CODE;                                      // == (b.vcode != 0): the host picks the instantiation
+    const int NK0 = b.NK[0];
+    const long long gbytes = codev ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
+    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING);
+    const unsigned char* lib_bytes = reinterpret_cast<const unsigned char*>(ftiles);
+    DV_STAMP(0);
+    if constexpr (FUSE) fused_block_begin(scratch);
+    const long long n_mine = GQ > (long long)blockIdx.x ? (GQ - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;       // items of this workgroup
+
+    // ---- loader state: the stage it issues next, (li, lst) = (item of this workgroup, stage), into ring slot lslot
+    const int lw = wave - NC;
+    long long li = 0;
+    int lst = 0, lslot = 0;
+    const unsigned char* lp[2] = {lib_bytes, lib_bytes};              // this lane's place in row 0 of the loader's two view groups
+    const unsigned char* lpv[2] = {lib_bytes, lib_bytes};             // and in their first V row when those are code rows
+    bool llive[2] = {false, false};
+    auto loader_item = [&]() {                                          // (re)aim at item li
+        llive[0] = llive[1] = false;
+        if (li < n_mine) {
+            const long long item = blockIdx.x + li * gridDim.x;
+            const long long g0 = (item * G32) / GQ, g1 = ((item + 1) * G32) / GQ;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long g = g0 + lw + 4 * h;                    // slot lw + 4 h of the item's eight: consumer (lw + 4 h) / 2, tile (lw + 4 h) % 2
+                llive[h] = g < g1;
+                lp[h] = lib_bytes + (llive[h] ? g : g0) * gbytes + lane * 16;
+                lpv[h] = lib_bytes + (llive[h] ? g : g0) * gbytes + (long long)NK0 * 1024 + lane * 12;
+            }
+        }
+    };
+    auto issue_stage = [&]() {
+        const unsigned slot = lds_base + (unsigned)lslot * (unsigned)SLOTB;
+        const int kb = lst * SK;
+        const uint4* hot = coef4 + lw * 64 + lane;                      // re-read where there is nothing to fetch (hot in L2)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (i < SK) {                                               // coefficient row (K-step kb + i, bit position lw)
+                int k = kb + i;
+                k = k < NKT ? k : NKT - 1;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((i * 4 + lw) * 1024));
+                lds_dma_16(li < n_mine ? coef4 + ((long long)k * 4 + lw) * 64 + lane : hot, dst);
+            } else {                                                    // library row (K-step kb + kk, slot lw + 4 h)
+                const int kk = (i - SK) >> 1, h = (i - SK) & 1;
+                int k = kb + kk;
+                k = k < NKT ? k : NKT - 1;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + kk * 8 + lw + 4 * h) * 1024));
+                if (!llive[h]) lds_dma_16(hot, dst);
+                else if (codev && k >= NK0) lds_dma_12_nt(lpv[h] + (long long)(k - NK0) * 768, dst);
+                else lds_dma_16_nt(reinterpret_cast<const uint4*>(lp[h] + (long long)k * 1024), dst);
+            }
+        }
+        lslot = lslot + 1 == RD ? 0 : lslot + 1;
+        if (++lst == nst) { lst = 0; ++li; loader_item(); }
+    };
+    if (loader) {
+        loader_item();
+#pragma unroll
+        for (int r = 0; r < RD - 1; ++r) issue_stage();
+    }
+
+    int cslot = 0;                                                      // ring slot of the consumers' current stage
+    for (long long j = 0; j < n_mine; ++j) {
+        const long long item = blockIdx.x + j * gridDim.x;
+        const long long g0 = (item * G32) / GQ, g1 = ((item + 1) * G32) / GQ;
+        long long gidx[TILES];
+        bool live[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const long long g = g0 + wave * TILES + t;
+            live[t] = !loader && g < g1;
+            gidx[t] = live[t] ? g : g0;
+        }
+        int tot_hs[TILES][16], tot_v[TILES][16];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot_hs[t][r] = 0; tot_v[t][r] = 0; }
+        if (loader) {
+            for (int st = 0; st < nst; ++st) {
+                wait_vmcnt_le<PER * (RD - 2)>();                        // this wave's rows of stage (j, st) have landed ...
+                __builtin_amdgcn_s_barrier();                           // ... everybody's have; nobody still reads the slot before it
+                issue_stage();                                          // (may belong to the next item: its pipeline fill)
+            }
+        } else {
+            v16f_t acc[TILES][4];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
+            constexpr int READS = 4 + TILES;
+            v4u_t a[2][4], xl[2][TILES];
+            auto fetch = [&](int slot_i, auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const unsigned sad = lds_base + (unsigned)slot_i * (unsigned)SLOTB + (unsigned)lane * 16u;
+                const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * TILES * 1024);
+                static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * 4 + s_) * 1024>(a[k & 1][s_], sad); });
+                static_for<TILES>([&](auto tc) { constexpr int t_ = decltype(tc)::value; lds_read16<(k * 8 + t_) * 1024>(xl[k & 1][t_], lad); });
+            };
+            // bits stood for 0.5 / 1 / 2 / 1 (code rows: 0.5): signed counts 2 acc0, acc1, acc2 / 2, acc3 (code rows: 2 acc3) -- integers
+            auto flush = [&](int (&dst)[TILES][16], const int (&wd)[4], bool code) {
+                const float f3 = code ? 2.f : 1.f;
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dst[t][r] = __mul24(wd[0], (int)(2.f * acc[t][0][r])) + __mul24(wd[1], (int)acc[t][1][r]) + __mul24(wd[2], (int)(0.5f * acc[t][2][r])) +
+                                    __mul24(wd[3], (int)(f3 * acc[t][3][r]));
+            };
+            __builtin_amdgcn_s_barrier();                               // stage (j, 0) is in LDS
+            if (j == 0) DV_STAMP(1);
+            fetch(cslot, IntC<0>{});
+            // stages [s0, s1) of one kind: thermometer rows, or (codeC) the 3-bit code rows of the V segment
+            auto run_stages = [&](int s0, int s1, auto codeC) {
+                constexpr bool code_stage = decltype(codeC)::value;
+                for (int st = s0; st < s1; ++st) {
+                    const int kb = st * SK;
+                    const int nslot = cslot + 1 == RD ? 0 : cslot + 1;
+                    static_for<SK>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (k + 1 < SK) {
+                            fetch(cslot, IntC<k + 1>{});                // one K-step ahead
+                            lds_wait<READS>();                          // all but the newest READS reads have landed: K-step k's
+                        } else {
+                            lds_wait<0>();                              // everything this wave will use of the slot is in registers
+                            if (st + 1 < nst) {
+                                __builtin_amdgcn_s_barrier();           // stage st + 1 is in LDS; the loaders may refill slot st - 1 ... and,
+                                fetch(nslot, IntC<0>{});                //   one barrier later, this one
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) lds_tie(a[k & 1][s]);
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) lds_tie(xl[k & 1][t]);
+                        const bool on = kb + k < NKT;
+                        auto mfma = [&](int t, int s, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+                            const v8i_t bo = v8i_t{(int)b0, (int)b1, (int)b2, (int)b3, 0, 0, 0, 0};
+                            const v4u_t& av = a[k & 1][s];
+                            const v8i_t ao = v8i_t{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+                            if constexpr (FUSE) acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bo, ao, acc[t][s], 4, 4, 0, 0, 0, 0);   // views x headings
+                            else acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[t][s], 4, 4, 0, 0, 0, 0);
+                        };
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            unsigned x[4] = {xl[k & 1][t].x, xl[k & 1][t].y, xl[k & 1][t].z, xl[k & 1][t].w};
+                            if constexpr (!code_stage) {
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) {
+                                    // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
+                                    const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
+                                    const int sh = s < 3 ? 0 : 2;
+                                    mfma(t, s, (x[0] >> sh) & m, (x[1] >> sh) & m, (x[2] >> sh) & m, (x[3] >> sh) & m);
+                                }
+                            } else {
+                                const unsigned m1 = 0x11111111u;
+                                const unsigned m = on ? m1 : 0u;
+                                // the fourth dword's pixels: bit 3 of the three code dwords' nibbles (the LDS-DMA left a hole there)
+                                x[3] = ((x[0] >> 3) & m1) | ((x[1] >> 2) & (m1 << 1)) | ((x[2] >> 1) & (m1 << 2));
+                                // E2M1 operands of the four thermometer planes: t1, t4 as 0.5 (bit 0), t2 as 1 (bit 1), t3 as 2 (bit 2)
+                                mfma(t, 0, (x[0] | (x[0] >> 1)) & m, (x[1] | (x[1] >> 1)) & m, (x[2] | (x[2] >> 1)) & m, (x[3] | (x[3] >> 1)) & m);
+                                mfma(t, 1, x[0] & (m << 1), x[1] & (m << 1), x[2] & (m << 1), x[3] & (m << 1));
+                                mfma(t, 2, x[0] & (m << 2), x[1] & (m << 2), x[2] & (m << 2), x[3] & (m << 2));
+                                mfma(t, 3, x[0] & (x[0] >> 2) & m, x[1] & (x[1] >> 2) & m, x[2] & (x[2] >> 2) & m, x[3] & (x[3] >> 2) & m);
+                            }
+                        }
+                    });
+                    cslot = nslot;
+                }
+            };
+            // HS stages (when the library has that segment), then the V stages; the accumulators change hands at the boundary
+            const int nst0 = has_hs_sum ? (NK0 / SK < nst ? NK0 / SK : nst) : 0;       // (NK0 is a whole number of stages; no V K-steps: all of them)
+            const int hs_end = (has_hs_sum && !(c.hasv && b.NK[1] > 0)) ? nst : nst0;
+            run_stages(0, hs_end, IntC<0>{});
+            if (hs_end > 0 && hs_end < nst) {
+                flush(tot_hs, b.wacc[0], false);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
+            }
+            if constexpr (CODE) run_stages(hs_end, nst, IntC<1>{});
+            else run_stages(hs_end, nst, IntC<0>{});
+            if (hs_end < nst) flush(tot_v, b.wacc[1], codev);           // what the accumulators hold at the end: the V segment's sums,
+            else flush(tot_hs, b.wacc[0], false);                       // unless there are no V K-steps
+        }
+        if (j == 0) DV_STAMP(2);
+        if constexpr (!FUSE) {
+            const int nsum = has_hs_sum + c.hasv;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                if (live[t]) {
+#pragma unroll
+                    for (int seg = 0; seg < 2; ++seg) {
+                        if (seg == 0 ? !has_hs_sum : !c.hasv) continue;
+                        const int type_row = seg ? has_hs_sum : 0;
+                        int* dst = part + ((long long)type_row * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+                        (void)nsum;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            if (m < rows) dst[(long long)m * c.Fpad] = seg ? tot_v[t][r] : tot_hs[t][r];
+                        }
+                    }
+                }
+            }
+        } else {
+            auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
+            auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
+            if (j == 0) DV_STAMP(3);
+            fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, j, lane, wave, NC, loader);
+            if (j == 0) DV_STAMP(4);
+        }
+    }
+    if (loader) wait_vmcnt_le<0>();                                     // the re-reads past the last item
+    if constexpr (FUSE) fused_block_end(scratch, fz, c, a_off);
+    DV_STAMP(5);
+}
+
 // One launch, both forms: `offlevel` (k_patch_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form
 // reads ftiles (the code tiles when the library has them, else the bit tiles), the int8 form the bit tiles.
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE>
 __global__ void __launch_bounds__(512, 2)
 k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ ftiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4,
                 const unsigned* __restrict__ offlevel, int* __restrict__ part, LibCfg c, BitCfg b, int nchunk, int apad_total, int a_off,
                 int has_hs_sum, FuseArgs fz, int n_gq) {
-    if (__builtin_amdgcn_readfirstlane(*offlevel) == 0u)
+    if (__builtin_amdgcn_readfirstlane(*offlevel) == 0u) {
+        if constexpr (SKL > 0) {
+            static_assert(TILES == 1, "the loader / consumer body cuts the library into ranges of 8 view groups, like one group per wave");
+            if (nchunk == 1) {
+                sad_lc_fp4<SKL, RDL, FUSE, LCODE>(ftiles, coef4, part, c, b, apad_total, a_off, has_hs_sum, fz, n_gq);     // LCODE == (b.vcode != 0)
+                return;
+            }
+        }
         sad_ring_fp4<SK4, TILES, RD4, SKC, RDC, FUSE>(ftiles, coef4, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz, n_gq);
-    else
+    } else {
         sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz, n_gq);
+    }
 }
 
 // ------------------------------------------------------------------ error / coverage metrics of the agent

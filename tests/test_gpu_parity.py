@@ -1106,7 +1106,8 @@ def _engine_with(env):
 
 
 @pytest.mark.parametrize("F,h,w,A,cw,tiles", [(5000, 32, 32, 32, 0.5, "0"), (3001, 20, 24, 7, 0.3, "2"), (9037, 16, 16, 64, 0.5, "0"),
-                                               (4100, 32, 32, 16, 0.0, "2"), (2500, 12, 20, 33, 1.0, "0")])
+                                               (4100, 32, 32, 16, 0.0, "2"), (2500, 12, 20, 33, 1.0, "0"),
+                                               (70001, 16, 16, 32, 0.25, "0"), (41000, 8, 24, 9, 0.0, "0")])
 def test_fp4_form_gives_the_int8_forms_sums(F, h, w, A, cw, tiles):
     """The fp4 form of the matrix-core kernel (on-level patches, one gap width per nibble bit) must leave the very
     integer sums of the int8 form: scores, per-heading maxima and decisions identical to the last bit, with the
