@@ -123,9 +123,13 @@ def cpu_baseline(h, w, A, cw, seed, budget_views):
 
 def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
     """One GPU's share of BASELINE.json configs[4] (256 agents on 8 GPUs, 100k views replicated): n_agents agents x A
-    headings per ensemble step through dv_step_batch, patches uploaded every step; one planted answer is checked."""
+    headings per ensemble step against n_views views.  Two forms: `sensed` -- the agents' patches are sensed on the device
+    from the resident landscape (dv_sense_step_batch: nothing but poses goes up), the form an ensemble run uses -- and
+    `uploaded` -- patches handed over as host buffers every step (dv_step_batch, PCIe-inclusive); one planted answer is
+    checked there."""
     import navsim_amd
     from navsim_amd import synth
+    out = {}
     eng = navsim_amd.FamiliarityEngine(0)
     try:
         eng.generate_library(seed, n_views, h, w, chem_weight=cw)
@@ -138,11 +142,47 @@ def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
         for _ in range(n_steps):
             eng.step_batch(patches)
         dt = (time.perf_counter() - t0) / n_steps
+        out["uploaded"] = dict(view_comparisons_per_s=n_agents * A * n_views / dt, ms_per_ensemble_step=dt * 1e3,
+                               what="dv_step_batch, %d bytes of patches uploaded each step" % patches.nbytes)
     finally:
         eng.close()
-    return dict(view_comparisons_per_s=n_agents * A * n_views / dt, agent_steps_per_s=n_agents / dt, ms_per_ensemble_step=dt * 1e3,
-                what="%d agents x %d headings against %d views (%dx%d), dv_step_batch, patches uploaded each step: one "
-                     "GPU's share of BASELINE.json configs[4]" % (n_agents, A, n_views, w, h))
+    # sensed: a trained agent's engine (landscape + library of n_views sensed views resident), the ensemble's poses spread along the path
+    L = 2000
+    land = synth.synth_landscape(seed, L, 4)
+    path = synth.sin_training_path(0.5, 0.2 * L, 0.6 * L, arclen=0.6 * L * 1.4 / n_views)[:n_views]
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (w, h), 0.5, n_test_angles=A, n_sensor_levels=5,
+                                           familiarity_model=navsim_amd.sads_familiarity(cw), track_scene_familiarity=False)
+    nsf.train_from_path(path)
+    try:
+        idx = np.linspace(5, len(path) - 50, n_agents).astype(int)
+        xs, ys, angs = [], [], []
+        for i in idx:
+            dd = path[i + 1] - path[i]
+            nsf.position = tuple(path[i] + np.array([1.0, -1.0]))
+            nsf.angle = float(np.arctan2(dd[1], dd[0]) % (2 * np.pi))
+            x, y, a = nsf.headings_to_test()
+            xs.append(x); ys.append(y); angs.append(a)
+        angs = np.stack(angs)
+        e2 = nsf._engine
+        info = e2.library_info()
+        planes = (info["bit_planes_hs"] + info["bit_planes_v"]) if info["has_bit_planes"] else 0
+        for _ in range(3):
+            e2.sense_step_batch(xs, ys, angs)
+        t0 = time.perf_counter()
+        for _ in range(2 * n_steps):
+            e2.sense_step_batch(xs, ys, angs)
+        dt = (time.perf_counter() - t0) / (2 * n_steps)
+        out["sensed"] = dict(view_comparisons_per_s=n_agents * A * len(path) / dt, ms_per_ensemble_step=dt * 1e3, library_views=len(path),
+                             what="dv_sense_step_batch: patches sensed on the device, poses only go up")
+    finally:
+        nsf.clear_training()
+    best = out["sensed"]
+    k_elems = float(planes) * h * w                                # K-elements per (view, heading): bit planes x pixels of the sensed library
+    return dict(view_comparisons_per_s=best["view_comparisons_per_s"], agent_steps_per_s=n_agents / (best["ms_per_ensemble_step"] * 1e-3),
+                ms_per_ensemble_step=best["ms_per_ensemble_step"], sensed=out["sensed"], uploaded=out["uploaded"],
+                mfma_frac_of_fp4_peak=2.0 * best["view_comparisons_per_s"] * k_elems / 1e12 / FP4_MFMA_PEAK_TOPS,
+                what="%d agents x %d headings against %d views (%dx%d): one GPU's share of BASELINE.json configs[4]; headline = "
+                     "the sensed form; mfma_frac = 2 x comparisons x bit planes (%d) x pixels / s over the dense fp4 peak" % (n_agents, A, n_views, w, h, planes))
 
 
 def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):

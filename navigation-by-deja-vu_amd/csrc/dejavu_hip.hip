@@ -139,7 +139,7 @@ struct dv_ctx {
     // fp4 form of the matrix-core kernel (sad_ring_fp4): possible when every plane of a segment has one gap width
     bool fp4_ok = false;                      // this library's planes qualify (build_bit_planes)
     int fp4_env = 1;                          // DEJAVU_FP4=0: never
-    uint4* d_coef4 = nullptr;                 // [pass][K-step][4][64] E2M1 sign images (k_coef_image)
+    uint4* d_coef4 = nullptr;                 // [pass][K-step][4][64] E2M1 sign images (k_patch_prep)
     uint4* d_ctiles = nullptr;                // [Fpad/32][GSC][64] code tiles (k_bitpack_code), when bcfg.vcode
     size_t ctile_bytes = 0;
     // DEJAVU_VCODE=1: the fp4 form reads five-level value planes as 3-bit codes (k_bitpack_code: a third copy of the library, 5
@@ -521,6 +521,13 @@ static int build_bit_planes(dv_ctx* c) {
     // byte add up to |a - l_0|) and the bytes that have fp4 coefficients -- on a level, or outside the library's range
     PrepBits pb{};
     pb.enabled = 1;
+    pb.fp4 = c->fp4_ok ? 1 : 0;
+    for (int seg = 0; seg < 2; ++seg) { pb.T[seg] = b.T[seg]; pb.NK[seg] = b.NK[seg]; }
+    for (int k = 0; k < kMaxBitPlanes; ++k)
+        pb.tbl[k] = (unsigned)b.pl[k] | ((unsigned)b.lo[k] << 8) | ((unsigned)b.w[k] << 16) | ((unsigned)b.wfull[k] << 24);
+    // (the images' entries past a segment's last pixel are never written by k_patch_prep: zero for good)
+    HIP_TRY(c, hipMemsetAsync(c->d_coef, 0, (size_t)2 * nkt * 8192, c->stream));
+    if (c->fp4_ok) HIP_TRY(c, hipMemsetAsync(c->d_coef4, 0, (size_t)2 * nkt * 4096, c->stream));
     for (int bp = 0; bp < g.npl; ++bp) {
         pb.lmin[bp] = b.lmin[bp];
         for (int v = 0; v < 256; ++v) {
@@ -560,22 +567,12 @@ static int build_bit_planes(dv_ctx* c) {
 }
 
 // Coefficient image + constants of the resident patches (raw bytes in d_raw_patches), when the MFMA path may score them.
-static bool mfma_path_possible(const dv_ctx* c);
 static const unsigned* offlevel_word(const dv_ctx* c) {                 // the scoring kernel's form switch for the resident patches
     return c->fp4_ok ? &c->d_acc[c->acc_parity].off : c->d_one;
 }
-static int enqueue_bit_prep(dv_ctx* c, bool force = false) {
-    c->coef_ready = false;
-    if (!c->bits_ok || !(force || mfma_path_possible(c))) return DV_OK;
-    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
-    const int npass = c->APAD > 32 ? 2 : 1;
-    // one block per (pass, K-step) of the fp4 image and two of the int8 image; the blocks of the image that will not be
-    // read return at once (k_coef_image)
-    const unsigned blocks = (unsigned)(nkt * npass * (c->fp4_ok ? 3 : 2));
-    hipLaunchKernelGGL(k_coef_image, dim3(blocks), dim3(256), 0, c->stream, c->d_prep, c->d_coef, c->fp4_ok ? c->d_coef4 : nullptr,
-                       offlevel_word(c), c->cfg, c->bcfg, c->A, c->APAD, npass);
-    HIP_TRY(c, hipGetLastError());
-    c->coef_ready = true;
+static int enqueue_bit_prep(dv_ctx* c, bool force = false) {             // (the images are written by k_patch_prep whenever the library has bit planes)
+    (void)force;
+    c->coef_ready = c->bits_ok;
     return DV_OK;
 }
 
@@ -1011,20 +1008,21 @@ static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_ag
     c->acc_parity ^= 1;
     PrepAcc* cur = c->d_acc + c->acc_parity;
     PrepAcc* nxt = c->d_acc + (c->acc_parity ^ 1);
-    // (prep entries of the padded headings A..APAD-1 are left as they are: their sums are never read)
-    const long long total = (long long)A * c->cfg.Q * 4;
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    // (prep entries and image columns of the padded headings A..APAD-1 are left as they are: their sums are never read)
+    const dim3 grid((unsigned)(A * ((c->cfg.P + 255) / 256))), block(256);      // one block per (heading, 256 pixels)
     static const PoseSet no_poses{};
     const PrepBits pb = c->bits_ok ? c->pbits : PrepBits{};
+    uint4* i8 = c->bits_ok ? c->d_coef : nullptr;
+    uint4* i4 = (c->bits_ok && c->fp4_ok) ? c->d_coef4 : nullptr;
     if (mode == 1)
         hipLaunchKernelGGL(k_patch_prep<1>, grid, block, 0, c->stream, c->d_land, *poses, A, c->sensor, c->d_lut, c->d_raw_patches, c->d_prep,
-                           c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull);
+                           c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4);
     else if (mode == 2)
         hipLaunchKernelGGL(k_patch_prep<2>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
-                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, seed);
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, seed, i8, i4);
     else
         hipLaunchKernelGGL(k_patch_prep<0>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
-                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull);
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4);
     HIP_TRY(c, hipGetLastError());
     c->patches_sensed = mode == 1;     // no host synchronisation here: the step's result record carries the sensor's error flag
     return enqueue_bit_prep(c);
@@ -1418,16 +1416,6 @@ static void launch_generic_apad(dv_ctx* c) {
     else launch_generic<HAS_HS, HASV, 32, 64>(c);
 }
 
-// May the next integer scoring pass of the resident heading class go through k_sad_mfma?  (Decides whether the
-// per-step coefficient image is worth preparing.)
-static bool mfma_path_possible(const dv_ctx* c) {
-    if (!c->bits_ok || c->metric != 0) return false;
-    if (c->force_shape) return c->force_shape == 6;
-    if (c->shape_env) return c->shape_env == 6;
-    const int t = c->tuned_shape[apad_class(c->APAD)];
-    return t == 0 || t == 6;
-}
-
 static FuseArgs fuse_args(const dv_ctx* c) {
     FuseArgs fz{};
     fz.hsconst = c->d_acc[c->acc_parity].bhs;
@@ -1457,7 +1445,7 @@ static long long item_groups(long long G32, int VW) {
 
 // Both forms in one launch (k_sad_mfma_dual): the fp4 form when this prep's patches sit on the library's levels (the
 // device decides, offlevel_word); libraries without an fp4 form point that word at a constant 1 and pass no fp4 image.
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE, int HT>
 static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     static bool attr_set = false;
     const size_t lds8 = (size_t)RD8 * (SK8 * 8 + 8 * SK8 * TILES) * 1024;
@@ -1466,35 +1454,35 @@ static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     if (ldsc > lds) lds = ldsc;
     if constexpr (SKL > 0) {
         constexpr int lcb = lc_ring_bytes<SKL, RDL>();
-        static_assert(lcb + kFuseScratchBytes <= 160 * 1024, "LDS");
+        static_assert(lcb + kFuseScratchBytes + (HT - 1) * 512 <= 160 * 1024, "LDS");
         if ((size_t)lcb > lds) lds = (size_t)lcb;
     }
-    lds += FUSE ? (size_t)kFuseScratchBytes : 0;
+    lds += FUSE ? (size_t)kFuseScratchBytes + (HT - 1) * 512 : 0;     // (a second heading tile adds its 64 running-summary words)
     static_assert(fp4_ring_bytes(SKC, TILES, RDC, true) + kFuseScratchBytes <= 160 * 1024 && fp4_ring_bytes(SK4, TILES, RD4, false) + kFuseScratchBytes <= 160 * 1024, "LDS");
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long long G32 = c->cfg.Fpad / 32;
-    const long long n_gq = item_groups(G32, 8 * TILES);
+    const long long n_gq = item_groups(G32, 8 * TILES / HT);
     const long long items = n_gq * nchunk;
     const unsigned grid = (unsigned)(items < 256 ? items : 256);          // one 8-wave workgroup per CU, grid-stride
     const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
     FuseArgs fz{};
     if (FUSE) { fz = fuse_args(c); fz.nb = (int)grid; }
-    for (int a_off = 0; a_off < c->APAD; a_off += 32)
-        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+    for (int a_off = 0; a_off < c->APAD; a_off += 32 * HT)
+        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE, HT>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->bcfg.vcode ? c->d_ctiles : c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
                            c->fp4_ok ? c->d_coef4 + (size_t)(a_off / 32) * nkt * 256 : nullptr, offlevel_word(c), reinterpret_cast<int*>(c->d_part),
                            c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz, (int)n_gq);
     if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }     // one summary per workgroup
 }
 
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, int SKL = 0, int RDL = 3, bool LCODE = false>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, int SKL = 0, int RDL = 3, bool LCODE = false, int HT = 1>
 static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
     // One chunk and a step that may end in k_fold: the kernel finishes its scores itself.
-    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, true, SKL, RDL, LCODE>(c, nchunk, has_hs);
-    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, false, SKL, RDL, LCODE>(c, nchunk, has_hs);
+    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, true, SKL, RDL, LCODE, HT>(c, nchunk, has_hs);
+    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, false, SKL, RDL, LCODE, HT>(c, nchunk, has_hs);
 }
 
 // Work items of k_sad_mfma_dual = (chunk of K-steps, range of at most 8*TILES view groups of 32).  Two view groups per wave
@@ -1509,7 +1497,10 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     static const int lc = getenv("DEJAVU_LC") ? atoi(getenv("DEJAVU_LC")) : 1;
     const bool use_lc = lc != 0 && c->fp4_ok && !c->mfma_tiles_env;
     int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (use_lc ? 1 : (G32 >= 16ll * 320 ? 2 : 1));
-    const long long GQ = item_groups(G32, 8 * tiles);
+    // DEJAVU_HT=1 (A/B): 64 resident headings as two passes over the library instead of two heading tiles per view group in one
+    static const int ht_env = getenv("DEJAVU_HT") ? atoi(getenv("DEJAVU_HT")) : 2;
+    const bool two_tiles = use_lc && c->APAD == 64 && ht_env == 2;
+    const long long GQ = item_groups(G32, two_tiles ? 4 : 8 * tiles);
     int nchunk = 1;
     if (c->mfma_chunk_env) {
         nchunk = c->mfma_chunk_env;
@@ -1527,7 +1518,9 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
     // x 64x64 x 16 headings <4, 2> 46.7 us; fp4 <2, 3> 0.95 ms and <2, 4> 34.5 us.
     static const int ring = getenv("DEJAVU_RING") ? atoi(getenv("DEJAVU_RING")) : 0;                // A/B of ring shapes
-    if (use_lc && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, true>(c, nchunk, has_hs);
+    if (two_tiles && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, true, 2>(c, nchunk, has_hs);
+    else if (two_tiles) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, false, 2>(c, nchunk, has_hs);
+    else if (use_lc && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, true>(c, nchunk, has_hs);
     else if (use_lc && lc == 2) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 2, 5>(c, nchunk, has_hs);
     else if (use_lc) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3>(c, nchunk, has_hs);
     else if (tiles == 2) launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs);

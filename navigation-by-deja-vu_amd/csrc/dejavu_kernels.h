@@ -1552,8 +1552,8 @@ __global__ void k_decide(const StepState* __restrict__ st, const unsigned long l
 // navsim/util.pyx:171-184 (`ssds`, dead code there): sum over i,j of (a[i,j]-b[i,j])**2, double, row-major, sequential.
 // Layout: ftiles[g][q][lane] = 4 consecutive pixels (float4) of view g*64+lane, pixels zero padded to a multiple of 4
 // (a padded pixel is 0 in both operands and adds nothing); fprep[q][j][APAD] = patch pixel 4q+j of each heading.
-// Accumulation: fp32 fma over 16 pixels, then into a double (keeps the result within ~2e-7 relative of the
-// reference's all-double sum; near-ties are re-scored exactly by k_resolve_f32).  Scores are stored NEGATED
+// Accumulation: fp32 fma over runs of 8 pixels, each run then added into a double (keeps the result within 1e-6 relative of
+// the reference's all-double sum, typically 1e-7; near-ties are re-scored exactly by k_resolve_f32).  Scores are stored NEGATED
 // (fam = -ssd) so that the max-based reductions of k_combine_f32 / k_tail apply unchanged: most familiar = least SSD.
 __global__ void k_retile_f32(const float* __restrict__ raw, float4* __restrict__ ftiles, LibCfg c) {
     const long long total = (c.Fpad / 64) * (long long)c.Q * 64;       // c.Q = ceil(P/4) for this metric
@@ -1620,9 +1620,12 @@ k_ssd_tiles(const float4* __restrict__ ftiles, const float* __restrict__ fprep, 
             const int qb = blk * 4;
             if (PF) load_block(blk + NW < b1 ? blk + NW : blk, nxt);  // the next block's tiles, in flight while this one is scored
             else load_block(blk, cur);
-            float run[APAD];
+            // two fp32 runs of 8 pixels each per block (chunks 0, 1 and 2, 3), each added into the double on its own: a run's
+            // rounding error is bounded by 8 fp32 roundings of its partial sums (< 5e-7 relative, typically 1e-7), which keeps a
+            // score within the north star's 1e-6 of the reference's all-double sum
+            float run[2][APAD];
 #pragma unroll
-            for (int a = 0; a < APAD; ++a) run[a] = 0.f;
+            for (int a = 0; a < APAD; ++a) { run[0][a] = 0.f; run[1][a] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (qb + s < Q) {
@@ -1633,13 +1636,13 @@ k_ssd_tiles(const float4* __restrict__ ftiles, const float* __restrict__ fprep, 
 #pragma unroll
                         for (int a = 0; a < APAD; ++a) {
                             const float d = lw[j] - pp[j * apad_total + a];
-                            run[a] = __builtin_fmaf(d, d, run[a]);
+                            run[s >> 1][a] = __builtin_fmaf(d, d, run[s >> 1][a]);
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int a = 0; a < APAD; ++a) acc[a] += (double)run[a];
+            for (int a = 0; a < APAD; ++a) { acc[a] += (double)run[0][a]; acc[a] += (double)run[1][a]; }
             if (PF) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
@@ -1885,23 +1888,27 @@ __device__ __forceinline__ bool sense_pixel(const unsigned char* __restrict__ la
 }
 
 // ------------------------------------------------------------------ per-step patch preparation
-// ONE kernel makes the resident patches of a step, whatever their source (MODE): uploaded raw bytes (0), the sensor
+// ONE kernel makes everything a step needs of its patches, whatever their source (MODE): uploaded raw bytes (0), the sensor
 // model at the headings' poses (1: dv_sense_patches, dv_sense_step*), or the synthetic stream of the benchmarks (2).
-// One thread per (heading, group of 4 sensor pixels):
-//   raw[a][P][3]            the patches' bytes (written for MODE 1 and 2; the exact kernels and the tie resolver read them);
-//   prep[pl][q][j][APAD]    dword = 4 pixels (16q + 4j ..) of heading a in stored byte plane pl: the SGPR operands of
-//                           v_sad_u8 (byte path) and the source of the coefficient images (k_coef_image);
+// One block of 256 threads per (heading a, range of 256 sensor pixels); phase 1, one pixel per thread, leaves the pixels'
+// raw bytes and stored-plane bytes in LDS; phase 2 writes from there
+//   raw[a][P][3]            the patches' bytes (MODE 1 and 2; the exact kernels and the tie resolver read them);
+//   prep[pl][q][j][APAD]    dword = 4 pixels (16q + 4j ..) of heading a in stored byte plane pl: the SGPR operands of v_sad_u8;
+//   coef4 / coef            the coefficient images of the matrix-core kernel (layouts below, "bit-plane library"): 256 pixels are
+//                           T whole K-steps of a segment with T planes per pixel, so a block owns whole 16-byte entries of both
+//                           images -- one thread builds one entry from the bytes in LDS;
 //   acc->hs[a]              byte path: sum over pixels whose hue is outside the library's hue set of S (+ the excess of a
 //                           clamped signed-saturation byte), see plane_byte;
 //   acc->bhs[a], bv[a]      bit-plane path: everything of the two sums that does not depend on the view.  With the
-//                           thermometer identity (below, "bit-plane library") the patch-only terms of one byte add up to
+//                           thermometer identity the patch-only terms of one byte add up to
 //                           (l_0 - a)+ + (a - l_max)+ + sum_t alpha_t = |a - l_0|, l_0 the plane's smallest library value;
-//   acc->off                nonzero when some patch byte lies strictly inside a gap between two library levels: the
-//                           scoring kernel then takes its int8 form (k_sad_mfma_dual) and k_coef_image writes that image;
+//   acc->off                nonzero when some patch byte lies strictly inside a gap between two library levels: the scoring
+//                           kernel then takes its int8 form (k_sad_mfma_dual);
 //   acc->err                bit per agent of the pass: its sensor footprint reached past the end of the landscape.
-// The sums are folded per wave and added with one integer atomic each, so they must start at zero: `next` is the OTHER
+// The sums are folded per block and added with one integer atomic each, so they must start at zero: `next` is the OTHER
 // set of the pair, which nothing uses during this step -- block 0 clears it for the next preparation, and no memset
-// sits on a step's path.
+// sits on a step's path.  Image entries of K-steps past a segment's last pixel are never written: they were zeroed when the
+// images were allocated.
 struct PrepAcc {
     int hs[kMaxHeadings];
     int bhs[kMaxHeadings];
@@ -1910,8 +1917,12 @@ struct PrepAcc {
     unsigned off;
     unsigned pad;
 };
+constexpr int kPrepPlanes = 16;               // == kMaxBitPlanes (defined with the bit-plane library below)
 struct PrepBits {
     int enabled;                              // the library has bit planes (build_bit_planes)
+    int fp4;                                  // ... and an fp4 form: the E2M1 sign image is written too
+    int T[2], NK[2];                          // planes per pixel and K-steps of the HS and the V segment
+    unsigned tbl[kPrepPlanes];                // per bit plane: byte plane | lo << 8 | w << 16 | wfull << 24
     unsigned char lmin[kMaxHues + 1];         // smallest library value of each stored byte plane
     unsigned ok[kMaxHues + 1][8];             // bit v of plane pl: patch byte v has fp4 coefficients (on a level, or outside the range)
 };
@@ -1922,123 +1933,150 @@ template <int MODE>
 __global__ void __launch_bounds__(256)
 k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A, SensorCfg g, const unsigned char* __restrict__ lut,
              unsigned char* __restrict__ raw, unsigned* __restrict__ prep, LibCfg c, int APAD, PrepAcc* __restrict__ acc,
-             PrepAcc* __restrict__ next, int A_agent, PrepBits pb, unsigned long long seed) {
+             PrepAcc* __restrict__ next, int A_agent, PrepBits pb, unsigned long long seed, uint4* __restrict__ coef,
+             uint4* __restrict__ coef4) {
+    const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
-        if (threadIdx.x < kMaxHeadings) { next->hs[threadIdx.x] = 0; next->bhs[threadIdx.x] = 0; next->bv[threadIdx.x] = 0; }
-        if (threadIdx.x == 0) { next->err = 0; next->off = 0; }
+        if (tid < kMaxHeadings) { next->hs[tid] = 0; next->bhs[tid] = 0; next->bv[tid] = 0; }
+        if (tid == 0) { next->err = 0; next->off = 0; }
     }
-    // the level tables of the sensor (3 x 256 bytes) and the on-level bitmaps go to LDS: per-lane lookups
-    __shared__ unsigned char s_lut[768];
+    __shared__ unsigned char s_lut[768];                   // the sensor's level tables (3 x 256 bytes)
     __shared__ unsigned s_ok[(kMaxHues + 1) * 8];
-    if (MODE == 1 && threadIdx.x < 192) reinterpret_cast<unsigned*>(s_lut)[threadIdx.x] = reinterpret_cast<const unsigned*>(lut)[threadIdx.x];
-    if (threadIdx.x < (kMaxHues + 1) * 8) s_ok[threadIdx.x] = pb.ok[threadIdx.x >> 3][threadIdx.x & 7];
-    __syncthreads();
-    const int ngroups = c.Q * 4;                           // groups of 4 pixels, incl. the zero padding
-    const long long total = (long long)A * ngroups;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned s_tbl[kPrepPlanes];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[256 * 3];
+    __shared__ __attribute__((aligned(16))) unsigned char s_pl[(kMaxHues + 1)][256];      // stored-plane bytes of the block's pixels
+    __shared__ int s_red[4][4];
+    if (MODE == 1 && tid < 192) reinterpret_cast<unsigned*>(s_lut)[tid] = reinterpret_cast<const unsigned*>(lut)[tid];
+    if (tid < (kMaxHues + 1) * 8) s_ok[tid] = pb.ok[tid >> 3][tid & 7];
+    if (tid < kPrepPlanes) s_tbl[tid] = pb.tbl[tid];
+    const int nblk = (c.P + 255) / 256;                    // pixel ranges per heading
+    const int a = blockIdx.x / nblk, blk = blockIdx.x - a * nblk;
+    const int px = blk * 256 + tid;
+    if (MODE == 1) __syncthreads();                        // (the sensor tables are used in phase 1)
+    // ---- phase 1: this thread's pixel
+    unsigned H = 0, S = 0, V = 0;
+    bool sense_err = false;
+    if (px < c.P) {
+        if (MODE == 1) {
+            if (!sense_pixel(land, g, poses.p[a], s_lut, px / g.sw, px % g.sw, H, S, V)) { sense_err = true; H = S = V = 0; }
+        } else if (MODE == 2) {
+            synth_hsv(splitmix64((unsigned long long)((long long)a * c.P + px) + (seed + 1ull) * 0x9E3779B97F4A7C15ull), H, S, V);
+        } else {
+            const unsigned char* r = raw + ((long long)a * c.P + px) * 3;
+            H = r[0]; S = r[1]; V = r[2];
+        }
+    }
     int k_hs = 0, k_bhs = 0, k_bv = 0;
     bool off = false;
-    int a = 0;
-    if (t < total) {
-        a = (int)(t / ngroups);                            // heading-major: a wave never straddles two headings
-        const int grp = (int)(t % ngroups);                //   when ngroups is a multiple of 64; handled below otherwise
-        unsigned Hs[4] = {0, 0, 0, 0}, Ss[4] = {0, 0, 0, 0}, Vs[4] = {0, 0, 0, 0};
-        const long long roff = ((long long)a * c.P + (long long)grp * 4) * 3;
-        const bool whole = (roff & 3) == 0 && grp * 4 + 3 < c.P;      // the group's 12 raw bytes are three aligned dwords
-        if (MODE == 1) {
-            const Pose p = poses.p[a];
-            bool okp[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                  // four independent fetches in flight
-                const int px = grp * 4 + i;
-                okp[i] = true;
-                if (px < c.P) okp[i] = sense_pixel(land, g, p, s_lut, px / g.sw, px % g.sw, Hs[i], Ss[i], Vs[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (!okp[i]) { atomicOr(&acc->err, 1ull << (a / A_agent)); Hs[i] = Ss[i] = Vs[i] = 0; }     // bit = agent of the pass
-        } else if (MODE == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int px = grp * 4 + i;
-                if (px < c.P)
-                    synth_hsv(splitmix64((unsigned long long)((long long)a * c.P + px) + (seed + 1ull) * 0x9E3779B97F4A7C15ull), Hs[i], Ss[i], Vs[i]);
-            }
-        } else {
-            unsigned char rb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (whole) {
-                const unsigned* s = reinterpret_cast<const unsigned*>(raw + roff);
-                const unsigned d0 = s[0], d1 = s[1], d2 = s[2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { rb[k] = (unsigned char)(d0 >> (8 * k)); rb[4 + k] = (unsigned char)(d1 >> (8 * k)); rb[8 + k] = (unsigned char)(d2 >> (8 * k)); }
-            } else {
-                for (int i = 0; i < 12 && grp * 4 + i / 3 < c.P; ++i) rb[i] = raw[roff + i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { Hs[i] = rb[3 * i]; Ss[i] = rb[3 * i + 1]; Vs[i] = rb[3 * i + 2]; }
+    s_raw[tid * 3] = (unsigned char)H; s_raw[tid * 3 + 1] = (unsigned char)S; s_raw[tid * 3 + 2] = (unsigned char)V;
+    if (px < c.P) {
+        if (!c.generic && c.cw > 0.0) {
+            const int nk = c.signed_s ? 2 : c.nhs;
+            bool in_set = false;
+            for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
+            if (!in_set) k_hs = (int)S;
+            else if (c.signed_s && S > 127u) k_hs = (int)S - 127;       // excess over the clamped plane byte
         }
-        unsigned w[kMaxHues + 1];
-        for (int pl = 0; pl < c.npl; ++pl) w[pl] = 0;
+        k_bhs = k_hs;
+    }
+    for (int pl = 0; pl < c.npl; ++pl) {
+        const unsigned av = px < c.P ? plane_byte(c, pl, H, S, V) : 0u;
+        s_pl[pl][tid] = (unsigned char)av;
+        if (pb.enabled && px < c.P) {
+            const int d = abs((int)av - (int)pb.lmin[pl]);
+            if (pl < c.nhs) k_bhs += d; else k_bv += d;
+        }
+    }
+    __syncthreads();                                       // s_ok is in LDS; so are the block's bytes
+    if (pb.enabled && px < c.P)
+        for (int pl = 0; pl < c.npl; ++pl) {
+            const unsigned av = s_pl[pl][tid];
+            off |= ((s_ok[pl * 8 + (av >> 5)] >> (av & 31)) & 1u) == 0u;
+        }
+    // the block's sums: wave shuffles, then four values through LDS
+    {
+        int s0 = k_hs, s1 = k_bhs, s2 = k_bv, s3 = (off ? 1 : 0) | (sense_err ? 2 : 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = grp * 4 + i;
-            if (px >= c.P) break;
-            const unsigned H = Hs[i], S = Ss[i], V = Vs[i];
-            int konst = 0;
-            if (!c.generic && c.cw > 0.0) {
-                const int nk = c.signed_s ? 2 : c.nhs;
-                bool in_set = false;
-                for (int k = 0; k < nk; ++k) in_set |= (H == c.hues[k]);
-                if (!in_set) konst = (int)S;
-                else if (c.signed_s && S > 127u) konst = (int)S - 127;       // excess over the clamped plane byte
-            }
-            k_hs += konst;
-            k_bhs += konst;
-            for (int pl = 0; pl < c.npl; ++pl) {
-                const unsigned av = plane_byte(c, pl, H, S, V);
-                w[pl] |= av << (8 * i);
-                if (pb.enabled) {
-                    const int d = abs((int)av - (int)pb.lmin[pl]);
-                    if (pl < c.nhs) k_bhs += d; else k_bv += d;
-                    off |= ((s_ok[pl * 8 + (av >> 5)] >> (av & 31)) & 1u) == 0u;
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 |= __shfl_xor(s3, o); }
+        if ((tid & 63) == 0) { s_red[tid >> 6][0] = s0; s_red[tid >> 6][1] = s1; s_red[tid >> 6][2] = s2; s_red[tid >> 6][3] = s3; }
+    }
+    // ---- phase 2: out of LDS.  Raw bytes and the byte path's operand dwords first
+    const long long rbase = ((long long)a * c.P + (long long)blk * 256) * 3;
+    const int npx = c.P - blk * 256 < 256 ? c.P - blk * 256 : 256;      // real pixels of this block
+    if (MODE != 0) {
+        if ((rbase & 3) == 0 && npx == 256) {
+            if (tid < 192) reinterpret_cast<unsigned*>(raw + rbase)[tid] = reinterpret_cast<const unsigned*>(s_raw)[tid];
+        } else {
+            for (int i = tid; i < npx * 3; i += 256) raw[rbase + i] = s_raw[i];
+        }
+    }
+    for (int i = tid; i < c.npl * 64; i += 256) {
+        const int pl = i >> 6, gq = i & 63;                // dword gq of the block: pixels blk * 256 + 4 gq ..
+        const int grp = blk * 64 + gq;
+        if (grp < c.Q * 4) prep[((long long)pl * c.Q * 4 + grp) * APAD + a] = reinterpret_cast<const unsigned*>(&s_pl[pl][0])[gq];
+    }
+    // the coefficient images: entry e of this block = (segment, K-step kk of the block's T, image part, half) -- one per thread
+    if (pb.enabled) {
+        const int NKT = pb.NK[0] + pb.NK[1];
+        const int pass = a >> 5, al = a & 31;
+        const int n4 = pb.fp4 ? 8 : 0;                     // entries per K-step: 4 bit positions x 2 halves (fp4), 8 slices x 2 halves (int8)
+        const int per_k = n4 + 16;
+        const int total = (pb.T[0] + pb.T[1]) * per_k;
+        for (int e = tid; e < total; e += 256) {
+            const int kidx = e / per_k, part = e - kidx * per_k;
+            const int seg = kidx >= pb.T[0] ? 1 : 0;
+            const int kk = kidx - (seg ? pb.T[0] : 0);
+            const int T = pb.T[seg], first = seg ? pb.T[0] : 0;
+            const int ksl = blk * T + kk;                  // K-step within the segment
+            if (ksl >= pb.NK[seg]) continue;               // (past the segment's last pixel: stays zero)
+            const bool is4 = part < n4;
+            const int sub = is4 ? part >> 1 : (part - n4) >> 1, half = part & 1;
+            const int step = is4 ? 4 : 8, cnt = is4 ? 8 : 4;
+            const unsigned uT = (unsigned)T, qs = (unsigned)step / uT, rs = (unsigned)step % uT;
+            unsigned out[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned n = (unsigned)((kk * 2 + half) * 4 + j) * 32u + (unsigned)sub;     // element within the block's T K-steps
+                unsigned lp = n / uT, r = n - lp * uT;      // local pixel, plane within the segment
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i < cnt) {
+                        const unsigned tb = s_tbl[first + (int)r];
+                        const bool real = (int)lp < npx;
+                        const int av = (int)s_pl[tb & 0xffu][lp & 255u];
+                        const int al_ = av - (int)((tb >> 8) & 0xffu);
+                        if (is4) {
+                            const int wf = (int)(tb >> 24);                 // 0: a copy of a split gap's first plane
+                            if (real && wf) out[j] |= (al_ >= wf ? 0xAu : 0x2u) << (4 * i);
+                        } else {
+                            const int wd = (int)((tb >> 16) & 0xffu);
+                            const int alpha = al_ < 0 ? 0 : (al_ > wd ? wd : al_);
+                            if (real) out[j] |= (unsigned)((wd - 2 * alpha) & 0xff) << (8 * i);
+                        }
+                        lp += qs; r += rs;
+                        if (r >= uT) { r -= uT; ++lp; }
+                    }
                 }
             }
+            const long long ks = (long long)pass * NKT + (seg ? pb.NK[0] : 0) + ksl;
+            const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
+            if (is4) coef4[(ks * 4 + sub) * 64 + al + 32 * half] = v;
+            else coef[(ks * 8 + sub) * 64 + al + 32 * half] = v;
         }
-        if (MODE != 0) {                                   // the group's raw bytes, for the exact kernels
-            unsigned char rawb[12];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { rawb[3 * i] = (unsigned char)Hs[i]; rawb[3 * i + 1] = (unsigned char)Ss[i]; rawb[3 * i + 2] = (unsigned char)Vs[i]; }
-            if (whole) {
-                unsigned* o = reinterpret_cast<unsigned*>(raw + roff);
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    o[d] = (unsigned)rawb[4 * d] | ((unsigned)rawb[4 * d + 1] << 8) | ((unsigned)rawb[4 * d + 2] << 16) | ((unsigned)rawb[4 * d + 3] << 24);
-            } else {
-                for (int i = 0; i < 12 && grp * 4 + i / 3 < c.P; ++i) raw[roff + i] = rawb[i];
-            }
-        }
-        const int q = grp >> 2, j = grp & 3;
-        for (int pl = 0; pl < c.npl; ++pl) prep[(((long long)pl * c.Q + q) * 4 + j) * APAD + a] = w[pl];
     }
-    if (__any(off) && (threadIdx.x & 63) == 0) atomicOr(&acc->off, 1u);
-    // per-heading constants: lanes of a wave may belong to two headings when ngroups is not a multiple of 64
-    const int a_first = __shfl(a, 0);
-    const bool uniform = __all(t >= total || a == a_first);
-    if (uniform) {
-        int s0 = (t < total) ? k_hs : 0, s1 = (t < total) ? k_bhs : 0, s2 = (t < total) ? k_bv : 0;
+    __syncthreads();
+    if (tid == 0) {
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        if ((threadIdx.x & 63) == 0) {
-            if (s0 != 0) atomicAdd(&acc->hs[a_first], s0);
-            if (s1 != 0) atomicAdd(&acc->bhs[a_first], s1);
-            if (s2 != 0) atomicAdd(&acc->bv[a_first], s2);
-        }
-    } else if (t < total) {
-        if (k_hs != 0) atomicAdd(&acc->hs[a], k_hs);
-        if (k_bhs != 0) atomicAdd(&acc->bhs[a], k_bhs);
-        if (k_bv != 0) atomicAdd(&acc->bv[a], k_bv);
+        for (int w = 0; w < 4; ++w) { s0 += s_red[w][0]; s1 += s_red[w][1]; s2 += s_red[w][2]; s3 |= s_red[w][3]; }
+        if (s0) atomicAdd(&acc->hs[a], s0);
+        if (s1) atomicAdd(&acc->bhs[a], s1);
+        if (s2) atomicAdd(&acc->bv[a], s2);
+        if (s3 & 1) atomicOr(&acc->off, 1u);
+        if (s3 & 2) atomicOr(&acc->err, 1ull << (a / A_agent));      // bit = agent of the pass
     }
 }
+
 // ------------------------------------------------------------------ bit-plane library + int8 MFMA scoring
 // |a - b| is not bilinear, but it becomes linear in b once b is known to come from a small level set
 // l_0 < l_1 < ... (the reference's sensor quantises V to n_sensor_levels values, NavBySceneFamiliarity.py:176-186, and
@@ -2059,6 +2097,7 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
 //     term is a multiple of it).  Slices 4..7 use x >> 4, so four accumulators carry the eight slices.
 // The integer sums are the ones k_sad_tiles produces, so everything downstream (k_finish / k_combine, tie rule) is shared.
 constexpr int kMaxBitPlanes = 16;
+static_assert(kMaxBitPlanes == kPrepPlanes, "PrepBits::tbl");
 struct BitCfg {
     int T[2];               // planes of the HS segment and of the V segment
     int NK[2];              // K-steps (256 K-elements) of each segment
@@ -2189,84 +2228,6 @@ k_bitpack_code(const uint4* __restrict__ btiles, unsigned* __restrict__ ctiles, 
     }
 }
 
-// Per-step operands of the MFMA path, from the patches' stored-plane bytes (prep, left by k_patch_prep).  One block of 256
-// threads per (pass of 32 headings, K-step, image part); every thread makes ONE 16-byte entry of an image with its own
-// loads (no LDS staging, no atomics: the whole preparation is one round trip).  Which image the scoring kernel will read
-// is known when this kernel starts (*offp, k_patch_prep), so only that one is written:
-//   fp4 image  coef4[pass][ks][bit b][lane] : nibble i of dword j = sign of K-element ((2 ks + half) 4 + j) 32 + 4 i + b
-//              as E2M1 (+1.0 = 0x2, -1.0 = 0xA; 0 for a copy of a split gap's first plane and beyond the last pixel);
-//              part = 0: thread = (b = wave, lane);
-//   int8 image coef[pass][ks][slice s][lane] : byte bb of dword j = w_t - 2 alpha_t of K-element ((2 ks + half) 4 + j) 32 + s + 8 bb;
-//              parts 1, 2: thread = (s = 4 (part - 1) + wave, lane).
-// lane = (heading & 31) + 32 half.  Element n of a segment = plane n % T of pixel n / T.
-__global__ void __launch_bounds__(256)
-k_coef_image(const unsigned* __restrict__ prep, uint4* __restrict__ coef, uint4* __restrict__ coef4, const unsigned* __restrict__ offp,
-             LibCfg c, BitCfg b, int A, int APAD, int npass) {
-    __shared__ unsigned s_tbl[kMaxBitPlanes];              // per bit plane: byte plane | lo << 8 | w << 16 | wfull << 24
-    if (threadIdx.x < kMaxBitPlanes)
-        s_tbl[threadIdx.x] = (unsigned)b.pl[threadIdx.x] | ((unsigned)b.lo[threadIdx.x] << 8) | ((unsigned)b.w[threadIdx.x] << 16) |
-                             ((unsigned)b.wfull[threadIdx.x] << 24);
-    __syncthreads();
-    const int NKT = b.NK[0] + b.NK[1];
-    const int n4 = coef4 ? NKT * npass : 0;
-    const unsigned off = (coef4 && offp) ? __builtin_amdgcn_readfirstlane(*offp) : 1u;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool is4 = (int)blockIdx.x < n4;
-    if (is4 ? off != 0u : (coef4 != nullptr && off == 0u)) return;      // the other image is the one that will be read
-    const int idx = is4 ? (int)blockIdx.x : ((int)blockIdx.x - n4) >> 1;   // (pass, K-step)
-    const int sub = is4 ? wave : (((int)blockIdx.x - n4) & 1) * 4 + wave;   // bit position / slice
-    const int pass = idx / NKT, ks = idx - pass * NKT;
-    const int seg = ks >= b.NK[0] ? 1 : 0;
-    const int ksl = ks - (seg ? b.NK[0] : 0);
-    const int T = b.T[seg], first = seg ? b.T[0] : 0;
-    const int a = pass * 32 + (lane & 31), half = lane >> 5;
-    const int STEP = is4 ? 4 : 8;
-    unsigned out[4] = {0u, 0u, 0u, 0u};
-    if (a < A && T > 0) {
-        const unsigned uT = (unsigned)T, qs = (unsigned)STEP / uT, rs = (unsigned)STEP % uT;
-        const unsigned* pa = prep + a;
-        const long long plane_stride = (long long)c.Q * 4 * APAD;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned n = (unsigned)((ksl * 2 + half) * 4 + j) * 32u + (unsigned)sub;     // < T * P + 256: fits 32 bits
-            unsigned px = n / uT, r = n - px * uT;
-            // the loads of a dword's elements go out together (clamped addresses: no conditional loads)
-            unsigned tb[8], dw[8], sh[8];
-            bool real[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (e < 32 / STEP) {
-                    tb[e] = s_tbl[first + (int)r];
-                    real[e] = px < (unsigned)c.P;
-                    const unsigned pxc = real[e] ? px : (unsigned)c.P - 1u;
-                    dw[e] = pa[(long long)(tb[e] & 0xffu) * plane_stride + (long long)(pxc >> 2) * APAD];
-                    sh[e] = 8u * (pxc & 3u);
-                    px += qs; r += rs;
-                    if (r >= uT) { r -= uT; ++px; }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (e < 32 / STEP) {
-                    const int av = (int)((dw[e] >> sh[e]) & 0xffu);
-                    const int al = av - (int)((tb[e] >> 8) & 0xffu);
-                    if (is4) {
-                        const int wf = (int)(tb[e] >> 24);                 // 0: a copy of a split gap's first plane
-                        if (real[e] && wf) out[j] |= (al >= wf ? 0xAu : 0x2u) << (4 * e);
-                    } else {
-                        const int wd = (int)((tb[e] >> 16) & 0xffu);
-                        const int alpha = al < 0 ? 0 : (al > wd ? wd : al);
-                        if (real[e]) out[j] |= (unsigned)((wd - 2 * alpha) & 0xff) << (8 * e);
-                    }
-                }
-            }
-        }
-    }
-    const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
-    if (is4) coef4[((long long)idx * 4 + sub) * 64 + lane] = v;
-    else coef[((long long)idx * 8 + sub) * 64 + lane] = v;
-}
-
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -2348,13 +2309,16 @@ template <int TILES, int NW, typename HsOf, typename VOf>
 __device__ __forceinline__ void
 fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&live)[TILES],
              unsigned long long* scratch, const LibCfg& c, const FuseArgs& fz, int a_off, int has_hs_sum, long long gq, int lane, int wave,
-             int n_entry_waves = NW, bool idle = false) {
+             int parity, int n_entry_waves = NW, bool idle = false, const int* consts = nullptr, unsigned long long* blk = nullptr) {
     static_assert(NW == 8, "scratch layout");
-    // Waves that hold no sums (the loader waves of sad_lc_fp4) only keep the five barriers: raw ones, so that nothing waits
-    // for the LDS-DMA they have in flight for the next item.  Waves [0, n_entry_waves) hold the entries.
+    // Three workgroup barriers per call.  What a call needs cleared on entry is cleared by the call before it (fused_block_begin
+    // before the first): abest by wave 0, which alone touches it, and the queue counter of the NEXT call's parity -- the callers
+    // alternate `parity`, so a counter is cleared two barriers before anybody adds to it again.
+    // Waves that hold no sums (the loader waves of sad_lc_fp4) only keep the barriers: raw ones, so that nothing waits for the
+    // LDS-DMA they have in flight for the next item.  Waves [0, n_entry_waves) hold the entries.
     if (idle) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_barrier();
         return;
     }
     unsigned long long* sum_sc = scratch;                      // [NW][32] bits of the (non-negative) sc: bit order = value order
@@ -2365,9 +2329,10 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     unsigned long long* loose_sc = thr_key + 32;               // [32] per heading
     unsigned long long* q_sc = loose_sc + 32;                  // [kFuseQueue] bits of sc
     unsigned long long* q_id = q_sc + kFuseQueue;              // [kFuseQueue] heading of the pass << 40 | view
-    unsigned* q_n = reinterpret_cast<unsigned*>(q_id + kFuseQueue);
-    unsigned long long* blk_key = scratch + kFuseBlk;          // [32] the workgroup's best per heading over its items so far
-    unsigned long long* blk_view = blk_key + 32;               // [32] (fused_block_begin / fused_block_end)
+    unsigned* q_n = reinterpret_cast<unsigned*>(q_id + kFuseQueue) + (parity & 1);      // [2] counters, used alternately
+    unsigned* q_n_next = reinterpret_cast<unsigned*>(q_id + kFuseQueue) + ((parity & 1) ^ 1);
+    unsigned long long* blk_key = blk ? blk : scratch + kFuseBlk;      // [32] the workgroup's best per heading over its items so far
+    unsigned long long* blk_view = blk_key + 32;               // [32] (fused_block_begin / fused_block_end); `blk`: a second heading tile's
     // The lane index is made opaque here: everything below that depends on it is loop-invariant, and the compiler
     // would otherwise compute it once per kernel and hold it in registers through the scoring loop (48 64-bit values
     // per lane: the kernel then spills several hundred bytes per lane and reloads them entry by entry).
@@ -2377,10 +2342,8 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     const int a = a_off + n;
     const bool valid = a < fz.A_real;
     const int ac = valid ? a : fz.A_real - 1;
-    const int hsc = fz.hsconst[ac], vc = fz.vconst ? fz.vconst[ac] : 0;
-    if (threadIdx.x < 32) abest[threadIdx.x] = ~0ull;
-    if (threadIdx.x == 32) *q_n = 0;
-    __syncthreads();
+    // the lane's two per-heading constants: loaded here, or once per kernel by the caller (`consts`: one L2 round trip less per item)
+    const int hsc = consts ? consts[0] : fz.hsconst[ac], vc = consts ? consts[1] : (fz.vconst ? fz.vconst[ac] : 0);
     // score >= best - delta  =>  sc <= sc_best + 255 delta up to roundings of a few ulp of P: loose by far more
     const double margin = 256. * fz.delta + 256. * (double)c.P * 8.9e-16;
     const double kInf = __longlong_as_double(0x7ff0000000000000ll);
@@ -2453,6 +2416,7 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
         if (half == 0) { sum_sc[wave * 32 + n] = (unsigned long long)__double_as_longlong(bs); sum_view[wave * 32 + n] = bv; }
     }
     __syncthreads();
+    if (threadIdx.x == 32) *q_n_next = 0;                      // (the next call's queue counter: nobody reads or adds to it during this call)
     const unsigned long long kNone = 0x7ff0000000000000ull;   // +inf: no entry (sc >= 0: bit order = value order)
     if (threadIdx.x < 32) {                                    // thread n: the item's summary of heading a_off + n
         unsigned long long is = kNone, iv = ~0ull;
@@ -2491,12 +2455,11 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
             (void)gq;
         }
         item_view[n] = iv;
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) {
+        // Same 32 threads, same wave: its LDS operations complete in order, so every lane's atomicMin above has been applied when
+        // the loads below execute -- no barrier between the two halves of this section.
         unsigned long long tk = ~0ull, ls = 0ull;              // nothing passes
         if (valid) {
-            const unsigned long long best = abest[a / fz.A_agent - agent0];
+            const unsigned long long best = __hip_atomic_load(&abest[a / fz.A_agent - agent0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (best != ~0ull) {
                 const double scb = __longlong_as_double((long long)best);
                 tk = ordered_key(((double)c.P - scb / 255.) - fz.delta);
@@ -2505,6 +2468,7 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
         }
         thr_key[n] = tk;
         loose_sc[n] = ls;
+        __hip_atomic_store(&abest[n], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // clear for the next call (this wave alone touches it)
     }
     __syncthreads();
     auto list = [&](int m, double sc, unsigned long long f) {  // heading a_off + m of the pass, an entry within the loose bound
@@ -2531,9 +2495,14 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
 
 // The workgroup's running summary (fused_finish): cleared before its first item, written after its last --
 // bsum[agent][workgroup][2][A_agent], nb = gridDim.x summaries per agent.
-__device__ __forceinline__ void fused_block_begin(unsigned long long* scratch) {
+__device__ __forceinline__ void fused_block_begin(unsigned long long* scratch, bool first = true) {
     unsigned long long* blk_key = scratch + kFuseBlk;
     if (threadIdx.x < 32) { blk_key[threadIdx.x] = 0; blk_key[32 + threadIdx.x] = ~0ull; }
+    if (first) {                                               // what fused_finish expects cleared on entry
+        unsigned long long* abest = scratch + 2 * 8 * 32 + 32;
+        if (threadIdx.x < 32) abest[threadIdx.x] = ~0ull;
+        if (threadIdx.x == 32) scratch[2 * 8 * 32 + 4 * 32 + 2 * kFuseQueue] = 0ull;      // both queue counters
+    }
     __syncthreads();
 }
 __device__ __forceinline__ void fused_block_end(const unsigned long long* scratch, const FuseArgs& fz, const LibCfg& c, int a_off) {
@@ -2569,6 +2538,8 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
     const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
     if constexpr (FUSE) fused_block_begin(reinterpret_cast<unsigned long long*>(lds_ring + RD * SLOT16));
+    int nfin = 0;                                 // fused_finish calls so far (their parity)
+    (void)nfin;
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / GQ);
         const long long gq = item - (long long)ch * GQ;
@@ -2705,8 +2676,9 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
                     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds_ring + RD * SLOT16);
                     auto of_tot = [&](int t, int r) -> int { return tot[t][r]; };
                     auto of_park = [&](int t, int r) -> int { return parkr[t][r]; };
-                    if (seg == 0) fused_finish<TILES, NW>(of_tot, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
-                    else fused_finish<TILES, NW>(of_park, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
+                    if (seg == 0) fused_finish<TILES, NW>(of_tot, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin);
+                    else fused_finish<TILES, NW>(of_park, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin);
+                    ++nfin;
                 }
             }
         }
@@ -2724,7 +2696,7 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
 // the signs are exact in fp4 (E2M1: +-1.0), the library bits too (bit 0/1/2 of a nibble ARE the E2M1 values 0.5/1/2, bit 3
 // comes down by a shift), and v_mfma_f32_32x32x64_f8f6f4 multiplies 64 K-elements in the time the int8 form takes for 32
 // (measured: 21.2 vs 18.3 ns per instruction and SIMD, tools/exp/mfma_fp4.hip).  The SAME bit tiles are the B operand:
-// K-element <-> (dword j, bit 4i + b) pairs with nibble i of coefficient image b of that K-step (k_coef_image), and any
+// K-element <-> (dword j, bit 4i + b) pairs with nibble i of coefficient image b of that K-step (k_patch_prep), and any
 // pairing works as long as both operands use it.  Sums of +-{0.5, 1, 2} stay exact in the fp32 accumulators (below 2^24
 // in halves); the four accumulators (one per bit position) are multiplied by their widths as integers at the end: the int32 sums are
 // the int8 form's, bit for bit.  With the coefficient image half the size, the kernel is left to the HBM stream.
@@ -2964,6 +2936,8 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
     const long long gbytes = b.vcode ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
     DV_STAMP(0);
     if constexpr (FUSE) fused_block_begin(reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING));
+    int nfin = 0;                                 // fused_finish calls so far (their parity)
+    (void)nfin;
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int ch = (int)(item / GQ);
         const long long gq = item - (long long)ch * GQ;
@@ -3033,7 +3007,7 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
             auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
             auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
             if (item == blockIdx.x) DV_STAMP(3);
-            fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave);
+            fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin++);
             if (item == blockIdx.x) DV_STAMP(4);
         }
     }
@@ -3060,54 +3034,68 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
 template <int SK, int RD>
 constexpr int lc_ring_bytes() { return RD * SK * 12 * 1024; }
 
-template <int SK, int RD, bool FUSE, bool CODE>
+template <int SK, int RD, bool FUSE, bool CODE, int HT>
 __device__ __forceinline__ void
 sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
            int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz, int n_gq) {
+    // HT = 1: a consumer multiplies TWO view groups by the 32 headings at a_off (8 view groups per item);
+    // HT = 2: ONE view group by the 64 headings at a_off .. a_off + 63, two heading tiles whose coefficient images lie one
+    //         pass apart (4 view groups per item): the library crosses HBM once for 64 headings, and the masked library
+    //         operands are made once for both tiles.
+    // Either way a K-step is 12 rows of 1 KB in the ring (4 HT coefficient rows + 8 / HT library rows) and 8 MFMAs per consumer.
     extern __shared__ uint4 lds_ring[];
-    constexpr int TILES = 2, NW = 8, NC = 4, NL = 4;
-    constexpr int COEF_ROWS = SK * 4, LIB_ROWS = SK * NC * TILES, ROWS = COEF_ROWS + LIB_ROWS;
+    constexpr int TL = 2 / HT;                                          // view groups per consumer
+    constexpr int NW = 8, NC = 4, NL = 4;
+    constexpr int KCOEF = 4 * HT, KLIB = NC * TL;                       // rows per K-step
+    constexpr int COEF_ROWS = SK * KCOEF, ROWS = SK * (KCOEF + KLIB);
     constexpr int SLOTB = ROWS * 1024;
-    constexpr int PER = ROWS / NL;                                    // LDS-DMA instructions per loader wave and stage
+    constexpr int PER = ROWS / NL;                                      // LDS-DMA instructions per loader wave and stage
     constexpr int RING = RD * SLOTB;
-    static_assert(PER == 3 * SK && PER * (RD - 1) < 64 && SK % 2 == 0 && RD >= 3, "ring shape");
+    constexpr int NU = SK * HT;                                         // pipeline units per stage: (K-step, heading tile)
+    static_assert((HT == 1 || HT == 2) && PER == 3 * SK && PER * (RD - 1) < 64 && SK % 2 == 0 && RD >= 3, "ring shape");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool loader = wave >= NC;
     const long long G32 = c.Fpad / 32, GQ = n_gq;
     const int NKT = b.NK[0] + b.NK[1];
     const int nst = (NKT + SK - 1) / SK;
-    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
     // code tiles (k_bitpack_code): the V rows are 768 bytes (3-bit level codes), moved by global_load_lds_dwordx3 -- every lane's
     // 12 bytes land 16 apart in LDS, so a row is read back like any other -- and decoded in registers by the consumers
-    constexpr bool codev = CODE;                                      // == (b.vcode != 0): the host picks the instantiation
+    constexpr bool codev = CODE;                                        // == (b.vcode != 0): the host picks the instantiation
     const int NK0 = b.NK[0];
     const long long gbytes = codev ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
+    const long long pass16 = (long long)NKT * 256;                      // uint4 between the coefficient images of two heading tiles
     const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
-    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING);
+    unsigned long long* scratch0 = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING);
     const unsigned char* lib_bytes = reinterpret_cast<const unsigned char*>(ftiles);
     DV_STAMP(0);
-    if constexpr (FUSE) fused_block_begin(scratch);
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h) fused_block_begin(scratch0 + h * 64, h == 0);      // (running summaries of heading tile h: 64 words behind the first tile's)
+    }
     const long long n_mine = GQ > (long long)blockIdx.x ? (GQ - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;       // items of this workgroup
 
     // ---- loader state: the stage it issues next, (li, lst) = (item of this workgroup, stage), into ring slot lslot
     const int lw = wave - NC;
     long long li = 0;
     int lst = 0, lslot = 0;
-    const unsigned char* lp[2] = {lib_bytes, lib_bytes};              // this lane's place in row 0 of the loader's two view groups
-    const unsigned char* lpv[2] = {lib_bytes, lib_bytes};             // and in their first V row when those are code rows
-    bool llive[2] = {false, false};
+    const unsigned char* lp[TL];                                        // this lane's place in row 0 of the loader's view group(s)
+    const unsigned char* lpv[TL];                                       // and in their first V row when those are code rows
+    bool llive[TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t) { lp[t] = lib_bytes; lpv[t] = lib_bytes; llive[t] = false; }
     auto loader_item = [&]() {                                          // (re)aim at item li
-        llive[0] = llive[1] = false;
+#pragma unroll
+        for (int t = 0; t < TL; ++t) llive[t] = false;
         if (li < n_mine) {
             const long long item = blockIdx.x + li * gridDim.x;
             const long long g0 = (item * G32) / GQ, g1 = ((item + 1) * G32) / GQ;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const long long g = g0 + lw + 4 * h;                    // slot lw + 4 h of the item's eight: consumer (lw + 4 h) / 2, tile (lw + 4 h) % 2
-                llive[h] = g < g1;
-                lp[h] = lib_bytes + (llive[h] ? g : g0) * gbytes + lane * 16;
-                lpv[h] = lib_bytes + (llive[h] ? g : g0) * gbytes + (long long)NK0 * 1024 + lane * 12;
+            for (int t = 0; t < TL; ++t) {
+                const long long g = g0 + lw + 4 * t;                    // slot lw + 4 t of the item's 4 TL: consumer (lw + 4 t) / TL, its group (lw + 4 t) % TL
+                llive[t] = g < g1;
+                lp[t] = lib_bytes + (llive[t] ? g : g0) * gbytes + lane * 16;
+                lpv[t] = lib_bytes + (llive[t] ? g : g0) * gbytes + (long long)NK0 * 1024 + lane * 12;
             }
         }
     };
@@ -3117,19 +3105,20 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
         const uint4* hot = coef4 + lw * 64 + lane;                      // re-read where there is nothing to fetch (hot in L2)
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            if (i < SK) {                                               // coefficient row (K-step kb + i, bit position lw)
-                int k = kb + i;
-                k = k < NKT ? k : NKT - 1;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((i * 4 + lw) * 1024));
-                lds_dma_16(li < n_mine ? coef4 + ((long long)k * 4 + lw) * 64 + lane : hot, dst);
-            } else {                                                    // library row (K-step kb + kk, slot lw + 4 h)
-                const int kk = (i - SK) >> 1, h = (i - SK) & 1;
+            if (i < SK * HT) {                                          // coefficient row (K-step kb + kk, heading tile h, bit position lw)
+                const int kk = i / HT, h = i % HT;
                 int k = kb + kk;
                 k = k < NKT ? k : NKT - 1;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + kk * 8 + lw + 4 * h) * 1024));
-                if (!llive[h]) lds_dma_16(hot, dst);
-                else if (codev && k >= NK0) lds_dma_12_nt(lpv[h] + (long long)(k - NK0) * 768, dst);
-                else lds_dma_16_nt(reinterpret_cast<const uint4*>(lp[h] + (long long)k * 1024), dst);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((kk * KCOEF + h * 4 + lw) * 1024));
+                lds_dma_16(li < n_mine ? coef4 + h * pass16 + ((long long)k * 4 + lw) * 64 + lane : hot, dst);
+            } else {                                                    // library row (K-step kb + kk, slot lw + 4 t)
+                const int kk = (i - SK * HT) / TL, t = (i - SK * HT) % TL;
+                int k = kb + kk;
+                k = k < NKT ? k : NKT - 1;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + kk * KLIB + lw + 4 * t) * 1024));
+                if (!llive[t]) lds_dma_16(hot, dst);
+                else if (codev && k >= NK0) lds_dma_12_nt(lpv[t] + (long long)(k - NK0) * 768, dst);
+                else lds_dma_16_nt(reinterpret_cast<const uint4*>(lp[t] + (long long)k * 1024), dst);
             }
         }
         lslot = lslot + 1 == RD ? 0 : lslot + 1;
@@ -3142,22 +3131,36 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
     }
 
     int cslot = 0;                                                      // ring slot of the consumers' current stage
+    int nfin = 0;                                                       // fused_finish calls so far (HT = 2: their parity)
+    (void)nfin;
+    int hconst[HT][2];                                                  // this lane's heading constants (fused_finish), per heading tile
+#pragma unroll
+    for (int h = 0; h < HT; ++h) { hconst[h][0] = 0; hconst[h][1] = 0; }
+    if (FUSE && !loader) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            const int a = a_off + 32 * h + (lane & 31), ac = a < fz.A_real ? a : fz.A_real - 1;
+            hconst[h][0] = fz.hsconst[ac];
+            hconst[h][1] = fz.vconst ? fz.vconst[ac] : 0;
+        }
+    }
     for (long long j = 0; j < n_mine; ++j) {
         const long long item = blockIdx.x + j * gridDim.x;
         const long long g0 = (item * G32) / GQ, g1 = ((item + 1) * G32) / GQ;
-        long long gidx[TILES];
-        bool live[TILES];
+        long long gidx[TL];
+        bool live[TL];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            const long long g = g0 + wave * TILES + t;
+        for (int t = 0; t < TL; ++t) {
+            const long long g = g0 + wave * TL + t;
             live[t] = !loader && g < g1;
             gidx[t] = live[t] ? g : g0;
         }
-        int tot_hs[TILES][16], tot_v[TILES][16];
+        // integer sums of the item: [u][r], u = view group t (HT = 1) or heading tile h (HT = 2)
+        int tot_hs[2][16], tot_v[2][16];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { tot_hs[t][r] = 0; tot_v[t][r] = 0; }
+            for (int r = 0; r < 16; ++r) { tot_hs[u][r] = 0; tot_v[u][r] = 0; }
         if (loader) {
             for (int st = 0; st < nst; ++st) {
                 wait_vmcnt_le<PER * (RD - 2)>();                        // this wave's rows of stage (j, st) have landed ...
@@ -3165,31 +3168,35 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                 issue_stage();                                          // (may belong to the next item: its pipeline fill)
             }
         } else {
-            v16f_t acc[TILES][4];
+            v16f_t acc[2][4];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
-            constexpr int READS = 4 + TILES;
-            v4u_t a[2][4], xl[2][TILES];
-            auto fetch = [&](int slot_i, auto kc) {
-                constexpr int k = decltype(kc)::value;
+                    for (int r = 0; r < 16; ++r) acc[u][s][r] = 0.f;
+            // operand registers of two units: unit q = (K-step q / HT, heading tile q % HT) lives in buffer q & 1; the library rows of
+            // a K-step in xl[k & 1] (read with the K-step's first unit)
+            v4u_t a[2][4], xl[2][TL];
+            auto fetch = [&](int slot_i, auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int k = q / HT, h = q % HT;
                 const unsigned sad = lds_base + (unsigned)slot_i * (unsigned)SLOTB + (unsigned)lane * 16u;
-                const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * TILES * 1024);
-                static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * 4 + s_) * 1024>(a[k & 1][s_], sad); });
-                static_for<TILES>([&](auto tc) { constexpr int t_ = decltype(tc)::value; lds_read16<(k * 8 + t_) * 1024>(xl[k & 1][t_], lad); });
+                static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * KCOEF + h * 4 + s_) * 1024>(a[q & 1][s_], sad); });
+                if constexpr (h == 0) {
+                    const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * TL * 1024);
+                    static_for<TL>([&](auto tc) { constexpr int t_ = decltype(tc)::value; lds_read16<(k * KLIB + t_) * 1024>(xl[k & 1][t_], lad); });
+                }
             };
             // bits stood for 0.5 / 1 / 2 / 1 (code rows: 0.5): signed counts 2 acc0, acc1, acc2 / 2, acc3 (code rows: 2 acc3) -- integers
-            auto flush = [&](int (&dst)[TILES][16], const int (&wd)[4], bool code) {
+            auto flush = [&](int (&dst)[2][16], const int (&wd)[4], bool code) {
                 const float f3 = code ? 2.f : 1.f;
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        dst[t][r] = __mul24(wd[0], (int)(2.f * acc[t][0][r])) + __mul24(wd[1], (int)acc[t][1][r]) + __mul24(wd[2], (int)(0.5f * acc[t][2][r])) +
-                                    __mul24(wd[3], (int)(f3 * acc[t][3][r]));
+                        dst[u][r] = __mul24(wd[0], (int)(2.f * acc[u][0][r])) + __mul24(wd[1], (int)acc[u][1][r]) + __mul24(wd[2], (int)(0.5f * acc[u][2][r])) +
+                                    __mul24(wd[3], (int)(f3 * acc[u][3][r]));
             };
             __builtin_amdgcn_s_barrier();                               // stage (j, 0) is in LDS
             if (j == 0) DV_STAMP(1);
@@ -3200,11 +3207,14 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                 for (int st = s0; st < s1; ++st) {
                     const int kb = st * SK;
                     const int nslot = cslot + 1 == RD ? 0 : cslot + 1;
-                    static_for<SK>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        if constexpr (k + 1 < SK) {
-                            fetch(cslot, IntC<k + 1>{});                // one K-step ahead
-                            lds_wait<READS>();                          // all but the newest READS reads have landed: K-step k's
+                    unsigned bo[4][4];                                  // HT = 2: the masked library operands of the K-step, made once for both heading tiles
+                    static_for<NU>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        constexpr int k = q / HT, h = q % HT;
+                        if constexpr (q + 1 < NU) {
+                            fetch(cslot, IntC<q + 1>{});                // one unit ahead
+                            if constexpr (((q + 1) % HT) == 0) lds_wait<4 + TL>();      // all but the newest unit's reads have landed
+                            else lds_wait<4>();
                         } else {
                             lds_wait<0>();                              // everything this wave will use of the slot is in registers
                             if (st + 1 < nst) {
@@ -3213,56 +3223,78 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                             }
                         }
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) lds_tie(a[k & 1][s]);
+                        for (int s = 0; s < 4; ++s) lds_tie(a[q & 1][s]);
+                        if constexpr (h == 0) {
 #pragma unroll
-                        for (int t = 0; t < TILES; ++t) lds_tie(xl[k & 1][t]);
+                            for (int t = 0; t < TL; ++t) lds_tie(xl[k & 1][t]);
+                        }
                         const bool on = kb + k < NKT;
-                        auto mfma = [&](int t, int s, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
-                            const v8i_t bo = v8i_t{(int)b0, (int)b1, (int)b2, (int)b3, 0, 0, 0, 0};
-                            const v4u_t& av = a[k & 1][s];
+                        auto mfma = [&](int u, int s, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+                            const v8i_t bv = v8i_t{(int)b0, (int)b1, (int)b2, (int)b3, 0, 0, 0, 0};
+                            const v4u_t& av = a[q & 1][s];
                             const v8i_t ao = v8i_t{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
-                            if constexpr (FUSE) acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bo, ao, acc[t][s], 4, 4, 0, 0, 0, 0);   // views x headings
-                            else acc[t][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[t][s], 4, 4, 0, 0, 0, 0);
+                            if constexpr (FUSE) acc[u][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bv, ao, acc[u][s], 4, 4, 0, 0, 0, 0);   // views x headings
+                            else acc[u][s] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bv, acc[u][s], 4, 4, 0, 0, 0, 0);
                         };
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) {
-                            unsigned x[4] = {xl[k & 1][t].x, xl[k & 1][t].y, xl[k & 1][t].z, xl[k & 1][t].w};
+                        // operand of bit position s from the library dwords x (thermometer rows), or of thermometer plane s (code rows)
+                        auto operand = [&](const unsigned (&x)[4], int s, unsigned (&o)[4]) {
                             if constexpr (!code_stage) {
+                                // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
+                                const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
+                                const int sh = s < 3 ? 0 : 2;
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) o[d] = (x[d] >> sh) & m;
+                            } else {
+                                // E2M1 operands of the four thermometer planes: t1, t4 as 0.5 (bit 0), t2 as 1 (bit 1), t3 as 2 (bit 2)
+                                const unsigned m = on ? 0x11111111u : 0u;
+#pragma unroll
+                                for (int d = 0; d < 4; ++d)
+                                    o[d] = s == 0 ? (x[d] | (x[d] >> 1)) & m : s == 1 ? x[d] & (m << 1) : s == 2 ? x[d] & (m << 2) : x[d] & (x[d] >> 2) & m;
+                            }
+                        };
+                        auto load_x = [&](int t, unsigned (&x)[4]) {
+                            x[0] = xl[k & 1][t].x; x[1] = xl[k & 1][t].y; x[2] = xl[k & 1][t].z; x[3] = xl[k & 1][t].w;
+                            if constexpr (code_stage)      // the fourth dword's pixels: bit 3 of the three code dwords' nibbles (the LDS-DMA left a hole there)
+                                x[3] = ((x[0] >> 3) & 0x11111111u) | ((x[1] >> 2) & 0x22222222u) | ((x[2] >> 1) & 0x44444444u);
+                        };
+                        if constexpr (HT == 1) {
+#pragma unroll
+                            for (int t = 0; t < TL; ++t) {
+                                unsigned x[4];
+                                load_x(t, x);
 #pragma unroll
                                 for (int s = 0; s < 4; ++s) {
-                                    // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
-                                    const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
-                                    const int sh = s < 3 ? 0 : 2;
-                                    mfma(t, s, (x[0] >> sh) & m, (x[1] >> sh) & m, (x[2] >> sh) & m, (x[3] >> sh) & m);
+                                    unsigned o[4];
+                                    operand(x, s, o);
+                                    mfma(t, s, o[0], o[1], o[2], o[3]);
                                 }
-                            } else {
-                                const unsigned m1 = 0x11111111u;
-                                const unsigned m = on ? m1 : 0u;
-                                // the fourth dword's pixels: bit 3 of the three code dwords' nibbles (the LDS-DMA left a hole there)
-                                x[3] = ((x[0] >> 3) & m1) | ((x[1] >> 2) & (m1 << 1)) | ((x[2] >> 1) & (m1 << 2));
-                                // E2M1 operands of the four thermometer planes: t1, t4 as 0.5 (bit 0), t2 as 1 (bit 1), t3 as 2 (bit 2)
-                                mfma(t, 0, (x[0] | (x[0] >> 1)) & m, (x[1] | (x[1] >> 1)) & m, (x[2] | (x[2] >> 1)) & m, (x[3] | (x[3] >> 1)) & m);
-                                mfma(t, 1, x[0] & (m << 1), x[1] & (m << 1), x[2] & (m << 1), x[3] & (m << 1));
-                                mfma(t, 2, x[0] & (m << 2), x[1] & (m << 2), x[2] & (m << 2), x[3] & (m << 2));
-                                mfma(t, 3, x[0] & (x[0] >> 2) & m, x[1] & (x[1] >> 2) & m, x[2] & (x[2] >> 2) & m, x[3] & (x[3] >> 2) & m);
                             }
+                        } else {
+                            if constexpr (h == 0) {
+                                unsigned x[4];
+                                load_x(0, x);
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) operand(x, s, bo[s]);
+                            }
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) mfma(h, s, bo[s][0], bo[s][1], bo[s][2], bo[s][3]);
                         }
                     });
                     cslot = nslot;
                 }
             };
             // HS stages (when the library has that segment), then the V stages; the accumulators change hands at the boundary
-            const int nst0 = has_hs_sum ? (NK0 / SK < nst ? NK0 / SK : nst) : 0;       // (NK0 is a whole number of stages; no V K-steps: all of them)
-            const int hs_end = (has_hs_sum && !(c.hasv && b.NK[1] > 0)) ? nst : nst0;
+            const int nst0 = has_hs_sum ? (NK0 / SK < nst ? NK0 / SK : nst) : 0;       // (NK0 is a whole number of stages)
+            const int hs_end = (has_hs_sum && !(c.hasv && b.NK[1] > 0)) ? nst : nst0; // (no V K-steps: all of them)
             run_stages(0, hs_end, IntC<0>{});
             if (hs_end > 0 && hs_end < nst) {
                 flush(tot_hs, b.wacc[0], false);
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[t][s][r] = 0.f;
+                        for (int r = 0; r < 16; ++r) acc[u][s][r] = 0.f;
             }
             if constexpr (CODE) run_stages(hs_end, nst, IntC<1>{});
             else run_stages(hs_end, nst, IntC<0>{});
@@ -3271,55 +3303,75 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
         }
         if (j == 0) DV_STAMP(2);
         if constexpr (!FUSE) {
-            const int nsum = has_hs_sum + c.hasv;
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
+            for (int u = 0; u < 2; ++u) {
+                const int t = HT == 1 ? u : 0, h = HT == 1 ? 0 : u;
+                const int rows = (apad_total - a_off - 32 * h) < 32 ? (apad_total - a_off - 32 * h) : 32;
                 if (live[t]) {
 #pragma unroll
                     for (int seg = 0; seg < 2; ++seg) {
                         if (seg == 0 ? !has_hs_sum : !c.hasv) continue;
                         const int type_row = seg ? has_hs_sum : 0;
-                        int* dst = part + ((long long)type_row * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
-                        (void)nsum;
+                        int* dst = part + ((long long)type_row * apad_total + a_off + 32 * h) * c.Fpad + gidx[t] * 32 + (lane & 31);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            if (m < rows) dst[(long long)m * c.Fpad] = seg ? tot_v[t][r] : tot_hs[t][r];
+                            if (m < rows) dst[(long long)m * c.Fpad] = seg ? tot_v[u][r] : tot_hs[u][r];
                         }
                     }
                 }
             }
         } else {
-            auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
-            auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
             if (j == 0) DV_STAMP(3);
-            fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, j, lane, wave, NC, loader);
+            if constexpr (HT == 1) {
+                auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
+                auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
+                fused_finish<TL, NW>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off, has_hs_sum, j, lane, wave, (int)(j & 1), NC, loader, hconst[0]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < HT; ++h) {
+                    auto of_hs = [&](int, int r) -> int { return tot_hs[h][r]; };
+                    auto of_v = [&](int, int r) -> int { return tot_v[h][r]; };
+                    if (a_off + 32 * h < fz.A_real)                     // (uniform: a heading tile without headings has nothing to finish)
+                        fused_finish<TL, NW>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, loader,
+                                             hconst[h], scratch0 + kFuseBlk + h * 64);
+                }
+            }
             if (j == 0) DV_STAMP(4);
         }
     }
     if (loader) wait_vmcnt_le<0>();                                     // the re-reads past the last item
-    if constexpr (FUSE) fused_block_end(scratch, fz, c, a_off);
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+            if (a_off + 32 * h < fz.A_real) fused_block_end(scratch0 + h * 64, fz, c, a_off + 32 * h);
+    }
     DV_STAMP(5);
 }
 
 // One launch, both forms: `offlevel` (k_patch_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form
 // reads ftiles (the code tiles when the library has them, else the bit tiles), the int8 form the bit tiles.
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE>
+template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE, int HT>
 __global__ void __launch_bounds__(512, 2)
 k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ ftiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4,
                 const unsigned* __restrict__ offlevel, int* __restrict__ part, LibCfg c, BitCfg b, int nchunk, int apad_total, int a_off,
                 int has_hs_sum, FuseArgs fz, int n_gq) {
-    if (__builtin_amdgcn_readfirstlane(*offlevel) == 0u) {
-        if constexpr (SKL > 0) {
-            static_assert(TILES == 1, "the loader / consumer body cuts the library into ranges of 8 view groups, like one group per wave");
-            if (nchunk == 1) {
-                sad_lc_fp4<SKL, RDL, FUSE, LCODE>(ftiles, coef4, part, c, b, apad_total, a_off, has_hs_sum, fz, n_gq);     // LCODE == (b.vcode != 0)
-                return;
-            }
+    // HT = 2: ONE launch covers the 64 headings at a_off (two heading tiles, coefficient images one pass apart); the bodies that
+    // multiply 32 headings per pass run twice
+    const bool fp4 = __builtin_amdgcn_readfirstlane(*offlevel) == 0u;
+    if constexpr (SKL > 0) {
+        static_assert(TILES == 1, "the loader / consumer body cuts the library into ranges of 8 / HT view groups; the other bodies must agree");
+        if (fp4 && nchunk == 1) {
+            sad_lc_fp4<SKL, RDL, FUSE, LCODE, HT>(ftiles, coef4, part, c, b, apad_total, a_off, has_hs_sum, fz, n_gq);     // LCODE == (b.vcode != 0)
+            return;
         }
-        sad_ring_fp4<SK4, TILES, RD4, SKC, RDC, FUSE>(ftiles, coef4, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz, n_gq);
-    } else {
-        sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef, part, c, b, nchunk, apad_total, a_off, has_hs_sum, fz, n_gq);
+    }
+    const int NKT = b.NK[0] + b.NK[1];
+#pragma unroll 1
+    for (int h = 0; h < HT; ++h) {
+        if (h > 0 && a_off + 32 * h >= apad_total) break;
+        if (fp4) sad_ring_fp4<SK4, TILES, RD4, SKC, RDC, FUSE>(ftiles, coef4 + (long long)h * NKT * 256, part, c, b, nchunk, apad_total, a_off + 32 * h, has_hs_sum, fz, n_gq);
+        else sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef + (long long)h * NKT * 512, part, c, b, nchunk, apad_total, a_off + 32 * h, has_hs_sum, fz, n_gq);
     }
 }
 

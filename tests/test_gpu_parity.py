@@ -514,12 +514,12 @@ def test_ssd_f32_metric_against_reference_ssds(eng, F, h, w, A):
         r = eng.step_f32(patches, want_scene=True)
         best_a = int(np.argmin(want.min(axis=1)))
         assert r["best_idex"] == best_a and r["best_view"] == int(np.argmin(want[best_a])), (exact, r["flags"])
-        np.testing.assert_allclose(r["angle_ssd"], want.min(axis=1), rtol=2e-6, atol=1e-12)      # north star: 1e-6 relative
-        np.testing.assert_allclose(r["scene_ssd"], want.max(axis=0), rtol=2e-6, atol=1e-12)
+        np.testing.assert_allclose(r["angle_ssd"], want.min(axis=1), rtol=1e-6, atol=1e-12)      # north star: 1e-6 relative
+        np.testing.assert_allclose(r["scene_ssd"], want.max(axis=0), rtol=1e-6, atol=1e-12)
         if exact:
             assert np.array_equal(r["angle_ssd"], want.min(axis=1))
         buf = eng.score_f32(patches[0])
-        np.testing.assert_allclose(buf, want[0], rtol=2e-6 if not exact else 0, atol=1e-12 if not exact else 0)
+        np.testing.assert_allclose(buf, want[0], rtol=1e-6 if not exact else 0, atol=1e-12 if not exact else 0)
     eng.set_exact(False)
     with pytest.raises(ValueError):
         eng.set_library_f32(lib.astype(np.float64))
