@@ -146,15 +146,18 @@ def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
                                what="dv_step_batch, %d bytes of patches uploaded each step" % patches.nbytes)
     finally:
         eng.close()
-    # sensed: a trained agent's engine (landscape + library of n_views sensed views resident), the ensemble's poses spread along the path
+    # sensed: the agents' patches come from the sensor model on the device (landscape resident, poses spread along a path); the
+    # library is the same synthetic one (views unrelated to the landscape: the work per step is what it is for any library of
+    # these levels, without the exact ties a library sensed every 0.02 px along one path would add)
     L = 2000
     land = synth.synth_landscape(seed, L, 4)
-    path = synth.sin_training_path(0.5, 0.2 * L, 0.6 * L, arclen=0.6 * L * 1.4 / n_views)[:n_views]
+    path = synth.sin_training_path(0.5, 0.2 * L, 0.6 * L, arclen=8.0)
     nsf = navsim_amd.NavBySceneFamiliarity(land, (w, h), 0.5, n_test_angles=A, n_sensor_levels=5,
                                            familiarity_model=navsim_amd.sads_familiarity(cw), track_scene_familiarity=False)
-    nsf.train_from_path(path)
+    e2 = nsf._engine
     try:
-        idx = np.linspace(5, len(path) - 50, n_agents).astype(int)
+        e2.generate_library(seed, n_views, h, w, chem_weight=cw)
+        idx = np.linspace(5, len(path) - 5, n_agents).astype(int)
         xs, ys, angs = [], [], []
         for i in idx:
             dd = path[i + 1] - path[i]
@@ -163,19 +166,20 @@ def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
             x, y, a = nsf.headings_to_test()
             xs.append(x); ys.append(y); angs.append(a)
         angs = np.stack(angs)
-        e2 = nsf._engine
         info = e2.library_info()
         planes = (info["bit_planes_hs"] + info["bit_planes_v"]) if info["has_bit_planes"] else 0
         for _ in range(3):
             e2.sense_step_batch(xs, ys, angs)
+        resolved = sum(1 for r in e2.sense_step_batch(xs, ys, angs) if r["flags"] & 1)
         t0 = time.perf_counter()
         for _ in range(2 * n_steps):
             e2.sense_step_batch(xs, ys, angs)
         dt = (time.perf_counter() - t0) / (2 * n_steps)
-        out["sensed"] = dict(view_comparisons_per_s=n_agents * A * len(path) / dt, ms_per_ensemble_step=dt * 1e3, library_views=len(path),
+        out["sensed"] = dict(view_comparisons_per_s=n_agents * A * n_views / dt, ms_per_ensemble_step=dt * 1e3, library_views=n_views,
+                             agents_resolved_exactly=resolved,
                              what="dv_sense_step_batch: patches sensed on the device, poses only go up")
     finally:
-        nsf.clear_training()
+        e2.close()
     best = out["sensed"]
     k_elems = float(planes) * h * w                                # K-elements per (view, heading): bit planes x pixels of the sensed library
     return dict(view_comparisons_per_s=best["view_comparisons_per_s"], agent_steps_per_s=n_agents / (best["ms_per_ensemble_step"] * 1e-3),
@@ -305,6 +309,8 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
     s_ref = 3 if cw > 0 else 1
     algo_bytes = float(F) * h * w * s_ref
     streamed = float(info["bit_tile_bytes"] if shape == 6 else info["tile_bytes"])
+    if shape == 6 and info.get("mixed_layout"):                  # + the saturation byte planes' share of the byte tiles
+        streamed += float(info["tile_bytes"]) * info["n_hue_planes"] / max(info["n_planes"], 1)
     nsum = (1 if info["n_hue_planes"] > 0 or info["generic_hue"] else 0) + (1 if info["has_value_plane"] else 0)
     apad = 8 if A <= 8 else (16 if A <= 16 else (32 if A <= 32 else 64))
     traffic = committed_traffic(workload, kernel)
@@ -338,6 +344,12 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
         ops = 2.0 * 32 * (((F + 63) // 64) * 64) * k_total * passes
         # the fp4 form (on-level patches) multiplies the same K-elements with v_mfma_f32_32x32x64_f8f6f4: twice the int8 peak
         peak = FP4_MFMA_PEAK_TOPS if form["fp4"] else I8_MFMA_PEAK_TOPS
+        if info.get("mixed_layout"):
+            lane_ops = float(apad) * F * h * w * info["n_hue_planes"] / 4.0
+            vpeak = 256 * 4 * 64 / 4.0 * CLOCK_PEAK_GHZ * 1e9
+            out["valu"] = {"lane_ops_per_launch": lane_ops, "achieved": lane_ops / t, "peak": vpeak, "unit": "v_sad_u8 lane-ops/s",
+                           "frac": lane_ops / t / vpeak, "clock_ghz_assumed": CLOCK_PEAK_GHZ,
+                           "what": "the saturation byte planes' pass (k_sad_tiles) behind the matrix-core pass on the value bits: the bound of this layout"}
         out["mfma"] = {"dtype": "fp4 (E2M1 signs x library bits, f32 accumulate, exact)" if form["fp4"] else "i8",
                        "ops_per_launch": ops, "achieved": ops / t / 1e12, "peak": peak,
                        "unit": "TOP/s", "frac": ops / t / 1e12 / peak,
@@ -356,12 +368,14 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
     return out
 
 
-def secondary_scoring(device_index, seed, F, h, w, A, cw, steps, warmup):
-    """One more workload on a fresh engine (N=1 only): value, step and kernel time, roofline."""
+def secondary_scoring(device_index, seed, F, h, w, A, cw, steps, warmup, full_range_s=False):
+    """One more workload on a fresh engine (N=1 only): value, step and kernel time, roofline.  full_range_s: the library's
+    saturation takes every value 0..127 (a swept concentration range) -- too many levels for thermometer planes, so the layout
+    is the mixed one: value bit planes on the matrix cores, then the saturation byte planes with v_sad_u8, k_finish on both."""
     import navsim_amd
     eng = navsim_amd.FamiliarityEngine(device=device_index)
     try:
-        eng.generate_library(seed, F, h, w, cw)
+        eng.generate_library(seed, F, h, w, cw, full_range_s=full_range_s)
         eng.generate_patches(seed, A)
         info = eng.library_info()
         for i in range(warmup):
@@ -386,7 +400,7 @@ def secondary_scoring(device_index, seed, F, h, w, A, cw, steps, warmup):
         eng.synchronize()
         dt_res = time.perf_counter() - t0
         shape = eng.workgroup_shape(A)
-        workload = workload_name(w, h, F, A, cw, 1)
+        workload = workload_name(w, h, F, A, cw, 1) + (", saturation 0..127 (mixed layout)" if full_range_s else "")
         return {"workload": workload, "value": F * A * steps / dt, "unit": "view-comparisons/s", "ms_per_step": dt / steps * 1e3,
                 "steps": steps, "workgroup_shape": shape,
                 "scoring_only": {"value": F * A * steps / dt_res, "ms_per_step": dt_res / steps * 1e3,
@@ -600,6 +614,11 @@ def main():
                 out["configs1"] = secondary_scoring(device_index, args.seed, 50000, 64, 64, 16, cw, 200, 20)
             except Exception as e:                               # noqa: BLE001 - an extra block must not cost the JSON line
                 out["configs1"] = {"error": repr(e)}
+        if extras and args.secondary:
+            try:
+                out["full_range_s"] = secondary_scoring(device_index, args.seed, F, h, w, A, cw, max(args.steps // 5, 5), 3, full_range_s=True)
+            except Exception as e:                               # noqa: BLE001
+                out["full_range_s"] = {"error": repr(e)}
         if extras and args.agent_steps > 0:
             try:
                 rates, n_lib, ens_rate, outliers = agent_steps_per_s(64, 64, 16, cw, 50000, args.seed, args.agent_steps)

@@ -99,6 +99,10 @@ typedef struct dv_lib_info {
     int32_t fp4_form;           /* 1: the planes also allow the fp4 form of that kernel (on-level patches, see dv_patches_on_level) */
     int64_t bit_tile_bytes;     /* bytes the matrix-core scoring kernel streams per pass (int8 form; fp4 form without code tiles) */
     int64_t code_tile_bytes;    /* bytes its fp4 form streams per pass when the value plane is stored as 3-bit level codes, else 0 */
+    int32_t mixed_layout;       /* 1: the saturation planes take too many values for bit planes: the matrix-core kernel scores the
+                                   value bit planes, a v_sad_u8 pass the saturation BYTE planes (bit_planes_hs is 0 and a step
+                                   streams bit_tile_bytes + the saturation planes' share of tile_bytes) */
+    int32_t reserved0;
 } dv_lib_info;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -131,6 +135,11 @@ int dv_append_library(dv_ctx *ctx, const uint8_t *views, int64_t n_views, int ch
 /* Same library as navsim_amd.synth.synth_views(seed, n_views, h, w, first_view), generated on the GPU. */
 int dv_generate_library(dv_ctx *ctx, uint64_t seed, int64_t n_views, int h, int w,
                         double chem_weight, int64_t first_view);
+/* The same with the saturation drawn from every value 0..127 (a swept concentration range, scripts/run_experiment.py:132,192)
+ * when full_range_s != 0: such a library keeps its saturation planes as bytes (dv_lib_info.mixed_layout).  dv_generate_patches
+ * then draws its patches' saturation the same way. */
+int dv_generate_library_ex(dv_ctx *ctx, uint64_t seed, int64_t n_views, int h, int w, double chem_weight, int64_t first_view,
+                           int full_range_s);
 int dv_clear_library(dv_ctx *ctx);
 int dv_get_library_info(const dv_ctx *ctx, dv_lib_info *out);
 /*

@@ -125,6 +125,8 @@ struct dv_ctx {
     float tuned_us[4][6] = {};                // what the timing saw per shape (DEJAVU_VERBOSE prints it)
     // bit-plane copy of the library for the int8 MFMA scoring path (k_sad_mfma), when its values come from few levels
     bool bits_ok = false;
+    bool mixed = false;                       // the bit tiles hold the V segment only; the saturation planes are scored as bytes (launch_int_scoring)
+    bool hs_bytes_pass = false;               // set while that byte pass is being launched (scoring_grid: one chunk, like the matrix-core pass)
     BitCfg bcfg{};
     uint4* d_btiles = nullptr;                // [Fpad/32][GS][64]
     size_t btile_bytes = 0;                   // of which streamed per pass: (Fpad/32) * (NK_hs + NK_v) KB
@@ -449,6 +451,7 @@ static int build_bit_planes(dv_ctx* c) {
     const LibCfg& g = c->cfg;
     c->bits_ok = false;
     c->fp4_ok = false;
+    c->mixed = false;
     if (c->bits_env == 0 || c->metric != 0 || g.generic) return DV_OK;
     unsigned* d_presence = nullptr;
     uint32_t presence[(kMaxHues + 1) * 8];
@@ -466,11 +469,23 @@ static int build_bit_planes(dv_ctx* c) {
     BitCfg b{};
     b.nbp = g.npl;
     int t = 0;
+    bool mixed = false;
+    static const int mixed_env = getenv("DEJAVU_MIXED") ? atoi(getenv("DEJAVU_MIXED")) : 1;
     for (int bp = 0; bp < g.npl; ++bp) {
         if (bp == g.nhs) b.T[0] = t;                                   // HS planes come first
         int lmin = 0, lmax = 0;
         const int n = plan_byte_plane(presence + bp * 8, kMaxBitPlanes - t, b.lo + t, b.w + t, &lmin, &lmax);
-        if (n < 0) return DV_OK;                                        // too many levels: byte path
+        if (n < 0) {
+            // Too many levels.  A saturation plane: the MIXED layout keeps ALL saturation planes as bytes (scored with v_sad_u8 by
+            // k_sad_tiles) and makes bit planes of the value plane only, scored on the matrix cores; the two passes meet in
+            // k_finish (launch_int_scoring).  The value plane: byte path.
+            if (bp >= g.nhs || !g.hasv || !mixed_env) return DV_OK;
+            mixed = true;
+            t = 0;
+            for (int k = 0; k < g.nhs; ++k) { b.lmin[k] = 0; b.lmax[k] = 255; }
+            bp = g.nhs - 1;                                             // on with the value plane
+            continue;
+        }
         for (int k = 0; k < n; ++k) b.pl[t + k] = (unsigned char)bp;
         b.lmin[bp] = (unsigned char)lmin;
         b.lmax[bp] = (unsigned char)lmax;
@@ -481,7 +496,7 @@ static int build_bit_planes(dv_ctx* c) {
     const int total = t;
     if (total == 0) return DV_OK;                                       // a constant library: nothing to stream either way
     // worth it when it streams at most 3/4 of the bytes (DEJAVU_BITS=2: whenever the planes fit)
-    if (c->bits_env == 1 && total * 4 > g.npl * 8 * 3) return DV_OK;
+    if (c->bits_env == 1 && (total + (mixed ? 8 * g.nhs : 0)) * 4 > g.npl * 8 * 3) return DV_OK;
     // a segment's sum must fit an int32 with room to spare
     for (int seg = 0; seg < 2; ++seg)
         if ((double)b.T[seg] * g.P * 127.0 > 1.9e9) return DV_OK;
@@ -490,7 +505,7 @@ static int build_bit_planes(dv_ctx* c) {
     // (fp4_segment's kflush); the padding K-steps hold no bits and no coefficients
     b.NK[0] = (b.NK[0] + 3) / 4 * 4;
     // Five value levels (four planes of the one value byte plane): the fp4 form may read them as 3-bit codes (k_bitpack_code)
-    const bool five_levels = c->fp4_env != 0 && c->vcode_env != 0 && g.hasv && b.T[1] == 4;
+    const bool five_levels = c->fp4_env != 0 && c->vcode_env != 0 && g.hasv && b.T[1] == 4 && !mixed;
     const int nkt = b.NK[0] + b.NK[1];
     b.GS = nkt | 1;
     // fp4 form of the kernel.  A gap wider than 127 was split for the int8 coefficients into planes that carry the same bits
@@ -505,6 +520,7 @@ static int build_bit_planes(dv_ctx* c) {
         if (T > 0 && !plan_fp4_segment(T, pres, b.lo + first, b.w + first, b.wfull + first, b.wacc[seg])) one_width = false;
     }
     c->fp4_ok = one_width && c->fp4_env != 0;
+    if (mixed && !c->fp4_ok) return DV_OK;                              // (the mixed form has the fp4 body only)
     const long long G32 = g.Fpad / 32;
     c->btile_bytes = (size_t)G32 * nkt * 1024;
     if (hipMalloc(&c->d_btiles, (size_t)G32 * b.GS * 1024) != hipSuccess || hipMalloc(&c->d_coef, (size_t)2 * nkt * 8192) != hipSuccess) {
@@ -532,10 +548,12 @@ static int build_bit_planes(dv_ctx* c) {
         pb.lmin[bp] = b.lmin[bp];
         for (int v = 0; v < 256; ++v) {
             const bool level = (presence[bp * 8 + (v >> 5)] >> (v & 31)) & 1u;
-            if (level || v <= (int)b.lmin[bp] || v >= (int)b.lmax[bp]) pb.ok[bp][v >> 5] |= 1u << (v & 31);
+            // (mixed: the saturation planes are scored as bytes, any patch byte goes)
+            if ((mixed && bp < g.nhs) || level || v <= (int)b.lmin[bp] || v >= (int)b.lmax[bp]) pb.ok[bp][v >> 5] |= 1u << (v & 31);
         }
     }
     c->pbits = pb;
+    c->mixed = mixed;
     b.vcode = 0;
     b.GSC = b.GS;
     if (c->fp4_ok && five_levels) {
@@ -1159,6 +1177,10 @@ extern "C" int dv_set_library_from_poses(dv_ctx* c, const double* x, const doubl
 }
 
 extern "C" int dv_generate_library(dv_ctx* c, uint64_t seed, int64_t F, int h, int w, double cw, int64_t first) {
+    return dv_generate_library_ex(c, seed, F, h, w, cw, first, 0);
+}
+
+extern "C" int dv_generate_library_ex(dv_ctx* c, uint64_t seed, int64_t F, int h, int w, double cw, int64_t first, int full_range_s) {
     int rc = check_lib_args(c, F, h, w, cw);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1166,6 +1188,7 @@ extern "C" int dv_generate_library(dv_ctx* c, uint64_t seed, int64_t F, int h, i
     const unsigned char hues[2] = {0, 127};   // synth.hsv_from_words: H = bit * 127, S > 0 in both
     rc = alloc_library(c, F, h, w, cw, first, 2, hues, 0, 127);     // synth: S is 0 or 127
     if (rc) { free_library(c); return rc; }
+    c->cfg.synth_full_s = full_range_s ? 1 : 0;
     const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.npl * c->cfg.Q * 64;
     hipLaunchKernelGGL(k_generate_tiles, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_tiles,
                        c->cfg, (unsigned long long)seed);
@@ -1233,6 +1256,7 @@ extern "C" int dv_get_library_info(const dv_ctx* c, dv_lib_info* o) {
     o->bit_planes_v = c->bits_ok ? c->bcfg.T[1] : 0;
     o->bit_tile_bytes = c->bits_ok ? (int64_t)c->btile_bytes : 0;
     o->code_tile_bytes = (c->bits_ok && c->bcfg.vcode) ? (int64_t)c->ctile_bytes : 0;
+    o->mixed_layout = (c->bits_ok && c->mixed) ? 1 : 0;
     return DV_OK;
 }
 
@@ -1308,6 +1332,7 @@ static dim3 scoring_grid(dv_ctx* c, int kernel_wpc, dim3& block, int wpb = 1, si
     long long n = c->target_items ? (c->target_items + G - 1) / G : slots / G;
     if (n < 1) n = 1;
     if (n > c->nchunk_cap) n = c->nchunk_cap;
+    if (c->hs_bytes_pass) n = 1;                                             // its sums share the matrix-core pass's one-chunk rows
     c->nchunk = (int)n;
     const long long n_items = G * n;
     block = dim3(64 * wpb);
@@ -1512,7 +1537,7 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     const int nk_min = c->bcfg.NK[1] > 0 ? (c->bcfg.NK[0] > 0 && c->bcfg.NK[0] < c->bcfg.NK[1] ? c->bcfg.NK[0] : c->bcfg.NK[1]) : c->bcfg.NK[0];
     while (nchunk > 1 && nk_min / nchunk < 4) --nchunk;                  // keep a few K-steps per chunk
     if (nchunk > c->nchunk_cap) nchunk = c->nchunk_cap;
-    if (nchunk < 1) nchunk = 1;
+    if (nchunk < 1 || c->mixed) nchunk = 1;                              // (mixed layout: the byte pass shares the one-chunk rows of the partial sums)
     c->nchunk = nchunk;
     // <int8 stage, ring | fp4 stage, ring (thermometer rows) | fp4 stage, ring (code rows), view groups per wave>.  Measured in
     // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
@@ -1541,9 +1566,30 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial,
     if (!g.generic && shape_now(c) == 6) {
         if (!c->coef_ready) { const int rc = enqueue_bit_prep(c, true); if (rc) return rc; }
         has_hs_sum = g.nhs > 0 ? 1 : 0;
+        if (c->mixed) {
+            // Mixed layout: the value segment on the matrix cores (its bit tiles hold nothing else: the kernel leaves zeros in the
+            // saturation rows of the partial sums), then the saturation byte planes with v_sad_u8 into those rows -- half the
+            // vector work of the byte path's two sums -- and k_finish on both.  Off-level value patches take the kernel's int8 form
+            // as always.
+            c->fuse_request = false;
+            launch_mfma(c, has_hs_sum);
+            HIP_TRY(c, hipGetLastError());
+            c->hs_bytes_pass = true;
+            const int keep = c->force_shape;
+            c->force_shape = c->APAD >= 16 ? 2 : 1;                       // four waves share an item and fold in LDS (tools/sweep_grid.sh)
+            switch (g.nhs) {
+                case 1: launch_tiles_apad<1, 0>(c); break;
+                case 2: launch_tiles_apad<2, 0>(c); break;
+                case 3: launch_tiles_apad<3, 0>(c); break;
+                default: launch_tiles_apad<4, 0>(c); break;
+            }
+            c->force_shape = keep;
+            c->hs_bytes_pass = false;
+            c->nchunk = 1;
+        } else
         launch_mfma(c, has_hs_sum);
         c->last_form = DV_FORM_MATRIX_CORES | (c->fp4_ok ? DV_FORM_FP4 : 0) | (c->epilogue_fused ? DV_FORM_FUSED_FINISH : 0);
-        c->int_hsconst = c->d_acc[c->acc_parity].bhs;
+        c->int_hsconst = c->mixed ? c->d_acc[c->acc_parity].hs : c->d_acc[c->acc_parity].bhs;
         c->int_vconst = c->d_acc[c->acc_parity].bv;
     } else if (g.generic) {
         has_hs_sum = 1;

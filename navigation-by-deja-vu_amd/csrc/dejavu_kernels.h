@@ -53,6 +53,7 @@ struct LibCfg {
     int hasv;           // value plane present
     int generic;        // H and S kept as planes (more than kMaxHues hues)
     int signed_s;       // two hues and every library S <= 127: ONE saturation plane holding 128 + (S of hue0) - (S of hue1)
+    int synth_full_s;   // the synthetic generators (dv_generate_library_ex, dv_generate_patches) draw S from 0..127 instead of {0, 127}
     unsigned char hues[kMaxHues];
     double cw;          // chem_weight
     double whs;         // 0.5 * cw          (util.pyx:59,68)
@@ -89,12 +90,12 @@ __host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long 
     return z ^ (z >> 31);
 }
 // Same bit fields as navsim_amd/synth.py:hsv_from_words.
-__device__ __forceinline__ void synth_hsv(unsigned long long z, unsigned& H, unsigned& S, unsigned& V) {
+__device__ __forceinline__ void synth_hsv(unsigned long long z, unsigned& H, unsigned& S, unsigned& V, int full_s = 0) {
     const unsigned lvl = (unsigned)(((z & 0xFFFFull) * 5ull) >> 16);
     const unsigned levels[5] = {0u, 63u, 127u, 191u, 255u};
     V = levels[lvl];
     H = (unsigned)((z >> 16) & 1ull) * 127u;
-    S = (unsigned)((z >> 17) & 1ull) * 127u;
+    S = full_s ? (unsigned)((z >> 17) & 0x7Full) : (unsigned)((z >> 17) & 1ull) * 127u;
 }
 // Byte stored in plane `pl` for a pixel (H,S,V).
 // Signed-saturation plane: with two hues, |S_s,0 - S_f,0| + |S_s,1 - S_f,1| = |x_s - x_f| for x = S_0 - S_1 (at most one of
@@ -242,7 +243,7 @@ __global__ void k_generate_tiles(uint4* __restrict__ tiles, LibCfg c, unsigned l
             const int px = q * 16 + i;
             if (px < c.P) {
                 unsigned H, S, V;
-                synth_hsv(splitmix64(base + (unsigned long long)px), H, S, V);
+                synth_hsv(splitmix64(base + (unsigned long long)px), H, S, V, c.synth_full_s);
                 w[i >> 2] |= plane_byte(c, pl, H, S, V) << (8 * (i & 3));
             }
         }
@@ -1960,7 +1961,7 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         if (MODE == 1) {
             if (!sense_pixel(land, g, poses.p[a], s_lut, px / g.sw, px % g.sw, H, S, V)) { sense_err = true; H = S = V = 0; }
         } else if (MODE == 2) {
-            synth_hsv(splitmix64((unsigned long long)((long long)a * c.P + px) + (seed + 1ull) * 0x9E3779B97F4A7C15ull), H, S, V);
+            synth_hsv(splitmix64((unsigned long long)((long long)a * c.P + px) + (seed + 1ull) * 0x9E3779B97F4A7C15ull), H, S, V, c.synth_full_s);
         } else {
             const unsigned char* r = raw + ((long long)a * c.P + px) * 3;
             H = r[0]; S = r[1]; V = r[2];

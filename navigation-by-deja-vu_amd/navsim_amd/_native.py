@@ -67,6 +67,8 @@ class LibInfo(ctypes.Structure):
         ("fp4_form", ctypes.c_int32),
         ("bit_tile_bytes", ctypes.c_int64),
         ("code_tile_bytes", ctypes.c_int64),
+        ("mixed_layout", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -99,6 +101,8 @@ PROTOTYPES = {
                                       ctypes.c_double, ctypes.c_int64]),
     "dv_generate_library": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_int64]),
+    "dv_generate_library_ex": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_double, ctypes.c_int64, ctypes.c_int]),
     "dv_append_library": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64, ctypes.c_int]),
     "dv_append_library_from_poses": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int64, _u8p]),
     "dv_clear_library": (ctypes.c_int, [_ctx_p]),

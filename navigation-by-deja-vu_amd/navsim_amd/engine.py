@@ -68,10 +68,10 @@ class FamiliarityEngine(object):
                                              int(first_view)), "dv_set_library")
         self.n_views, self.shape = F, (h, w)
 
-    def generate_library(self, seed, n_views, h, w, chem_weight=0.0, first_view=0):
-        """Same bytes as synth.synth_views(seed, n_views, h, w, first_view), generated in HBM."""
-        self._check(self._lib.dv_generate_library(self._ctx, int(seed), int(n_views), int(h), int(w),
-                                                  float(chem_weight), int(first_view)), "dv_generate_library")
+    def generate_library(self, seed, n_views, h, w, chem_weight=0.0, first_view=0, full_range_s=False):
+        """Same bytes as synth.synth_views(seed, n_views, h, w, first_view, full_range_s), generated in HBM."""
+        self._check(self._lib.dv_generate_library_ex(self._ctx, int(seed), int(n_views), int(h), int(w), float(chem_weight),
+                                                     int(first_view), 1 if full_range_s else 0), "dv_generate_library_ex")
         self.n_views, self.shape = int(n_views), (int(h), int(w))
 
     def append_library(self, scenes):
@@ -106,7 +106,7 @@ class FamiliarityEngine(object):
                     chem_weight=info.chem_weight, delta=info.delta, hues=[int(x) for x in info.hues][:info.n_hues],
                     signed_saturation=bool(info.signed_saturation), has_bit_planes=bool(info.has_bit_planes),
                     bit_planes_hs=info.bit_planes_hs, bit_planes_v=info.bit_planes_v, bit_tile_bytes=info.bit_tile_bytes,
-                    fp4_form=bool(info.fp4_form), code_tile_bytes=info.code_tile_bytes)
+                    fp4_form=bool(info.fp4_form), code_tile_bytes=info.code_tile_bytes, mixed_layout=bool(info.mixed_layout))
 
     def read_planes(self, v0, n):
         info = self.library_info()

@@ -35,16 +35,20 @@ def _pixel_words(seed, first_pixel, n_pixels):
         return splitmix64(idx + np.uint64(seed) * GOLDEN)
 
 
-def hsv_from_words(z):
-    """Map hash words to (H, S, V) bytes; same bit fields as k_generate_tiles."""
+def hsv_from_words(z, full_range_s=False):
+    """Map hash words to (H, S, V) bytes; same bit fields as k_generate_tiles.  full_range_s: the saturation takes every
+    value 0..127 (a swept concentration range, scripts/run_experiment.py:132,192) instead of {0, 127}."""
     lvl = ((z & np.uint64(0xFFFF)) * np.uint64(5)) >> np.uint64(16)
     v = V_LEVELS[lvl.astype(np.int64)]
     h = (((z >> np.uint64(16)) & np.uint64(1)) * np.uint64(127)).astype(np.uint8)
-    s = (((z >> np.uint64(17)) & np.uint64(1)) * np.uint64(127)).astype(np.uint8)
+    if full_range_s:
+        s = ((z >> np.uint64(17)) & np.uint64(0x7F)).astype(np.uint8)
+    else:
+        s = (((z >> np.uint64(17)) & np.uint64(1)) * np.uint64(127)).astype(np.uint8)
     return h, s, v
 
 
-def synth_views(seed, n_views, h, w, first_view=0):
+def synth_views(seed, n_views, h, w, first_view=0, full_range_s=False):
     """uint8[n_views, h, w, 3] HSV views; view f depends only on (seed, first_view + f)."""
     npx = h * w
     out = np.empty((n_views, npx, 3), dtype=np.uint8)
@@ -53,7 +57,7 @@ def synth_views(seed, n_views, h, w, first_view=0):
     for f0 in range(0, n_views, slab):
         f1 = min(n_views, f0 + slab)
         z = _pixel_words(seed, (first_view + f0) * npx, (f1 - f0) * npx)
-        hh, ss, vv = hsv_from_words(z)
+        hh, ss, vv = hsv_from_words(z, full_range_s)
         o = out[f0:f1].reshape(-1, 3)
         o[:, 0] = hh
         o[:, 1] = ss
@@ -61,9 +65,9 @@ def synth_views(seed, n_views, h, w, first_view=0):
     return out.reshape(n_views, h, w, 3)
 
 
-def synth_patches(seed, n_headings, h, w):
+def synth_patches(seed, n_headings, h, w, full_range_s=False):
     """uint8[A, h, w, 3] sensor patches: the same distribution, stream seed+1."""
-    return synth_views(seed + 1, n_headings, h, w)
+    return synth_views(seed + 1, n_headings, h, w, full_range_s=full_range_s)
 
 
 def near_match_patch(view, seed, fraction=0.01):

@@ -179,6 +179,12 @@ SHAPES = [
     (150, 9, 13, 12, 0.35, "signed"),
     (90, 16, 16, 16, 1.0, "signed"),
     (70, 8, 8, 5, 0.5, "twohues_big_s"),
+    # many saturation values, few value levels: the mixed layout (value bit planes on the matrix cores + saturation bytes)
+    (900, 16, 16, 12, 0.35, "mixed_signed"),
+    (5000, 16, 16, 33, 0.3, "mixed_signed"),
+    (700, 12, 20, 32, 0.5, "mixed_threehues"),
+    (600, 16, 16, 9, 0.25, "mixed_offv"),
+    (2100, 9, 13, 5, 1.0, "mixed_signed"),
 ]
 
 
@@ -187,6 +193,17 @@ def make_inputs(F, h, w, A, kind, seed):
         return synth.synth_views(seed, F, h, w), synth.synth_patches(seed, A, h, w)
     lib = synth.random_hsv(seed, (F, h, w, 3))
     pat = synth.random_hsv(seed + 1, (A, h, w, 3))
+    if kind.startswith("mixed"):     # value in five levels, saturation in many
+        lib[..., 2] = synth.V_LEVELS[lib[..., 2] % 5]
+        pat[..., 2] = synth.V_LEVELS[pat[..., 2] % 5] if kind != "mixed_offv" else pat[..., 2]
+        if kind == "mixed_threehues":
+            lib[..., 0] = (lib[..., 0] % 3) * 40
+            pat[..., 0] = (pat[..., 0] % 4) * 40
+        else:                        # two hues, S <= 127: one signed saturation plane with ~255 values
+            lib[..., 0] = np.where(lib[..., 0] & 1, 200, 10)
+            lib[..., 1] >>= 1
+            pat[..., 0] = np.where(pat[..., 0] & 1, 200, 10)
+        return lib, pat
     if kind == "manyhues":           # > 4 hues with S > 0: generic-hue layout
         lib[..., 0] &= 0x0F
         pat[..., 0] &= 0x0F
@@ -221,12 +238,21 @@ def test_ragged_shapes_against_oracle(eng, F, h, w, A, cw, kind):
         assert info["signed_saturation"] and info["n_hue_planes"] == 1
     if kind == "twohues_big_s":
         assert not info["signed_saturation"] and info["n_hue_planes"] == 2
+    if kind.startswith("mixed") and eng.mode == "mfma+fold" and 0.0 < cw < 1.0:
+        assert info["mixed_layout"] and info["bit_planes_hs"] == 0 and info["bit_planes_v"] == 4, info
     want = oracle.step(lib, pat, cw)
     for exact in (False, True):
         eng.set_exact(exact)
         got = eng.step(pat, want_scene=True)
         assert got["best_idex"] == want["best_idex"], (exact, got["n_candidates"], got["flags"])
         assert got["best_view"] == want["best_view"]
+        if not exact:                                            # the step as the agent runs it (finished inside the scoring kernel where it can be)
+            fused = eng.step(pat, want_scene=False)
+            assert (fused["best_idex"], fused["best_view"]) == (want["best_idex"], want["best_view"])
+            assert np.array_equal(fused["angle_familiarity"], got["angle_familiarity"]) and np.array_equal(fused["angle_view"], got["angle_view"])
+            if kind.startswith("mixed") and eng.mode == "mfma+fold" and 0.0 < cw < 1.0:
+                form = eng.scoring_form()
+                assert form["matrix_cores"] and not form["fused_finish"], form      # two passes (value bits, saturation bytes) meet in k_finish
         np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL, atol=1e-12)
         np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=RTOL, atol=1e-12)
         if exact:
