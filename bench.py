@@ -420,6 +420,8 @@ def main():
     ap.add_argument("--headings", type=int, default=32)
     ap.add_argument("--chem-weight", type=float, default=0.25,
                     help="0 < cw < 1 keeps all three reference bytes per pixel (H,S,V) algorithmically live")
+    ap.add_argument("--full-range-s", action="store_true", help="headline library with saturation 0..127 instead of {0, 127}: the "
+                    "mixed layout (value bit planes + saturation bytes); the default run times it as the `full_range_s` block")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--cpu-views", type=int, default=8000, help="views in the CPU-baseline sample (0 = skip); the "
                     "default is ~15 s of one host core at the headline shape")
@@ -477,7 +479,7 @@ def main():
 
     F, h, w, A, cw = args.views, args.sensor, args.sensor, args.headings, args.chem_weight
     eng = navsim_amd.FamiliarityEngine(device=device_index)
-    eng.generate_library(args.seed, F, h, w, cw, first_view=rank * F)     # this rank's shard, made in HBM
+    eng.generate_library(args.seed, F, h, w, cw, first_view=rank * F, full_range_s=args.full_range_s)     # this rank's shard, made in HBM
     eng.generate_patches(args.seed, A)                                     # same patches on every rank
     info = eng.library_info()
 
@@ -527,8 +529,8 @@ def main():
     # decision has to come through the exchange (a stale or mis-ordered record gives the previous answer instead).
     from navsim_amd import synth
     a_star, f_star = A // 2, (world - 1) * F + (12345 % F)
-    probe = synth.synth_patches(args.seed, A, h, w)
-    probe[a_star] = synth.synth_views(args.seed, 1, h, w, first_view=f_star)[0]
+    probe = synth.synth_patches(args.seed, A, h, w, full_range_s=args.full_range_s)
+    probe[a_star] = synth.synth_views(args.seed, 1, h, w, first_view=f_star, full_range_s=args.full_range_s)[0]
     eng.upload_patches(probe)
     chk = one_step()
     ok = args.skip_known_answer or ((int(chk["best_idex"]), int(chk["best_view"])) == (a_star, f_star) and
@@ -554,7 +556,7 @@ def main():
         comparisons = float(world) * F * A * args.steps
         kern_ms = kern_ms_total / max(kern_n, 1)
         shape = eng.workgroup_shape(A)
-        workload = workload_name(w, h, F, A, cw, world)
+        workload = workload_name(w, h, F, A, cw, world) + (", saturation 0..127 (mixed layout)" if args.full_range_s else "")
         out = {
             "metric": "view-comparisons/sec (sensor x library x headings)",
             "value": comparisons / dt,
@@ -614,7 +616,7 @@ def main():
                 out["configs1"] = secondary_scoring(device_index, args.seed, 50000, 64, 64, 16, cw, 200, 20)
             except Exception as e:                               # noqa: BLE001 - an extra block must not cost the JSON line
                 out["configs1"] = {"error": repr(e)}
-        if extras and args.secondary:
+        if extras and args.secondary and not args.full_range_s:
             try:
                 out["full_range_s"] = secondary_scoring(device_index, args.seed, F, h, w, A, cw, max(args.steps // 5, 5), 3, full_range_s=True)
             except Exception as e:                               # noqa: BLE001

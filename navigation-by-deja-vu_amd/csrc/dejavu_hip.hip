@@ -83,6 +83,7 @@ struct dv_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;         // the agent's error / coverage metrics (k_path_error): beside the steps, not between them
     std::string err;
     int exact = 0;
 
@@ -261,6 +262,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     if (!c) return fail(nullptr, DV_ERR_OOM, "dv_create: out of host memory");
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->t0);
     if (e == hipSuccess) e = hipEventCreate(&c->t1);
     if (e != hipSuccess) {
@@ -310,6 +312,7 @@ extern "C" void dv_destroy(dv_ctx* c) {
     for (auto e : c->pev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -2062,6 +2065,7 @@ extern "C" int dv_set_training_path(dv_ctx* c, const double* xy, int64_t n) {
     if (!c) return DV_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     if (c->d_path) { (void)hipFree(c->d_path); c->d_path = nullptr; }
     if (c->d_cover) { (void)hipFree(c->d_cover); c->d_cover = nullptr; }
     c->n_path = 0;
@@ -2093,7 +2097,8 @@ extern "C" int dv_path_error_enqueue(dv_ctx* c, double x, double y, double reach
     const unsigned long long seq = ++c->err_enq;
     long long nb = (c->n_path + 255) / 256;
     if (nb > 512) nb = 512;
-    hipLaunchKernelGGL(k_path_error, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_path, (long long)c->n_path, x, y, reach,
+    // on its own stream: the answer is collected a step later (dv_path_error_wait), so it runs beside the next step's kernels
+    hipLaunchKernelGGL(k_path_error, dim3((unsigned)nb), dim3(256), 0, c->aux_stream, c->d_path, (long long)c->n_path, x, y, reach,
                        c->d_cover, c->d_errstate, c->d_errout + (seq % kErrRing), seq);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
@@ -2114,7 +2119,7 @@ extern "C" int dv_path_error_wait(dv_ctx* c, double* nearest) {
     }
     if (!seen) {
         HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
         if (*word != seq) return fail(c, DV_ERR_STATE, "the path-error answer never arrived");
     }
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -2127,6 +2132,7 @@ extern "C" int dv_path_coverage(dv_ctx* c, uint8_t* out, int64_t n) {
     if (!c || !out) return DV_ERR_INVALID;
     if (c->n_path < 1 || n != c->n_path) return fail(c, DV_ERR_STATE, "no training path of %lld points set", (long long)n);
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_cover, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DV_OK;
@@ -2137,6 +2143,7 @@ extern "C" int dv_path_reset(dv_ctx* c) {
     if (c->n_path < 1) return DV_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     c->err_deq = c->err_enq;                                     // answers of the run being abandoned are dropped
     HIP_TRY(c, hipMemsetAsync(c->d_cover, 0, (size_t)c->n_path, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
