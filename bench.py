@@ -314,6 +314,9 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
     nsum = (1 if info["n_hue_planes"] > 0 or info["generic_hue"] else 0) + (1 if info["has_value_plane"] else 0)
     apad = 8 if A <= 8 else (16 if A <= 16 else (32 if A <= 32 else 64))
     traffic = committed_traffic(workload, kernel)
+    if traffic and shape == 6 and info.get("mixed_layout"):      # two scoring kernels per step: + the saturation byte pass
+        t2 = committed_traffic(workload, "k_sad_tiles")
+        traffic = (traffic[0] + t2[0], traffic[1] + " (k_sad_mfma_dual + k_sad_tiles)") if t2 else None
     moved = traffic[0] if traffic else None
     t = kern_ms * 1e-3
     # partial sums written once per chunk; their count is the engine's choice, so only a lower bound (one chunk) is

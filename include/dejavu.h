@@ -331,7 +331,7 @@ int dv_profile_kernel(dv_ctx *ctx, int enable);
 /* Sum and count of the bracketed scoring-kernel launches since the last read; resets. */
 int dv_profile_read(dv_ctx *ctx, double *total_ms, int64_t *n_launches);
 /* Workgroup shape of the scoring kernel in use for steps of n_headings headings on the resident library (1..5: forms
- * of the byte-plane kernels, csrc/dejavu_hip.hip:launch_tiles_apad; 6: the bit-plane matrix-core kernel k_sad_mfma;
+ * of the byte-plane kernels, csrc/dejavu_hip.hip:launch_tiles_apad; 6: the bit-plane matrix-core kernel k_sad_mfma_dual (mixed layout: + a v_sad_u8 pass over the saturation byte planes);
  * 0 = not timed yet, or not applicable to this library). */
 int dv_workgroup_shape(dv_ctx *ctx, int n_headings, int *shape);
 /* Streaming-read microbenchmark over n_bytes of device memory (achievable HBM ceiling). */

@@ -49,7 +49,7 @@ def step_case_inputs(case):
 # Forms of the scoring path every GPU engine test runs under.  The engine reads these variables when it is created.
 #   k_finish / k_combine+k_tail : the two ways a step ends (DEJAVU_FINISH=2 / 0), byte-plane kernels timed as usual;
 #   mfma    : the bit-plane copy is built whenever the library's values allow it (DEJAVU_BITS=2) and scored on the matrix
-#             cores (DEJAVU_SHAPE=6, k_sad_mfma); libraries it cannot describe fall back to the byte-plane kernels;
+#             cores (DEJAVU_SHAPE=6, k_sad_mfma_dual); libraries it cannot describe fall back to the byte-plane kernels;
 #             finishing epilogue outside the kernel (DEJAVU_FUSE=0), int8 coefficients only (DEJAVU_FP4=0);
 #   mfma+fold : the matrix-core kernel as it ships: the fp4 form where the patches sit on the library's levels, the
 #             finishing epilogue inside the kernel, the step ends in k_fold;

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def eng():
-    e = navsim_amd.FamiliarityEngine(0)                  # DEJAVU_FINISH=2 for the GPU suite: tests/conftest.py
+    e = navsim_amd.FamiliarityEngine(0)                  # the product default (nothing forced)
     yield e
     e.close()
 

@@ -578,7 +578,7 @@ def test_ssd_f32_ties_and_duplicates(eng):
 @pytest.mark.parametrize("A", [5, 16, 30, 64])
 def test_every_workgroup_shape_gives_identical_results(A):
     """The scoring kernel's forms (1 single-wave, 2 four waves + LDS sums, 3/4 heading ways, 5 packed accumulators;
-    csrc/dejavu_hip.hip:launch_tiles_apad; 6 the bit-plane matrix-core kernel k_sad_mfma) are normally chosen by timing; forced one by one they must produce the same
+    csrc/dejavu_hip.hip:launch_tiles_apad; 6 the bit-plane matrix-core kernel k_sad_mfma_dual) are normally chosen by timing; forced one by one they must produce the same
     integer sums, hence bit-identical scores and the reference's decision."""
     import os
     F, h, w, cw = 1500, 20, 24, 0.25
@@ -1174,7 +1174,7 @@ def test_fp4_form_gives_the_int8_forms_sums(F, h, w, A, cw, tiles):
 
 
 def test_off_level_patches_take_the_int8_form_in_the_same_launch():
-    """A patch byte strictly inside a gap of the library's levels has no fp4 coefficient: k_bit_prep flags the prep and
+    """A patch byte strictly inside a gap of the library's levels has no fp4 coefficient: k_patch_prep flags the prep and
     the same launch scores with the int8 image.  Alternating on-level and off-level patch sets on one engine: every
     step against the oracle, and the flag follows the patches."""
     F, h, w, A, cw = 6000 + 5, 24, 16, 12, 0.4

@@ -1,26 +1,9 @@
-# A/B runs of bench.py under env settings: one line per run
+# A/B runs of bench.py's headline under env settings, one line per run (edit the `run` lines)
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ab
-run() {   # name, bench args...; env in front
-  name=$1; shift
-  timeout -k 10 240 python bench.py "$@" --cpu-views 0 --batch-agents 0 --secondary 0 --agent-steps 0 > gpurun_out/ab/$name.json 2> gpurun_out/ab/$name.err || echo "$name FAILED"
-  python - "$name" <<'PY'
-import json,sys
-n=sys.argv[1]
-try:
-    d=json.loads(open('gpurun_out/ab/%s.json'%n).read().strip().splitlines()[-1])
-    print("%-22s step %8.1f us  scoring_only %8.1f us  kernel %8.1f us  frac %.3f" % (n, d['ms_per_step']*1e3, d['scoring_only']['ms_per_step']*1e3, d['roofline']['kernel_ms']*1e3, d['roofline']['frac']))
-except Exception as e:
-    print(n, "no result", e)
-PY
-}
-C1="--views 50000 --sensor 64 --headings 16 --steps 300 --warmup 30 --event-every 4"
-C2="--steps 40 --warmup 5"
-DEJAVU_BALANCE=0 run c1_bal0 $C1
-DEJAVU_BALANCE=1 run c1_bal1 $C1
-DEJAVU_BALANCE=1 DEJAVU_RING=1 run c1_bal1_ring1 $C1
-DEJAVU_BALANCE=1 DEJAVU_RING=2 run c1_bal1_ring2 $C1
-DEJAVU_BALANCE=0 DEJAVU_RING=1 run c1_bal0_ring1 $C1
-DEJAVU_BALANCE=0 run c2_bal0 $C2
-DEJAVU_BALANCE=1 run c2_bal1 $C2
-DEJAVU_BALANCE=0 run c2_bal0_again $C2
+source tools/runs/r3_ab_fn.sh
+DEJAVU_LC=0 run c1_lc0 $C1
+DEJAVU_LC=1 run c1_lc1 $C1
+DEJAVU_LC=1 DEJAVU_BALANCE=1 run c1_lc1_bal $C1
+DEJAVU_LC=0 run c2_lc0 $C2
+DEJAVU_LC=1 run c2_lc1 $C2
+DEJAVU_LC=1 DEJAVU_VCODE=1 run c2_lc1_code $C2
