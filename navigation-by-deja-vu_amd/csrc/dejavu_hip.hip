@@ -507,6 +507,8 @@ static int build_bit_planes(dv_ctx* c) {
     // the HS K-steps in whole stages of the fp4 ring (2 or 4 K-steps): the item then runs as one loop through both segments
     // (fp4_segment's kflush); the padding K-steps hold no bits and no coefficients
     b.NK[0] = (b.NK[0] + 3) / 4 * 4;
+    // and the V K-steps in whole stages of four too: the code tiles store a stage's code dwords together (k_bitpack_code)
+    b.NK[1] = (b.NK[1] + 3) / 4 * 4;
     // Five value levels (four planes of the one value byte plane): the fp4 form may read them as 3-bit codes (k_bitpack_code)
     const bool five_levels = c->fp4_env != 0 && c->vcode_env != 0 && g.hasv && b.T[1] == 4 && !mixed;
     const int nkt = b.NK[0] + b.NK[1];
@@ -1458,37 +1460,34 @@ static FuseArgs fuse_args(const dv_ctx* c) {
 }
 
 // View-group ranges (items per chunk) the library is cut into for a workgroup of 8 waves x TILES groups: as few as hold it,
-// ceil(G32 / VW), of equal size to within one group.  DEJAVU_BALANCE=1 (A/B) cuts finer -- one range per CU for small
-// libraries, whole rounds of the 256 resident workgroups for large ones -- which measured SLOWER (50 000 views x 64x64: ring
-// loop 28.7 -> 30.3 us; 500 000 x 128x128: 1.026 -> 1.035 ms): a workgroup's time per K-step does not depend on how many of
-// its waves have a group (tools/exp/stamps.py), so idle CUs cost less than waves that only keep the ring's bookkeeping going.
+// ceil(G32 / VW), of equal size to within one group -- 500 000 views x 128x128: 7.63 ranges of 8 per workgroup, so 94 of the 256
+// workgroups sit out the eighth round.  Two finer cuts were measured and are SLOWER, because a range takes its consumers' time per
+// stage whatever the bytes it streams (tools/exp/stamps.py):
+//   round 2: every range finer (one per CU for small libraries, whole rounds of the 256 workgroups for large ones): 50 000 views x
+//     64x64 ring loop 28.7 -> 30.3 us, 500 000 x 128x128 1.026 -> 1.035 ms;
+//   round 3: whole ranges of 8 for the whole rounds and only the last round's cut evenly over all 256 workgroups: every workgroup
+//     then ends within 50 us of the others, but later -- 500 000 views 0.969 -> 0.977 ms, 50 000 views loop 26.8 -> 28.1 us.
 static long long item_groups(long long G32, int VW) {
-    const long long n = (G32 + VW - 1) / VW;
-    static const int balance = getenv("DEJAVU_BALANCE") ? atoi(getenv("DEJAVU_BALANCE")) : 0;
-    if (!balance) return n;
-    if (n < 256) return G32 < 256 ? G32 : 256;
-    const long long up = (n + 255) / 256 * 256;
-    return n * 4 >= up * 3 ? up : n;
+    return (G32 + VW - 1) / VW;
 }
 
 // Both forms in one launch (k_sad_mfma_dual): the fp4 form when this prep's patches sit on the library's levels (the
 // device decides, offlevel_word); libraries without an fp4 form point that word at a constant 1 and pass no fp4 image.
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE, int HT>
+template <int SK8, int RD8, int SK4, int RD4, int TILES, bool FUSE, int SKL, int RDL, bool LCODE, int HT>
 static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     static bool attr_set = false;
     const size_t lds8 = (size_t)RD8 * (SK8 * 8 + 8 * SK8 * TILES) * 1024;
-    const size_t lds4 = (size_t)fp4_ring_bytes(SK4, TILES, RD4, false), ldsc = (size_t)fp4_ring_bytes(SKC, TILES, RDC, true);
+    const size_t lds4 = (size_t)fp4_ring_bytes(SK4, TILES, RD4);
     size_t lds = lds8 > lds4 ? lds8 : lds4;
-    if (ldsc > lds) lds = ldsc;
     if constexpr (SKL > 0) {
         constexpr int lcb = lc_ring_bytes<SKL, RDL>();
         static_assert(lcb + kFuseScratchBytes + (HT - 1) * 512 <= 160 * 1024, "LDS");
         if ((size_t)lcb > lds) lds = (size_t)lcb;
     }
     lds += FUSE ? (size_t)kFuseScratchBytes + (HT - 1) * 512 : 0;     // (a second heading tile adds its 64 running-summary words)
-    static_assert(fp4_ring_bytes(SKC, TILES, RDC, true) + kFuseScratchBytes <= 160 * 1024 && fp4_ring_bytes(SK4, TILES, RD4, false) + kFuseScratchBytes <= 160 * 1024, "LDS");
+    static_assert(fp4_ring_bytes(SK4, TILES, RD4) + kFuseScratchBytes <= 160 * 1024, "LDS");
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_sad_mfma_dual<SK8, RD8, SK4, RD4, TILES, FUSE, SKL, RDL, LCODE, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long long G32 = c->cfg.Fpad / 32;
@@ -1499,18 +1498,18 @@ static void launch_mfma_dual_f(dv_ctx* c, int nchunk, int has_hs) {
     FuseArgs fz{};
     if (FUSE) { fz = fuse_args(c); fz.nb = (int)grid; }
     for (int a_off = 0; a_off < c->APAD; a_off += 32 * HT)
-        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, SKC, RDC, TILES, FUSE, SKL, RDL, LCODE, HT>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
+        hipLaunchKernelGGL((k_sad_mfma_dual<SK8, RD8, SK4, RD4, TILES, FUSE, SKL, RDL, LCODE, HT>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles,
                            c->bcfg.vcode ? c->d_ctiles : c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
                            c->fp4_ok ? c->d_coef4 + (size_t)(a_off / 32) * nkt * 256 : nullptr, offlevel_word(c), reinterpret_cast<int*>(c->d_part),
                            c->cfg, c->bcfg, nchunk, c->APAD, a_off, has_hs, fz, (int)n_gq);
     if (FUSE) { c->epilogue_fused = true; c->fused_nb = (int)grid; }     // one summary per workgroup
 }
 
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, int SKL = 0, int RDL = 3, bool LCODE = false, int HT = 1>
+template <int SK8, int RD8, int SK4, int RD4, int TILES, int SKL = 0, int RDL = 3, bool LCODE = false, int HT = 1>
 static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
     // One chunk and a step that may end in k_fold: the kernel finishes its scores itself.
-    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, true, SKL, RDL, LCODE, HT>(c, nchunk, has_hs);
-    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, SKC, RDC, TILES, false, SKL, RDL, LCODE, HT>(c, nchunk, has_hs);
+    if (c->fuse_request && nchunk == 1 && c->fuse_env) launch_mfma_dual_f<SK8, RD8, SK4, RD4, TILES, true, SKL, RDL, LCODE, HT>(c, nchunk, has_hs);
+    else launch_mfma_dual_f<SK8, RD8, SK4, RD4, TILES, false, SKL, RDL, LCODE, HT>(c, nchunk, has_hs);
 }
 
 // Work items of k_sad_mfma_dual = (chunk of K-steps, range of at most 8*TILES view groups of 32).  Two view groups per wave
@@ -1546,15 +1545,15 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
     // x 64x64 x 16 headings <4, 2> 46.7 us; fp4 <2, 3> 0.95 ms and <2, 4> 34.5 us.
     static const int ring = getenv("DEJAVU_RING") ? atoi(getenv("DEJAVU_RING")) : 0;                // A/B of ring shapes
-    if (two_tiles && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, true, 2>(c, nchunk, has_hs);
-    else if (two_tiles) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, false, 2>(c, nchunk, has_hs);
-    else if (use_lc && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3, true>(c, nchunk, has_hs);
-    else if (use_lc && lc == 2) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 2, 5>(c, nchunk, has_hs);
-    else if (use_lc) launch_mfma_dual<4, 2, 2, 4, 2, 4, 1, 4, 3>(c, nchunk, has_hs);
-    else if (tiles == 2) launch_mfma_dual<1, 3, 2, 3, 2, 3, 2>(c, nchunk, has_hs);
-    else if (ring == 1) launch_mfma_dual<4, 2, 2, 6, 2, 6, 1>(c, nchunk, has_hs);
-    else if (ring == 2) launch_mfma_dual<4, 2, 4, 3, 4, 3, 1>(c, nchunk, has_hs);
-    else launch_mfma_dual<4, 2, 2, 4, 2, 4, 1>(c, nchunk, has_hs);
+    if (two_tiles && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, true, 2>(c, nchunk, has_hs);
+    else if (two_tiles) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, false, 2>(c, nchunk, has_hs);
+    else if (use_lc && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, true>(c, nchunk, has_hs);
+    else if (use_lc && lc == 2) launch_mfma_dual<4, 2, 2, 4, 1, 2, 5>(c, nchunk, has_hs);
+    else if (use_lc) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3>(c, nchunk, has_hs);
+    else if (tiles == 2) launch_mfma_dual<1, 3, 2, 3, 2>(c, nchunk, has_hs);
+    else if (ring == 1) launch_mfma_dual<4, 2, 2, 6, 1>(c, nchunk, has_hs);
+    else if (ring == 2) launch_mfma_dual<4, 2, 4, 3, 1>(c, nchunk, has_hs);
+    else launch_mfma_dual<4, 2, 2, 4, 1>(c, nchunk, has_hs);
 }
 
 // The integer path of one scoring pass: k_sad_tiles / k_sad_generic, then k_combine.  `after_tiles` (optional) is

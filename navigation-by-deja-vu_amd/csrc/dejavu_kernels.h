@@ -31,7 +31,9 @@ namespace dv {
 // of the matrix-core kernel's phases per workgroup, in a buffer nothing else reads.  The product build has no stamps.
 #ifdef DEJAVU_STAMPS
 __device__ unsigned long long g_dv_stamps[256 * 8];
-#define DV_STAMP(i) do { if (threadIdx.x == 0) g_dv_stamps[(blockIdx.x & 255) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// (slots 6 and 7: the shader-clock counter beside stamps 1 and 2 -- the clock the CU held during the first item's loop)
+#define DV_STAMP(i) do { if (threadIdx.x == 0) { g_dv_stamps[(blockIdx.x & 255) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 1 || (i) == 2) g_dv_stamps[(blockIdx.x & 255) * 8 + 5 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define DV_STAMP(i) do { } while (0)
 #endif
@@ -1584,9 +1586,13 @@ __global__ void k_prep_f32(const float* __restrict__ raw, float* __restrict__ fp
 // take the item's 16-pixel blocks round-robin; lane <-> view, APAD headings per pass (a_off selects the slice of the
 // apad_total resident ones: 32 or 64 headings are further passes over the library).
 //   * arithmetic: d = l - p, run = fma(d, d, run) in fp32 over one 16-pixel block, then added into a double per heading
-//     (~1e-7 relative; near-ties are re-scored exactly by k_resolve_f32).  Two VALU instructions per pixel and heading
-//     are the floor of this form -- packed fp32 is not faster on gfx950 (measured: 283 us against 213) -- so the kernel
-//     is co-limited by VALU issue and HBM: the next block's tiles are loaded before the current one is scored;
+//     (~1e-7 relative; near-ties are re-scored exactly by k_resolve_f32).  Two VALU operations per pixel and heading are
+//     the floor of this form (the expansion l^2 - 2 l p + p^2 halves them but cancels: a near match's small SSD would lose its
+//     1e-6).  hipcc's SLP pass pairs them into v_pk_add_f32 / v_pk_fma_f32 (256 packed instructions per 16-pixel block and 16
+//     headings), which is what runs fastest: 50 000 views x 64x64 x 16 headings 195 us, 245 us built with -fno-slp-vectorize
+//     (round 3; hand-packed source measured slower than either in round 1).  At 16 headings the kernel is bound by that
+//     instruction stream, not by HBM (8 lane-operations per library byte): the next block's tiles are loaded before the current
+//     one is scored so that the loads hide behind it;
 //   * the NW waves add their doubles up in LDS in a fixed order (wave 0 + 1 + 2 + 3: reproducible) and share the
 //     stores, so a quarter of the partial sums cross HBM.
 template <int APAD, int NW, bool PF>
@@ -2190,18 +2196,22 @@ k_bitpack(const uint4* __restrict__ tiles, uint4* __restrict__ btiles, LibCfg c,
 // n_sensor_levels, NavBySceneFamiliarity.py:66): its four thermometer bits per pixel carry log2(5) bits of information, and
 // three stored bits decode back to them with two or three VALU operations per plane --
 //     level 0..4  ->  code b2 b1 b0 = 000, 001, 010, 110, 111:   t1 = b0 | b1,  t2 = b1,  t3 = b2,  t4 = b0 & b2.
-// The HS rows are the bit tiles' (1 KB: thermometer bits as they are).  A V row is THREE dwords per lane (768 B, moved
-// by global_load_lds_dwordx3) for the same K-step whose bit-tile row has four: nibble i of dword w (w = 0, 1, 2) holds in
-// bits 0..2 the code of the pixel whose thermometer bits are nibble i of dword w of the bit-tile row, and in bit 3 bit w
-// of the code of the pixel at nibble i of dword 3.  5 bits per pixel where the bit tiles take 6; the K-elements, hence
-// the coefficient image and the sums, are the same.  One thread per (view group of 32, K-step, lane).
+// The HS rows are the bit tiles' (1 KB: thermometer bits as they are).  A V K-step is THREE code dwords per lane where the
+// bit-tile row has four: nibble i of code dword w (w = 0, 1, 2) holds in bits 0..2 the code of the pixel whose thermometer bits
+// are nibble i of dword w of the bit-tile row, and in bit 3 bit w of the code of the pixel at nibble i of dword 3.  5 bits per
+// pixel where the bit tiles take 6; the K-elements, hence the coefficient image and the sums, are the same.
+// A lane's twelve code dwords of a STAGE of four V K-steps (dword d = 3 kk + w of K-step kk) are stored as three full 1-KB rows
+// ("chunks": chunk d / 4 holds the lanes' dwords 4 (d / 4) .. + 3, 16 bytes per lane): the kernel moves a stage of a view group
+// with three global_load_lds_dwordx4 -- 1 KB per wave-instruction like every other row; rows of 768 B moved by dwordx3 took as long
+// as 1-KB rows, sad_lc_fp4 -- and a consumer has a K-step's three dwords in registers after reading whole chunks.
+// One thread per (view group of 32, K-step, lane).
 __device__ __forceinline__ unsigned level_code(unsigned thermo4) {       // thermometer nibble t4 t3 t2 t1 -> code
     const unsigned level = __popc(thermo4 & 15u);
     return level == 0 ? 0u : level == 1 ? 1u : level == 2 ? 2u : level == 3 ? 6u : 7u;
 }
 __global__ void __launch_bounds__(256)
 k_bitpack_code(const uint4* __restrict__ btiles, unsigned* __restrict__ ctiles, LibCfg c, BitCfg b) {
-    const int NKT = b.NK[0] + b.NK[1];
+    const int NKT = b.NK[0] + b.NK[1];                                  // (NK[1] is a whole number of stages of four: build_bit_planes)
     const long long G32 = c.Fpad / 32;
     const long long total = G32 * NKT * 64;
     const long long tt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2216,7 +2226,8 @@ k_bitpack_code(const uint4* __restrict__ btiles, unsigned* __restrict__ ctiles, 
         reinterpret_cast<uint4*>(group + (long long)ks * 256)[lane] = own;
     } else {
         const unsigned o[4] = {own.x, own.y, own.z, own.w};
-        unsigned* row = group + (long long)b.NK[0] * 256 + (long long)(ks - b.NK[0]) * 192 + lane * 3;
+        const int ksl = ks - b.NK[0];
+        unsigned* stage = group + (long long)b.NK[0] * 256 + (long long)(ksl >> 2) * 768;      // 3 KB = 768 dwords per stage
         for (int w = 0; w < 3; ++w) {
             unsigned x = 0;
             for (int i = 0; i < 8; ++i) {
@@ -2224,7 +2235,8 @@ k_bitpack_code(const uint4* __restrict__ btiles, unsigned* __restrict__ ctiles, 
                 const unsigned extra = (level_code(o[3] >> (4 * i)) >> w) & 1u;
                 x |= (code | (extra << 3)) << (4 * i);
             }
-            row[w] = x;
+            const int d = 3 * (ksl & 3) + w;
+            stage[(d >> 2) * 256 + lane * 4 + (d & 3)] = x;
         }
     }
 }
@@ -2254,15 +2266,6 @@ __device__ __forceinline__ void wait_vmcnt_le() {
 __device__ __forceinline__ void lds_dma_16(const uint4* gsrc, unsigned lds_byte_addr) {     // 64 lanes x 16 B -> 1 KB of LDS
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
-}
-// A 768-byte code row: 12 bytes per lane.  global_load_lds_dwordx3 puts every lane's 12 bytes 16 apart in LDS
-// (tools/exp/lds_dma3.hip), so the row takes 1 KB there and is read back with one ds_read_b128 per lane like any other.
-// (Moving it with 48 lanes of a dwordx4 packs it into 768 B of LDS, but the three ds_read_b32 per lane that then read it
-// cannot be tied to a counted wait as one register tuple: the compiler copied them out early in one build.)
-__device__ __forceinline__ void lds_dma_12_nt(const unsigned char* gsrc, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ void lds_dma_16_nt(const uint4* gsrc, unsigned lds_byte_addr) {  // library rows: used once per step
@@ -2725,23 +2728,20 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(IntC<I>{}); static_for<N, I + 1>(f); }
 }
 
-// One segment (HS or V) of one item in the fp4 form: the ring loop, then the segment's integer sums in tot.
-//   CODE = false: library rows are thermometer bits, 1 KB per K-step (bit tiles, or the HS rows of the code tiles);
-//   CODE = true : the V rows of the code tiles, 768 B per K-step (k_bitpack_code), decoded in registers:
-//                 t1 = (x | x >> 1) & m, t2 = x & 2m, t3 = x & 4m, t4 = x & (x >> 2) & m per code dword, m = 0x11111111.
-// [k0, k1): K-steps of the coefficient image (absolute); lib[t]: this lane's place in the library row of K-step k0
-// (row pitch 1024 or 768 bytes).  w[b]: gap width of the planes on bit b.
+// One segment (HS or V) of one item in the fp4 form: the ring loop, then the segment's integer sums in tot.  Library rows are
+// the bit tiles' (thermometer bits, 1 KB per K-step; the code tiles are sad_lc_fp4's).
+// [k0, k1): K-steps of the coefficient image (absolute); lib[t]: this lane's place in the library row of K-step k0.
+// w[b]: gap width of the planes on bit b.
 // kflush in (k0, k1), a whole number of stages past k0: the range covers BOTH segments (HS rows then V rows, consecutive
 // in the bit tiles and in the coefficient image) -- at K-step kflush the accumulators leave the HS sums in totf (widths wf)
 // and start over, so the ring streams through the boundary and an item has one pipeline fill, not two.
-template <int SK, int TILES, int RD, bool FUSE, bool CODE>
+template <int SK, int TILES, int RD, bool FUSE>
 __device__ __forceinline__ void
 fp4_segment(const unsigned char* const (&lib)[TILES], const bool (&live)[TILES], const uint4* __restrict__ coef4, int k0, int k1, const int (&w)[4],
             int lane, int wave, int (&tot)[TILES][16], int kflush, const int (&wf)[4], int (&totf)[TILES][16]) {
     extern __shared__ uint4 lds_ring[];
     constexpr int NW = 8;
-    constexpr int ROWB = CODE ? 768 : 1024;       // bytes of a library row in HBM
-    constexpr int LROWB = 1024;                   // and in LDS (a code row keeps a 4-byte hole per lane there)
+    constexpr int ROWB = 1024, LROWB = 1024;      // bytes of a library row in HBM and in LDS
     constexpr int COEF_ROWS = SK * 4;
     constexpr int LIB_ROWS = NW * SK * TILES;
     constexpr int SLOTB = COEF_ROWS * 1024 + LIB_ROWS * LROWB;
@@ -2775,7 +2775,6 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const bool (&live)[TILES],
                 lr = lr < k1 - k0 ? lr : k1 - k0 - 1;                 // clamped: masked below
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)(COEF_ROWS * 1024 + row * LROWB));
                 if (!live[t]) lds_dma_16(coef4 + (long long)k0 * 256 + lane, dst);       // a slot without a group: a coefficient row, hot in L2
-                else if constexpr (CODE) lds_dma_12_nt(lib[t] + (long long)lr * ROWB, dst);     // (keeps the wave's vmcnt arithmetic; never used)
                 else lds_dma_16_nt(reinterpret_cast<const uint4*>(lib[t] + (long long)lr * ROWB), dst);
             }
         };
@@ -2803,7 +2802,7 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const bool (&live)[TILES],
             static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * 4 + s_) * 1024>(a[k & 1][s_], cad); });
             static_for<TILES>([&](auto tc) {
                 constexpr int t_ = decltype(tc)::value;
-                lds_read16<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);              // (CODE: the fourth dword is the hole)
+                lds_read16<(k * TILES + t_) * LROWB>(xl[k & 1][t_], lad);
             });
         };
 #pragma unroll
@@ -2826,7 +2825,7 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const bool (&live)[TILES],
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         totf[t][r] = __mul24(wf[0], (int)(2.f * acc[t][0][r])) + __mul24(wf[1], (int)acc[t][1][r]) + __mul24(wf[2], (int)(0.5f * acc[t][2][r])) +
-                                     __mul24(wf[3], (int)((CODE ? 2.f : 1.f) * acc[t][3][r]));
+                                     __mul24(wf[3], (int)acc[t][3][r]);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -2875,25 +2874,13 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const bool (&live)[TILES],
                 const bool on = kb + k < k1;
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    unsigned x[4] = {xl[k & 1][t].x, xl[k & 1][t].y, xl[k & 1][t].z, xl[k & 1][t].w};
-                    if constexpr (!CODE) {
+                    const unsigned x[4] = {xl[k & 1][t].x, xl[k & 1][t].y, xl[k & 1][t].z, xl[k & 1][t].w};
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
-                            const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
-                            const int sh = s < 3 ? 0 : 2;
-                            mfma(t, s, a[k & 1][s], (x[0] >> sh) & m, (x[1] >> sh) & m, (x[2] >> sh) & m, (x[3] >> sh) & m);
-                        }
-                    } else {
-                        const unsigned m1 = 0x11111111u;
-                        const unsigned m = on ? m1 : 0u;
-                        // the fourth dword's pixels: bit 3 of the three code dwords' nibbles
-                        x[3] = ((x[0] >> 3) & m1) | ((x[1] >> 2) & (m1 << 1)) | ((x[2] >> 1) & (m1 << 2));
-                        // E2M1 operands of the four thermometer planes: t1, t4 as 0.5 (bit 0), t2 as 1 (bit 1), t3 as 2 (bit 2)
-                        mfma(t, 0, a[k & 1][0], (x[0] | (x[0] >> 1)) & m, (x[1] | (x[1] >> 1)) & m, (x[2] | (x[2] >> 1)) & m, (x[3] | (x[3] >> 1)) & m);
-                        mfma(t, 1, a[k & 1][1], x[0] & (m << 1), x[1] & (m << 1), x[2] & (m << 1), x[3] & (m << 1));
-                        mfma(t, 2, a[k & 1][2], x[0] & (m << 2), x[1] & (m << 2), x[2] & (m << 2), x[3] & (m << 2));
-                        mfma(t, 3, a[k & 1][3], x[0] & (x[0] >> 2) & m, x[1] & (x[1] >> 2) & m, x[2] & (x[2] >> 2) & m, x[3] & (x[3] >> 2) & m);
+                    for (int s = 0; s < 4; ++s) {
+                        // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
+                        const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
+                        const int sh = s < 3 ? 0 : 2;
+                        mfma(t, s, a[k & 1][s], (x[0] >> sh) & m, (x[1] >> sh) & m, (x[2] >> sh) & m, (x[3] >> sh) & m);
                     }
                 }
             });
@@ -2907,34 +2894,33 @@ fp4_segment(const unsigned char* const (&lib)[TILES], const bool (&live)[TILES],
         __builtin_amdgcn_s_barrier();
         DV_STAMP(2);
     }
-    // bits stood for 0.5 / 1 / 2 / (1, CODE: 0.5): signed counts 2 acc0, acc1, acc2 / 2, acc3 (CODE: 2 acc3) -- integers --
-    // each times the gap width of the planes on that bit position (widths < 256, |counts| < 2^23)
+    // bits stood for 0.5 / 1 / 2 / 1: signed counts 2 acc0, acc1, acc2 / 2, acc3 -- integers -- each times the gap width of the
+    // planes on that bit position (widths < 256, |counts| < 2^23)
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             tot[t][r] = __mul24(w[0], (int)(2.f * acc[t][0][r])) + __mul24(w[1], (int)acc[t][1][r]) + __mul24(w[2], (int)(0.5f * acc[t][2][r])) +
-                        __mul24(w[3], (int)((CODE ? 2.f : 1.f) * acc[t][3][r]));
+                        __mul24(w[3], (int)acc[t][3][r]);
 }
 
 // LDS the rings of fp4_segment take (the FUSE scratch sits behind the larger of a kernel's two).
-constexpr int fp4_ring_bytes(int SK, int TILES, int RD, bool code) { (void)code; return RD * (SK * 4 * 1024 + 8 * SK * TILES * 1024); }
+constexpr int fp4_ring_bytes(int SK, int TILES, int RD) { return RD * (SK * 4 * 1024 + 8 * SK * TILES * 1024); }
 
-template <int SK, int TILES, int RD, int SKC, int RDC, bool FUSE>
+template <int SK, int TILES, int RD, bool FUSE>
 __device__ __forceinline__ void
-sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
+sad_ring_fp4(const uint4* __restrict__ btiles, const uint4* __restrict__ coef4, int* __restrict__ part, const LibCfg& c, const BitCfg& b,
              int nchunk, int apad_total, int a_off, int has_hs_sum, const FuseArgs& fz, int n_gq) {
     extern __shared__ uint4 lds_ring[];           // the rings of fp4_segment, then the FUSE scratch
     constexpr int NW = 8;
-    constexpr int RING = fp4_ring_bytes(SK, TILES, RD, false) > fp4_ring_bytes(SKC, TILES, RDC, true) ? fp4_ring_bytes(SK, TILES, RD, false)
-                                                                                                         : fp4_ring_bytes(SKC, TILES, RDC, true);
+    constexpr int RING = fp4_ring_bytes(SK, TILES, RD);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long G32 = c.Fpad / 32;
     const long long GQ = n_gq;                    // view-group ranges the library is cut into (item_groups)
     const long long n_items = GQ * nchunk;
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
-    const long long gbytes = b.vcode ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
+    const long long gbytes = (long long)b.GS * 1024;                    // between view groups
     DV_STAMP(0);
     if constexpr (FUSE) fused_block_begin(reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(lds_ring) + RING));
     int nfin = 0;                                 // fused_finish calls so far (their parity)
@@ -2952,38 +2938,32 @@ sad_ring_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
             live[t] = g < g1;
             if (!live[t]) g = g0;                 // a slot without a group streams nothing (fp4_segment: one row, re-read)
             gidx[t] = g;
-            grp[t] = reinterpret_cast<const unsigned char*>(ftiles) + g * gbytes;
+            grp[t] = reinterpret_cast<const unsigned char*>(btiles) + g * gbytes;
         }
         int tot_hs[TILES][16], tot_v[TILES][16];
         (void)tot_hs;
         (void)tot_v;
-        // one chunk, both sums, thermometer rows throughout, HS K-steps a whole number of stages: ONE ring loop for the item
-        const bool merged = nchunk == 1 && has_hs_sum && c.hasv && !b.vcode && b.NK[0] % SK == 0 && b.NK[0] > 0 && b.NK[1] > 0;
+        // one chunk, both sums, HS K-steps a whole number of stages: ONE ring loop for the item
+        const bool merged = nchunk == 1 && has_hs_sum && c.hasv && b.NK[0] % SK == 0 && b.NK[0] > 0 && b.NK[1] > 0;
         if (merged) {
             const unsigned char* lib[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + lane * 16;
-            fp4_segment<SK, TILES, RD, FUSE, false>(lib, live, coef4, 0, b.NK[0] + b.NK[1], b.wacc[1], lane, wave, tot_v, b.NK[0], b.wacc[0], tot_hs);
+            fp4_segment<SK, TILES, RD, FUSE>(lib, live, coef4, 0, b.NK[0] + b.NK[1], b.wacc[1], lane, wave, tot_v, b.NK[0], b.wacc[0], tot_hs);
         }
         if (!merged && has_hs_sum) {
             const int k0 = (int)(((long long)ch * b.NK[0]) / nchunk), k1 = (int)(((long long)(ch + 1) * b.NK[0]) / nchunk);
             const unsigned char* lib[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)k0 * 1024 + lane * 16;
-            fp4_segment<SK, TILES, RD, FUSE, false>(lib, live, coef4, k0, k1, b.wacc[0], lane, wave, tot_hs, -1, b.wacc[0], tot_hs);
+            fp4_segment<SK, TILES, RD, FUSE>(lib, live, coef4, k0, k1, b.wacc[0], lane, wave, tot_hs, -1, b.wacc[0], tot_hs);
         }
         if (!merged && c.hasv) {
             const int r0 = (int)(((long long)ch * b.NK[1]) / nchunk), r1 = (int)(((long long)(ch + 1) * b.NK[1]) / nchunk);
             const unsigned char* lib[TILES];
-            if (b.vcode) {
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)b.NK[0] * 1024 + (long long)r0 * 768 + lane * 12;
-                fp4_segment<SKC, TILES, RDC, FUSE, true>(lib, live, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
-            } else {
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)(b.NK[0] + r0) * 1024 + lane * 16;
-                fp4_segment<SK, TILES, RD, FUSE, false>(lib, live, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
-            }
+            for (int t = 0; t < TILES; ++t) lib[t] = grp[t] + (long long)(b.NK[0] + r0) * 1024 + lane * 16;
+            fp4_segment<SK, TILES, RD, FUSE>(lib, live, coef4, b.NK[0] + r0, b.NK[0] + r1, b.wacc[1], lane, wave, tot_v, -1, b.wacc[1], tot_v);
         }
         if constexpr (!FUSE) {
             const int nsum = has_hs_sum + c.hasv;
@@ -3053,15 +3033,19 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
     constexpr int PER = ROWS / NL;                                      // LDS-DMA instructions per loader wave and stage
     constexpr int RING = RD * SLOTB;
     constexpr int NU = SK * HT;                                         // pipeline units per stage: (K-step, heading tile)
+    constexpr int PERC = SK * HT + 3 * TL;                              // ... of a stage of code rows: three 1-KB chunks per view group
     static_assert((HT == 1 || HT == 2) && PER == 3 * SK && PER * (RD - 1) < 64 && SK % 2 == 0 && RD >= 3, "ring shape");
+    static_assert(!CODE || (SK == 4 && RD == 3), "code rows come in stages of four K-steps; the counted wait below knows one younger stage");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool loader = wave >= NC;
     const long long G32 = c.Fpad / 32, GQ = n_gq;
     const int NKT = b.NK[0] + b.NK[1];
     const int nst = (NKT + SK - 1) / SK;
-    // code tiles (k_bitpack_code): the V rows are 768 bytes (3-bit level codes), moved by global_load_lds_dwordx3 -- every lane's
-    // 12 bytes land 16 apart in LDS, so a row is read back like any other -- and decoded in registers by the consumers
+    // code tiles (k_bitpack_code): a V stage of a view group is three 1-KB chunks (a lane's twelve 3-bit-code dwords of the
+    // stage's four K-steps), chunk c in the ring row where K-step c's library row would be, decoded in registers by the consumers.
+    // (Rows of 768 B per K-step moved by global_load_lds_dwordx3 took LONGER than the thermometer rows they replace: 500 000 views
+    // x 128x128, first item's loop 128 us against 114 -- tools/exp/stamps.py.)
     constexpr bool codev = CODE;                                        // == (b.vcode != 0): the host picks the instantiation
     const int NK0 = b.NK[0];
     const long long gbytes = codev ? (long long)b.GSC * 256 : (long long)b.GS * 1024;      // between view groups
@@ -3081,7 +3065,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
     long long li = 0;
     int lst = 0, lslot = 0;
     const unsigned char* lp[TL];                                        // this lane's place in row 0 of the loader's view group(s)
-    const unsigned char* lpv[TL];                                       // and in their first V row when those are code rows
+    const unsigned char* lpv[TL];                                       // and in their first V chunk when those are code rows
     bool llive[TL];
 #pragma unroll
     for (int t = 0; t < TL; ++t) { lp[t] = lib_bytes; lpv[t] = lib_bytes; llive[t] = false; }
@@ -3096,32 +3080,53 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                 const long long g = g0 + lw + 4 * t;                    // slot lw + 4 t of the item's 4 TL: consumer (lw + 4 t) / TL, its group (lw + 4 t) % TL
                 llive[t] = g < g1;
                 lp[t] = lib_bytes + (llive[t] ? g : g0) * gbytes + lane * 16;
-                lpv[t] = lib_bytes + (llive[t] ? g : g0) * gbytes + (long long)NK0 * 1024 + lane * 12;
+                lpv[t] = lib_bytes + (llive[t] ? g : g0) * gbytes + (long long)NK0 * 1024 + lane * 16;
             }
         }
     };
+    bool young_code = false;                                            // the stage issued last is one of code rows (PERC instructions, not PER)
     auto issue_stage = [&]() {
         const unsigned slot = lds_base + (unsigned)lslot * (unsigned)SLOTB;
         const int kb = lst * SK;
         const uint4* hot = coef4 + lw * 64 + lane;                      // re-read where there is nothing to fetch (hot in L2)
+        const bool code_stage = codev && kb >= NK0;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            if (i < SK * HT) {                                          // coefficient row (K-step kb + kk, heading tile h, bit position lw)
-                const int kk = i / HT, h = i % HT;
-                int k = kb + kk;
-                k = k < NKT ? k : NKT - 1;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((kk * KCOEF + h * 4 + lw) * 1024));
-                lds_dma_16(li < n_mine ? coef4 + h * pass16 + ((long long)k * 4 + lw) * 64 + lane : hot, dst);
-            } else {                                                    // library row (K-step kb + kk, slot lw + 4 t)
-                const int kk = (i - SK * HT) / TL, t = (i - SK * HT) % TL;
+        for (int i = 0; i < SK * HT; ++i) {                             // coefficient row (K-step kb + kk, heading tile h, bit position lw)
+#ifdef DEJAVU_EXP_SKIP
+            if (DEJAVU_EXP_SKIP & 1) continue;
+#endif
+            const int kk = i / HT, h = i % HT;
+            int k = kb + kk;
+            k = k < NKT ? k : NKT - 1;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((kk * KCOEF + h * 4 + lw) * 1024));
+            lds_dma_16(li < n_mine ? coef4 + h * pass16 + ((long long)k * 4 + lw) * 64 + lane : hot, dst);
+        }
+        if (code_stage) {
+#pragma unroll
+            for (int i = 0; i < 3 * TL; ++i) {                          // chunk cc of the stage, slot lw + 4 t
+#ifdef DEJAVU_EXP_SKIP
+                if (DEJAVU_EXP_SKIP & 2) continue;
+#endif
+                const int cc = i / TL, t = i % TL;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + cc * KLIB + lw + 4 * t) * 1024));
+                if (!llive[t]) lds_dma_16(hot, dst);
+                else lds_dma_16_nt(reinterpret_cast<const uint4*>(lpv[t] + (long long)((kb - NK0) / SK) * 3072 + cc * 1024), dst);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SK * TL; ++i) {                         // library row (K-step kb + kk, slot lw + 4 t)
+#ifdef DEJAVU_EXP_SKIP
+                if (DEJAVU_EXP_SKIP & 2) continue;
+#endif
+                const int kk = i / TL, t = i % TL;
                 int k = kb + kk;
                 k = k < NKT ? k : NKT - 1;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + kk * KLIB + lw + 4 * t) * 1024));
                 if (!llive[t]) lds_dma_16(hot, dst);
-                else if (codev && k >= NK0) lds_dma_12_nt(lpv[t] + (long long)(k - NK0) * 768, dst);
                 else lds_dma_16_nt(reinterpret_cast<const uint4*>(lp[t] + (long long)k * 1024), dst);
             }
         }
+        young_code = code_stage;
         lslot = lslot + 1 == RD ? 0 : lslot + 1;
         if (++lst == nst) { lst = 0; ++li; loader_item(); }
     };
@@ -3164,7 +3169,15 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
             for (int r = 0; r < 16; ++r) { tot_hs[u][r] = 0; tot_v[u][r] = 0; }
         if (loader) {
             for (int st = 0; st < nst; ++st) {
-                wait_vmcnt_le<PER * (RD - 2)>();                        // this wave's rows of stage (j, st) have landed ...
+                // this wave's rows of stage (j, st) have landed once only the younger stages' instructions are outstanding ...
+#ifdef DEJAVU_EXP_SKIP          // (timing experiments of tools/exp/stamps.py: bit 0 leaves out the coefficient rows, bit 1 the library rows)
+                constexpr int XC = (DEJAVU_EXP_SKIP & 1) ? 0 : SK * HT, XL = (DEJAVU_EXP_SKIP & 2) ? 0 : SK * TL, XLC = (DEJAVU_EXP_SKIP & 2) ? 0 : 3 * TL;
+                if (CODE && young_code) wait_vmcnt_le<XC + XLC>();
+                else wait_vmcnt_le<(XC + XL) * (RD - 2)>();
+#else
+                if (CODE && young_code) wait_vmcnt_le<PERC>();
+                else wait_vmcnt_le<PER * (RD - 2)>();
+#endif
                 __builtin_amdgcn_s_barrier();                           // ... everybody's have; nobody still reads the slot before it
                 issue_stage();                                          // (may belong to the next item: its pipeline fill)
             }
@@ -3178,15 +3191,26 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                     for (int r = 0; r < 16; ++r) acc[u][s][r] = 0.f;
             // operand registers of two units: unit q = (K-step q / HT, heading tile q % HT) lives in buffer q & 1; the library rows of
             // a K-step in xl[k & 1] (read with the K-step's first unit)
-            v4u_t a[2][4], xl[2][TL];
-            auto fetch = [&](int slot_i, auto qc) {
+            // Code rows: chunk 0 of a stage is read where K-step 0's row would be (so the read ahead across a stage boundary is the
+            // same whatever the next stage holds), chunk 1 with K-step 1, chunk 2 with K-step 2 into xc2 (chunk 0 is still in use
+            // then: K-step 1 takes its last dword), nothing with K-step 3.
+            v4u_t a[2][4], xl[2][TL], xc2[TL];
+            auto fetch = [&](int slot_i, auto qc, auto codeC) {
                 constexpr int q = decltype(qc)::value;
                 constexpr int k = q / HT, h = q % HT;
+                constexpr bool code_rows = decltype(codeC)::value != 0;
                 const unsigned sad = lds_base + (unsigned)slot_i * (unsigned)SLOTB + (unsigned)lane * 16u;
+#ifdef DEJAVU_EXP_NOLDS
+                if (q > 0) return;
+#endif
                 static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * KCOEF + h * 4 + s_) * 1024>(a[q & 1][s_], sad); });
-                if constexpr (h == 0) {
+                if constexpr (h == 0 && (!code_rows || k < 3)) {
                     const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * TL * 1024);
-                    static_for<TL>([&](auto tc) { constexpr int t_ = decltype(tc)::value; lds_read16<(k * KLIB + t_) * 1024>(xl[k & 1][t_], lad); });
+                    static_for<TL>([&](auto tc) {
+                        constexpr int t_ = decltype(tc)::value;
+                        if constexpr (code_rows && k == 2) lds_read16<(k * KLIB + t_) * 1024>(xc2[t_], lad);
+                        else lds_read16<(k * KLIB + t_) * 1024>(xl[k & 1][t_], lad);
+                    });
                 }
             };
             // bits stood for 0.5 / 1 / 2 / 1 (code rows: 0.5): signed counts 2 acc0, acc1, acc2 / 2, acc3 (code rows: 2 acc3) -- integers
@@ -3201,7 +3225,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
             };
             __builtin_amdgcn_s_barrier();                               // stage (j, 0) is in LDS
             if (j == 0) DV_STAMP(1);
-            fetch(cslot, IntC<0>{});
+            fetch(cslot, IntC<0>{}, IntC<0>{});
             // stages [s0, s1) of one kind: thermometer rows, or (codeC) the 3-bit code rows of the V segment
             auto run_stages = [&](int s0, int s1, auto codeC) {
                 constexpr bool code_stage = decltype(codeC)::value;
@@ -3213,21 +3237,24 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                         constexpr int q = decltype(qc)::value;
                         constexpr int k = q / HT, h = q % HT;
                         if constexpr (q + 1 < NU) {
-                            fetch(cslot, IntC<q + 1>{});                // one unit ahead
-                            if constexpr (((q + 1) % HT) == 0) lds_wait<4 + TL>();      // all but the newest unit's reads have landed
-                            else lds_wait<4>();
+                            fetch(cslot, IntC<q + 1>{}, codeC);         // one unit ahead
+                            constexpr int k1 = (q + 1) / HT, h1 = (q + 1) % HT;
+                            lds_wait<4 + ((h1 == 0 && (!code_stage || k1 < 3)) ? TL : 0)>();      // all but the newest unit's reads have landed
                         } else {
                             lds_wait<0>();                              // everything this wave will use of the slot is in registers
                             if (st + 1 < nst) {
                                 __builtin_amdgcn_s_barrier();           // stage st + 1 is in LDS; the loaders may refill slot st - 1 ... and,
-                                fetch(nslot, IntC<0>{});                //   one barrier later, this one
+                                fetch(nslot, IntC<0>{}, IntC<0>{});     //   one barrier later, this one
                             }
                         }
 #pragma unroll
                         for (int s = 0; s < 4; ++s) lds_tie(a[q & 1][s]);
                         if constexpr (h == 0) {
 #pragma unroll
-                            for (int t = 0; t < TL; ++t) lds_tie(xl[k & 1][t]);
+                            for (int t = 0; t < TL; ++t) {
+                                if constexpr (!code_stage || k < 2) lds_tie(xl[k & 1][t]);
+                                else if constexpr (k == 2) lds_tie(xc2[t]);
+                            }
                         }
                         const bool on = kb + k < NKT;
                         auto mfma = [&](int u, int s, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
@@ -3239,6 +3266,13 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                         };
                         // operand of bit position s from the library dwords x (thermometer rows), or of thermometer plane s (code rows)
                         auto operand = [&](const unsigned (&x)[4], int s, unsigned (&o)[4]) {
+#ifdef DEJAVU_EXP_NOMASK
+                            if (true) {
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) o[d] = x[d];
+                                return;
+                            }
+#endif
                             if constexpr (!code_stage) {
                                 // bit s of every nibble as an E2M1 value: 0.5 / 1 / 2 in place, bit 3 shifted down to the 1.0 position
                                 const unsigned m = on ? (s < 3 ? (0x11111111u << s) : 0x22222222u) : 0u;
@@ -3254,9 +3288,17 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                             }
                         };
                         auto load_x = [&](int t, unsigned (&x)[4]) {
-                            x[0] = xl[k & 1][t].x; x[1] = xl[k & 1][t].y; x[2] = xl[k & 1][t].z; x[3] = xl[k & 1][t].w;
-                            if constexpr (code_stage)      // the fourth dword's pixels: bit 3 of the three code dwords' nibbles (the LDS-DMA left a hole there)
+                            if constexpr (!code_stage) {
+                                x[0] = xl[k & 1][t].x; x[1] = xl[k & 1][t].y; x[2] = xl[k & 1][t].z; x[3] = xl[k & 1][t].w;
+                            } else {
+                                // the K-step's three code dwords: dwords 3 k .. 3 k + 2 of the stage's twelve (chunks xl[0], xl[1], xc2)
+                                if constexpr (k == 0) { x[0] = xl[0][t].x; x[1] = xl[0][t].y; x[2] = xl[0][t].z; }
+                                else if constexpr (k == 1) { x[0] = xl[0][t].w; x[1] = xl[1][t].x; x[2] = xl[1][t].y; }
+                                else if constexpr (k == 2) { x[0] = xl[1][t].z; x[1] = xl[1][t].w; x[2] = xc2[t].x; }
+                                else { x[0] = xc2[t].y; x[1] = xc2[t].z; x[2] = xc2[t].w; }
+                                // the fourth dword's pixels: bit 3 of the three code dwords' nibbles
                                 x[3] = ((x[0] >> 3) & 0x11111111u) | ((x[1] >> 2) & 0x22222222u) | ((x[2] >> 1) & 0x44444444u);
+                            }
                         };
                         if constexpr (HT == 1) {
 #pragma unroll
@@ -3350,9 +3392,10 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
     DV_STAMP(5);
 }
 
-// One launch, both forms: `offlevel` (k_patch_prep) says whether this step's patches allow the fp4 coefficients.  The fp4 form
-// reads ftiles (the code tiles when the library has them, else the bit tiles), the int8 form the bit tiles.
-template <int SK8, int RD8, int SK4, int RD4, int SKC, int RDC, int TILES, bool FUSE, int SKL, int RDL, bool LCODE, int HT>
+// One launch, both forms: `offlevel` (k_patch_prep) says whether this step's patches allow the fp4 coefficients.  The loader /
+// consumer body of the fp4 form reads ftiles (the code tiles when the library has them, else the bit tiles), everything else the
+// bit tiles.
+template <int SK8, int RD8, int SK4, int RD4, int TILES, bool FUSE, int SKL, int RDL, bool LCODE, int HT>
 __global__ void __launch_bounds__(512, 2)
 k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ ftiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4,
                 const unsigned* __restrict__ offlevel, int* __restrict__ part, LibCfg c, BitCfg b, int nchunk, int apad_total, int a_off,
@@ -3371,7 +3414,7 @@ k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ ftil
 #pragma unroll 1
     for (int h = 0; h < HT; ++h) {
         if (h > 0 && a_off + 32 * h >= apad_total) break;
-        if (fp4) sad_ring_fp4<SK4, TILES, RD4, SKC, RDC, FUSE>(ftiles, coef4 + (long long)h * NKT * 256, part, c, b, nchunk, apad_total, a_off + 32 * h, has_hs_sum, fz, n_gq);
+        if (fp4) sad_ring_fp4<SK4, TILES, RD4, FUSE>(btiles, coef4 + (long long)h * NKT * 256, part, c, b, nchunk, apad_total, a_off + 32 * h, has_hs_sum, fz, n_gq);
         else sad_ring_i8<SK8, TILES, RD8, FUSE>(btiles, coef + (long long)h * NKT * 512, part, c, b, nchunk, apad_total, a_off + 32 * h, has_hs_sum, fz, n_gq);
     }
 }

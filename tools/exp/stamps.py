@@ -9,10 +9,10 @@ import ctypes, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "navigation-by-deja-vu_amd", "csrc")
-SO = os.path.join(ROOT, "tools", "exp", "libdejavu_stamps.so")
-if sys.argv[1] == "build":
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DDEJAVU_STAMPS",
-                    "-shared", "-o", SO, os.path.join(CSRC, "dejavu_hip.hip"), "-ldl"], check=True, cwd=CSRC)
+SO = os.path.join(ROOT, "tools", "exp", os.environ.get("STAMPS_SO", "libdejavu_stamps.so"))
+if sys.argv[1] == "build":         # build [extra -D flags]: e.g. STAMPS_SO=libdejavu_stamps_nocoef.so ... build -DDEJAVU_EXP_SKIP=1 (results wrong, timing only)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DDEJAVU_STAMPS"] + sys.argv[2:] +
+                   ["-shared", "-o", SO, os.path.join(CSRC, "dejavu_hip.hip"), "-ldl"], check=True, cwd=CSRC)
     sys.exit(0)
 sys.path.insert(0, os.path.join(ROOT, "navigation-by-deja-vu_amd"))
 from navsim_amd import _native
@@ -39,4 +39,6 @@ for i, n in enumerate(names):
 for i in range(1, 6):
     d = (st[:, i] - st[:, i - 1]) / 100.0
     print("phase %d->%d: median %7.2f us  max %7.2f" % (i - 1, i, np.median(d), d.max()))
+clk = (st[:, 7] - st[:, 6]) / np.maximum(st[:, 2] - st[:, 1], 1) * 100.0
+print("shader clock during the first item's loop: median %.0f MHz  min %.0f  max %.0f" % (np.median(clk), clk.min(), clk.max()))
 eng.close()

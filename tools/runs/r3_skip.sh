@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+# timing-only experiments (results wrong): the scoring kernel without its coefficient rows (s1), without its library rows (s2), without
+# both (s3); s3 without the consumers' mask arithmetic (m) and without their LDS reads (l)
+for so in ${SOS:-libdejavu_stamps.so libdejavu_stamps_s1.so libdejavu_stamps_s2.so libdejavu_stamps_s3.so}; do
+  for shape in "50000 64 16" "500000 128 32"; do
+    echo "=== $so $shape"
+    STAMPS_SO=$so timeout -k 5 90 python tools/exp/stamps.py run $shape 2>/dev/null | grep "phase 1->2\|^exit\|^loop"
+  done
+done
