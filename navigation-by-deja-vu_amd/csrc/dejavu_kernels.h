@@ -62,6 +62,16 @@ struct LibCfg {
     double wv;          // 1 - cw            (util.pyx:69)
 };
 
+// Per-heading constants of a patch preparation (PrepAcc, k_patch_prep): a heading's sum is kept as kAccWays partial sums, each in
+// a cache line of its own (kAccStride ints apart) -- the blocks of a heading add to them with atomics, and atomics to ONE line
+// serialise in L2.
+constexpr int kAccStride = 32, kAccWays = 4;
+__device__ __forceinline__ int acc_sum(const int* __restrict__ p, int a) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < kAccWays; ++w) t += p[(w * kMaxHeadings + a) * kAccStride];
+    return t;
+}
 struct StepState {                       // zeroed by the scoring epilogue (k_combine / k_exact_all) of every step
     unsigned long long amax[kMaxHeadings];      // ordered key of max_f fam[a][f]
     unsigned long long aview[kMaxHeadings];     // ~f of the first view attaining it (0 = none)
@@ -597,8 +607,8 @@ k_combine(const unsigned* __restrict__ part, const int* __restrict__ hsconst, co
     unsigned long long key = 0;
     if (f0 < c.Fpad) {
         // a chunk's sum is an int32: the bit-plane path keeps the per-heading constants out of it, so it may be negative
-        const long long base = hsconst[a];
-        const long long vbase = vconst ? vconst[a] : 0;
+        const long long base = acc_sum(hsconst, a);
+        const long long vbase = vconst ? acc_sum(vconst, a) : 0;
         long long shs[4] = {base, base, base, base};
         long long sv[4] = {vbase, vbase, vbase, vbase};
         for (int ch = 0; ch < nchunk; ++ch) {
@@ -1296,8 +1306,8 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
             val[k] = 0.0;
             if (k < At) {
                 // the chunk sums are int32 and may wrap on the way (bit-plane path: negative chunks); their total fits
-                const long long shs = (long long)hsconst[a_base + t * 16 + k] + (long long)(int)shs_u[k];
-                const long long sv = (long long)(vconst ? vconst[a_base + t * 16 + k] : 0) + (long long)(int)sv_u[k];
+                const long long shs = (long long)acc_sum(hsconst, a_base + t * 16 + k) + (long long)(int)shs_u[k];
+                const long long sv = (long long)(vconst ? acc_sum(vconst, a_base + t * 16 + k) : 0) + (long long)(int)sv_u[k];
                 double acc = c.whs * (double)shs;
                 if (has_v_sum) acc = acc + c.wv * (double)sv;
                 val[k] = (double)c.P - acc / 255.;
@@ -1916,10 +1926,13 @@ __device__ __forceinline__ bool sense_pixel(const unsigned char* __restrict__ la
 // set of the pair, which nothing uses during this step -- block 0 clears it for the next preparation, and no memset
 // sits on a step's path.  Image entries of K-steps past a segment's last pixel are never written: they were zeroed when the
 // images were allocated.
+// (the sums are read with acc_sum: kAccWays partial sums per heading, a cache line each -- with the 32 headings' sums side by side in
+// one line, the 2048 blocks of a 128x128 x 32 heading preparation queued on three lines for most of the kernel's 28 us; a line per
+// heading 16 us)
 struct PrepAcc {
-    int hs[kMaxHeadings];
-    int bhs[kMaxHeadings];
-    int bv[kMaxHeadings];
+    int hs[kAccWays * kMaxHeadings * kAccStride];
+    int bhs[kAccWays * kMaxHeadings * kAccStride];
+    int bv[kAccWays * kMaxHeadings * kAccStride];
     unsigned long long err;
     unsigned off;
     unsigned pad;
@@ -1944,7 +1957,7 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
              uint4* __restrict__ coef4) {
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
-        if (tid < kMaxHeadings) { next->hs[tid] = 0; next->bhs[tid] = 0; next->bv[tid] = 0; }
+        if (tid < kAccWays * kMaxHeadings) { next->hs[tid * kAccStride] = 0; next->bhs[tid * kAccStride] = 0; next->bv[tid * kAccStride] = 0; }
         if (tid == 0) { next->err = 0; next->off = 0; }
     }
     __shared__ unsigned char s_lut[768];                   // the sensor's level tables (3 x 256 bytes)
@@ -1953,6 +1966,9 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[256 * 3];
     __shared__ __attribute__((aligned(16))) unsigned char s_pl[(kMaxHues + 1)][256];      // stored-plane bytes of the block's pixels
     __shared__ int s_red[4][4];
+    __shared__ __attribute__((aligned(16))) unsigned s_img4[kPrepPlanes * 32];      // the block's entries of the fp4 coefficient image ...
+    __shared__ __attribute__((aligned(16))) unsigned s_img8[kPrepPlanes * 64];      // ... and of the int8 one (phase 2)
+    for (int i = tid; i < kPrepPlanes * 32; i += 256) s_img4[i] = 0u;
     if (MODE == 1 && tid < 192) reinterpret_cast<unsigned*>(s_lut)[tid] = reinterpret_cast<const unsigned*>(lut)[tid];
     if (tid < (kMaxHues + 1) * 8) s_ok[tid] = pb.ok[tid >> 3][tid & 7];
     if (tid < kPrepPlanes) s_tbl[tid] = pb.tbl[tid];
@@ -2022,53 +2038,49 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         const int grp = blk * 64 + gq;
         if (grp < c.Q * 4) prep[((long long)pl * c.Q * 4 + grp) * APAD + a] = reinterpret_cast<const unsigned*>(&s_pl[pl][0])[gq];
     }
-    // the coefficient images: entry e of this block = (segment, K-step kk of the block's T, image part, half) -- one per thread
+    // the coefficient images.  The block's 256 pixels are T whole K-steps of a segment with T planes per pixel.  Every thread puts
+    // ITS pixel's coefficients where they belong in an LDS copy of the block's entries -- element n = lp T + r of the block (plane
+    // r of local pixel lp) is bit beta = n % 32 of dword j = n / 32 % 4 of half n / 128 % 2 of K-step n / 256: the fp4 image keeps it
+    // as nibble beta / 4 of the entry of bit position beta % 4 (an LDS atomic OR), the int8 image as byte beta / 8 of the entry of
+    // slice beta % 8 (a byte store) -- and the entries then leave as whole 16-byte stores, one per thread.  (Round 3 first built each
+    // entry by one thread walking its 32 or 16 elements: 144 threads in long divergent loops, most of the kernel's 28 us at
+    // 128x128 x 32 headings.)
     if (pb.enabled) {
         const int NKT = pb.NK[0] + pb.NK[1];
         const int pass = a >> 5, al = a & 31;
+        const int TT = pb.T[0] + pb.T[1];
+        const bool real = tid < npx;
+        for (int t = 0; t < TT; ++t) {
+            const int seg = t >= pb.T[0] ? 1 : 0;
+            const int r = t - (seg ? pb.T[0] : 0), T = pb.T[seg];
+            const unsigned tb = s_tbl[t];
+            const int n = tid * T + r;
+            const int kidx = (seg ? pb.T[0] : 0) + (n >> 8), m = n & 255;
+            const int half = m >> 7, j = (m >> 5) & 3, beta = m & 31;
+            const int al_ = (int)s_pl[tb & 0xffu][tid] - (int)((tb >> 8) & 0xffu);
+            if (pb.fp4) {
+                const int wf = (int)(tb >> 24);                            // 0: a copy of a split gap's first plane
+                if (real && wf) atomicOr(&s_img4[((kidx * 4 + (beta & 3)) * 2 + half) * 4 + j], (al_ >= wf ? 0xAu : 0x2u) << (4 * (beta >> 2)));
+            }
+            const int wd = (int)((tb >> 16) & 0xffu);
+            const int alpha = al_ < 0 ? 0 : (al_ > wd ? wd : al_);
+            reinterpret_cast<unsigned char*>(s_img8)[(((kidx * 8 + (beta & 7)) * 2 + half) * 4 + j) * 4 + (beta >> 3)] = real ? (unsigned char)((wd - 2 * alpha) & 0xff) : (unsigned char)0;
+        }
+        __syncthreads();
         const int n4 = pb.fp4 ? 8 : 0;                     // entries per K-step: 4 bit positions x 2 halves (fp4), 8 slices x 2 halves (int8)
         const int per_k = n4 + 16;
-        const int total = (pb.T[0] + pb.T[1]) * per_k;
+        const int total = TT * per_k;
         for (int e = tid; e < total; e += 256) {
             const int kidx = e / per_k, part = e - kidx * per_k;
             const int seg = kidx >= pb.T[0] ? 1 : 0;
             const int kk = kidx - (seg ? pb.T[0] : 0);
-            const int T = pb.T[seg], first = seg ? pb.T[0] : 0;
-            const int ksl = blk * T + kk;                  // K-step within the segment
+            const int ksl = blk * pb.T[seg] + kk;          // K-step within the segment
             if (ksl >= pb.NK[seg]) continue;               // (past the segment's last pixel: stays zero)
             const bool is4 = part < n4;
             const int sub = is4 ? part >> 1 : (part - n4) >> 1, half = part & 1;
-            const int step = is4 ? 4 : 8, cnt = is4 ? 8 : 4;
-            const unsigned uT = (unsigned)T, qs = (unsigned)step / uT, rs = (unsigned)step % uT;
-            unsigned out[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned n = (unsigned)((kk * 2 + half) * 4 + j) * 32u + (unsigned)sub;     // element within the block's T K-steps
-                unsigned lp = n / uT, r = n - lp * uT;      // local pixel, plane within the segment
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (i < cnt) {
-                        const unsigned tb = s_tbl[first + (int)r];
-                        const bool real = (int)lp < npx;
-                        const int av = (int)s_pl[tb & 0xffu][lp & 255u];
-                        const int al_ = av - (int)((tb >> 8) & 0xffu);
-                        if (is4) {
-                            const int wf = (int)(tb >> 24);                 // 0: a copy of a split gap's first plane
-                            if (real && wf) out[j] |= (al_ >= wf ? 0xAu : 0x2u) << (4 * i);
-                        } else {
-                            const int wd = (int)((tb >> 16) & 0xffu);
-                            const int alpha = al_ < 0 ? 0 : (al_ > wd ? wd : al_);
-                            if (real) out[j] |= (unsigned)((wd - 2 * alpha) & 0xff) << (8 * i);
-                        }
-                        lp += qs; r += rs;
-                        if (r >= uT) { r -= uT; ++lp; }
-                    }
-                }
-            }
             const long long ks = (long long)pass * NKT + (seg ? pb.NK[0] : 0) + ksl;
-            const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
-            if (is4) coef4[(ks * 4 + sub) * 64 + al + 32 * half] = v;
-            else coef[(ks * 8 + sub) * 64 + al + 32 * half] = v;
+            if (is4) coef4[(ks * 4 + sub) * 64 + al + 32 * half] = reinterpret_cast<const uint4*>(s_img4)[(kidx * 4 + sub) * 2 + half];
+            else coef[(ks * 8 + sub) * 64 + al + 32 * half] = reinterpret_cast<const uint4*>(s_img8)[(kidx * 8 + sub) * 2 + half];
         }
     }
     __syncthreads();
@@ -2076,9 +2088,10 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { s0 += s_red[w][0]; s1 += s_red[w][1]; s2 += s_red[w][2]; s3 |= s_red[w][3]; }
-        if (s0) atomicAdd(&acc->hs[a], s0);
-        if (s1) atomicAdd(&acc->bhs[a], s1);
-        if (s2) atomicAdd(&acc->bv[a], s2);
+        const int slot = ((blk & (kAccWays - 1)) * kMaxHeadings + a) * kAccStride;
+        if (s0) atomicAdd(&acc->hs[slot], s0);
+        if (s1) atomicAdd(&acc->bhs[slot], s1);
+        if (s2) atomicAdd(&acc->bv[slot], s2);
         if (s3 & 1) atomicOr(&acc->off, 1u);
         if (s3 & 2) atomicOr(&acc->err, 1ull << (a / A_agent));      // bit = agent of the pass
     }
@@ -2279,7 +2292,7 @@ __device__ __forceinline__ void lds_dma_16_nt(const uint4* gsrc, unsigned lds_by
 // lists candidates against the item's own best (the superset rule of k_finish); k_fold behind the kernel folds the
 // summaries and decides.  The partial sums then cross HBM not at all, and k_finish / k_combine + k_tail drop out of the step.
 struct FuseArgs {
-    const int* hsconst;             // per-heading constants of the two sums (k_patch_prep: PrepAcc::bhs, bv)
+    const int* hsconst;             // per-heading constants of the two sums (k_patch_prep: PrepAcc::bhs, bv, read with acc_sum)
     const int* vconst;
     unsigned long long* bsum;       // [agents][nb][2][A_agent] workgroup summaries
     unsigned long long* ctmp;       // [agents][kTmpCap][2] shared extra-candidate lists
@@ -2347,7 +2360,7 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     const bool valid = a < fz.A_real;
     const int ac = valid ? a : fz.A_real - 1;
     // the lane's two per-heading constants: loaded here, or once per kernel by the caller (`consts`: one L2 round trip less per item)
-    const int hsc = consts ? consts[0] : fz.hsconst[ac], vc = consts ? consts[1] : (fz.vconst ? fz.vconst[ac] : 0);
+    const int hsc = consts ? consts[0] : acc_sum(fz.hsconst, ac), vc = consts ? consts[1] : (fz.vconst ? acc_sum(fz.vconst, ac) : 0);
     // score >= best - delta  =>  sc <= sc_best + 255 delta up to roundings of a few ulp of P: loose by far more
     const double margin = 256. * fz.delta + 256. * (double)c.P * 8.9e-16;
     const double kInf = __longlong_as_double(0x7ff0000000000000ll);
@@ -3146,8 +3159,8 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             const int a = a_off + 32 * h + (lane & 31), ac = a < fz.A_real ? a : fz.A_real - 1;
-            hconst[h][0] = fz.hsconst[ac];
-            hconst[h][1] = fz.vconst ? fz.vconst[ac] : 0;
+            hconst[h][0] = acc_sum(fz.hsconst, ac);
+            hconst[h][1] = fz.vconst ? acc_sum(fz.vconst, ac) : 0;
         }
     }
     for (long long j = 0; j < n_mine; ++j) {
