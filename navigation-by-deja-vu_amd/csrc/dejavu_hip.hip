@@ -133,6 +133,7 @@ struct dv_ctx {
     size_t btile_bytes = 0;                   // of which streamed per pass: (Fpad/32) * (NK_hs + NK_v) KB
     uint4* d_coef = nullptr;                  // [2 passes][NK][8][64] int8 coefficient image of the resident patches
     bool coef_ready = false;                  // d_coef / d_coef4 describe the resident patches
+    bool prep_dwords_ready = false;           // d_prep describes them too (k_patch_prep leaves it out for steps on the matrix cores)
     int bits_env = 1;                         // DEJAVU_BITS: 0 never build the bit planes, 1 when they save bytes, 2 whenever possible
     int mfma_tiles_env = 0, mfma_chunk_env = 0;   // DEJAVU_MFMA_TILES / DEJAVU_MFMA_CHUNK (0 = by library size)
     const int* int_hsconst = nullptr;         // constants that go with the partial sums of the last integer scoring pass
@@ -1021,6 +1022,25 @@ extern "C" int dv_sense(dv_ctx* c, const double* x, const double* y, const doubl
     return check_sense_error(c);
 }
 
+static int shape_now(dv_ctx* c);
+// The byte kernels (k_sad_tiles, k_sad_packed, k_sad_generic) read the patches as dwords of d_prep; a step on the matrix cores does
+// not (the mixed layout's saturation pass does).
+static bool needs_prep_dwords(dv_ctx* c) {
+    return c->cfg.generic || c->mixed || !c->bits_ok || shape_now(c) != 6;
+}
+// ... and if a byte kernel is about to run on patches prepared without them: from the raw bytes, nothing else touched.
+static int ensure_prep_dwords(dv_ctx* c) {
+    if (c->prep_dwords_ready) return DV_OK;
+    const dim3 grid((unsigned)(c->A * ((c->cfg.P + 255) / 256))), block(256);
+    static const PoseSet no_poses{};
+    hipLaunchKernelGGL(k_patch_prep<0>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, c->A, SensorCfg{}, (const unsigned char*)nullptr,
+                       c->d_raw_patches, c->d_prep, c->cfg, c->APAD, c->d_acc + c->acc_parity, c->d_acc + (c->acc_parity ^ 1), c->A_agent, PrepBits{},
+                       0ull, (uint4*)nullptr, (uint4*)nullptr, 1);
+    HIP_TRY(c, hipGetLastError());
+    c->prep_dwords_ready = true;
+    return DV_OK;
+}
+
 // Senses the patches of A_total headings (poses by value) straight into the scoring kernel's operand layout: ONE
 // kernel, no copy and no memset on the way (see k_sense_prep).  n_agents agents of A_agent headings each.
 static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_agents, int A_agent, unsigned long long seed) {
@@ -1037,15 +1057,19 @@ static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_ag
     const PrepBits pb = c->bits_ok ? c->pbits : PrepBits{};
     uint4* i8 = c->bits_ok ? c->d_coef : nullptr;
     uint4* i4 = (c->bits_ok && c->fp4_ok) ? c->d_coef4 : nullptr;
+    // the byte path's operand dwords only where a byte kernel will read them (launch_int_scoring writes them later if one does after all)
+    const bool dwords = needs_prep_dwords(c);
+    const int what = 2 | (dwords ? 1 : 0);
+    c->prep_dwords_ready = dwords;
     if (mode == 1)
         hipLaunchKernelGGL(k_patch_prep<1>, grid, block, 0, c->stream, c->d_land, *poses, A, c->sensor, c->d_lut, c->d_raw_patches, c->d_prep,
-                           c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4);
+                           c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4, what);
     else if (mode == 2)
         hipLaunchKernelGGL(k_patch_prep<2>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
-                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, seed, i8, i4);
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, seed, i8, i4, what);
     else
         hipLaunchKernelGGL(k_patch_prep<0>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
-                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4);
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4, what);
     HIP_TRY(c, hipGetLastError());
     c->patches_sensed = mode == 1;     // no host synchronisation here: the step's result record carries the sensor's error flag
     return enqueue_bit_prep(c);
@@ -1565,6 +1589,7 @@ static int launch_int_scoring(dv_ctx* c, hipEvent_t after_tiles, int* n_partial,
     c->int_vconst = nullptr;
     c->epilogue_fused = false;                           // set again below by a pass that finishes its own scores
     c->last_form = 0;
+    if (needs_prep_dwords(c)) { const int rc = ensure_prep_dwords(c); if (rc) return rc; }
     if (!g.generic && shape_now(c) == 6) {
         if (!c->coef_ready) { const int rc = enqueue_bit_prep(c, true); if (rc) return rc; }
         has_hs_sum = g.nhs > 0 ? 1 : 0;

@@ -1954,9 +1954,14 @@ __global__ void __launch_bounds__(256)
 k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A, SensorCfg g, const unsigned char* __restrict__ lut,
              unsigned char* __restrict__ raw, unsigned* __restrict__ prep, LibCfg c, int APAD, PrepAcc* __restrict__ acc,
              PrepAcc* __restrict__ next, int A_agent, PrepBits pb, unsigned long long seed, uint4* __restrict__ coef,
-             uint4* __restrict__ coef4) {
+             uint4* __restrict__ coef4, int what) {
+    // what: bit 0 = the byte path's operand dwords (prep) -- 393 000 four-byte stores into lines shared by 32 headings at 128x128 x 32
+    // headings, which a step on the matrix cores never reads: launch_patch_prep leaves them out there, and launch_int_scoring has
+    // them written from the raw bytes (MODE 0, what = 1) should a byte kernel run on these patches after all;
+    // bit 1 = everything else.
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0) {
+    const bool all = (what & 2) != 0;
+    if (blockIdx.x == 0 && all) {
         if (tid < kAccWays * kMaxHeadings) { next->hs[tid * kAccStride] = 0; next->bhs[tid * kAccStride] = 0; next->bv[tid * kAccStride] = 0; }
         if (tid == 0) { next->err = 0; next->off = 0; }
     }
@@ -2026,13 +2031,14 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
     // ---- phase 2: out of LDS.  Raw bytes and the byte path's operand dwords first
     const long long rbase = ((long long)a * c.P + (long long)blk * 256) * 3;
     const int npx = c.P - blk * 256 < 256 ? c.P - blk * 256 : 256;      // real pixels of this block
-    if (MODE != 0) {
+    if (MODE != 0 && all) {
         if ((rbase & 3) == 0 && npx == 256) {
             if (tid < 192) reinterpret_cast<unsigned*>(raw + rbase)[tid] = reinterpret_cast<const unsigned*>(s_raw)[tid];
         } else {
             for (int i = tid; i < npx * 3; i += 256) raw[rbase + i] = s_raw[i];
         }
     }
+    if (what & 1)
     for (int i = tid; i < c.npl * 64; i += 256) {
         const int pl = i >> 6, gq = i & 63;                // dword gq of the block: pixels blk * 256 + 4 gq ..
         const int grp = blk * 64 + gq;
@@ -2045,7 +2051,7 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
     // slice beta % 8 (a byte store) -- and the entries then leave as whole 16-byte stores, one per thread.  (Round 3 first built each
     // entry by one thread walking its 32 or 16 elements: 144 threads in long divergent loops, most of the kernel's 28 us at
     // 128x128 x 32 headings.)
-    if (pb.enabled) {
+    if (pb.enabled && all) {
         const int NKT = pb.NK[0] + pb.NK[1];
         const int pass = a >> 5, al = a & 31;
         const int TT = pb.T[0] + pb.T[1];
@@ -2084,7 +2090,7 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && all) {
         int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { s0 += s_red[w][0]; s1 += s_red[w][1]; s2 += s_red[w][2]; s3 |= s_red[w][3]; }
