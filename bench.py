@@ -288,6 +288,42 @@ def ssd_f32_block(device_index, F, h, w, A, steps):
                          "frac_algorithmic": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
 
 
+def ssd_u8_block(device_index, F, h, w, A, steps):
+    """The exact-integer SSD of uint8 views on the int8 matrix cores (`ssds`, util.pyx:171-184, on uint8 data):
+    one byte per pixel per pass of 32 headings.  Patches are uploaded every step."""
+    import navsim_amd
+    rng = np.random.default_rng(1)
+    lib = rng.integers(0, 256, (F, h, w), dtype=np.uint8)
+    patches = rng.integers(0, 256, (A, h, w), dtype=np.uint8)
+    patches[A // 2] = lib[31337 % F]
+    patches[A // 2, 0, 0] ^= 1
+    eng = navsim_amd.FamiliarityEngine(device_index)
+    try:
+        eng.set_library_u8(lib)
+        for _ in range(5):
+            r = eng.step_u8(patches)
+        if (r["best_idex"], r["best_view"], r["step_ssd"]) != (A // 2, 31337 % F, 1.0):
+            raise RuntimeError("ssd_u8: planted view not found")
+        eng.profile_kernel(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step_u8(patches)
+        dt = (time.perf_counter() - t0) / steps
+        kms, kn = eng.profile_read()
+        eng.profile_kernel(False)
+    finally:
+        eng.close()
+    passes = (A + 31) // 32
+    kern_ms = kms / max(kn, 1)
+    streamed = float(F) * h * w * passes
+    return {"workload": "%dx%d sensor, %d stored uint8 views, %d headings, ssd_u8 (exact, int8 matrix cores)" % (w, h, F, A), "dtype": "u8",
+            "value": F * A / dt, "unit": "view-comparisons/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "roofline": {"bound": "hbm", "kernel": "k_ssd_u8_mfma", "kernel_ms": kern_ms, "launches_timed": kn,
+                         "library_passes": passes, "achieved": streamed / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": streamed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "bytes_basis": "streamed library bytes (1 B/px x passes of 32 headings) = the algorithmic bytes of a uint8 library"}}
+
+
 def workload_name(w, h, F, A, cw, world):
     named = ""
     if w == h:
@@ -643,6 +679,11 @@ def main():
                 out["ssd_f32"] = ssd_f32_block(device_index, 50000, 64, 64, 16, 50)
             except Exception as e:                               # noqa: BLE001
                 out["ssd_f32"] = {"error": repr(e)}
+        if extras and args.secondary:
+            try:
+                out["ssd_u8"] = ssd_u8_block(device_index, 50000, 64, 64, 16, 50)
+            except Exception as e:                               # noqa: BLE001
+                out["ssd_u8"] = {"error": repr(e)}
         if extras and args.batch_agents > 0:
             try:
                 out["ensemble"] = ensemble_comparisons_per_s(64, 64, 16, cw, args.seed, args.batch_agents, 100000, 5)

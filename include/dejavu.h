@@ -245,6 +245,18 @@ int dv_score_f32(dv_ctx *ctx, const float *patch, double *ssdbuf);
 int dv_step_f32(dv_ctx *ctx, const float *patches, int n_headings, uint32_t flags, dv_step_result *result,
                 double *scene_ssd);
 
+/* ---- ssd_u8 metric (the same `ssds`, navsim/util.pyx:171-184, for uint8 views) ---- */
+/*
+ * views: uint8[F,h,w] single channel, h * w <= 131072.  Scores are the EXACT integer sums of squared differences -- what ssds()
+ * returns for the same data as float64 -- computed on the int8 matrix cores (sum (a-b)^2 = sum a'^2 + sum b'^2 - 2 sum a'b' with
+ * a' = a - 128).  Ties go to the first heading, then the first view; nothing is re-scored.  Up to DV_MAX_HEADINGS headings per step,
+ * 32 per pass over the library (one byte per pixel).  Results as dv_step_f32's.
+ */
+int dv_set_library_u8(dv_ctx *ctx, const uint8_t *views, int64_t n_views, int h, int w, int64_t first_view);
+int dv_score_u8(dv_ctx *ctx, const uint8_t *patch, double *ssdbuf);
+int dv_step_u8(dv_ctx *ctx, const uint8_t *patches, int n_headings, uint32_t flags, dv_step_result *result,
+               double *scene_ssd);
+
 /* ---- resident / asynchronous form (benchmarks, pipelined callers) ------ */
 /* Upload patches and prepare their device layout; no host synchronisation. */
 int dv_upload_patches(dv_ctx *ctx, const uint8_t *patches, int n_headings);

@@ -88,11 +88,18 @@ struct dv_ctx {
     int exact = 0;
 
     // library
-    int metric = 0;                           // 0 = sads_hsv (uint8 HSV), 1 = ssd_f32 (float32, one channel)
+    int metric = 0;                           // 0 = sads_hsv (uint8 HSV), 1 = ssd_f32 (float32, one channel), 2 = ssd_u8 (uint8, one channel)
     float4* d_ftiles = nullptr;               // ssd_f32 library
     float* d_fraw = nullptr;                  // [64][P] raw float patches
     float* d_fprep = nullptr;                 // [Q][4][64]
     double* d_fpart = nullptr;                // [nchunk][64][Fpad]
+    uint4* d_u8tiles = nullptr;               // ssd_u8 library: [Fpad/32][K][64] (k_retile_u8), K = ceil(P / 32) K-steps
+    unsigned char* d_u8raw = nullptr;         // [64][P] raw uint8 patches
+    uint4* d_u8prep = nullptr;                // [2][K][64] operand rows of the two passes of 32 headings
+    int* d_u8part = nullptr;                  // [u8_nchunk][64][Fpad] cross terms
+    unsigned long long* d_vnorm = nullptr;    // [Fpad] sum of (x - 128)^2 of each view
+    unsigned long long* d_pnorm = nullptr;    // [64] ... of each heading's patch
+    int u8_K = 0, u8_KC = 0, u8_nchunk = 0;   // K-steps, K-steps per LDS chunk, chunks
     bool have_lib = false;
     LibCfg cfg{};
     int h = 0, w = 0;
@@ -235,6 +242,7 @@ static void free_library(dv_ctx* c) {
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_acc); F(c->d_one); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
+    F(c->d_u8tiles); F(c->d_u8raw); F(c->d_u8prep); F(c->d_u8part); F(c->d_vnorm); F(c->d_pnorm);
     F(c->d_btiles); F(c->d_coef); F(c->d_coef4); F(c->d_ctiles); c->ctile_bytes = 0;
     c->pbits = PrepBits{};
     c->bits_ok = false; c->coef_ready = false; c->btile_bytes = 0;
@@ -930,6 +938,81 @@ extern "C" int dv_step_f32(dv_ctx* c, const float* patches, int A, uint32_t flag
     return DV_OK;
 }
 
+// ------------------------------------------------------------------ ssd_u8 metric
+// Exact SSD of single-channel uint8 views on the int8 matrix cores (k_ssd_u8_mfma); results as ssd_f32's.
+extern "C" int dv_set_library_u8(dv_ctx* c, const uint8_t* views, int64_t F, int h, int w, int64_t first) {
+    int rc = check_lib_args(c, F, h, w, 0.0);
+    if (rc) return rc;
+    if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
+    if ((long long)h * w > 131072) return fail(c, DV_ERR_INVALID, "ssd_u8: %d x %d pixels: the int32 cross terms hold at most 131072", h, w);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = alloc_library(c, F, h, w, 0.0, first, 0, nullptr, 0);       // common per-step buffers (fam, state, records)
+    if (rc) { free_library(c); return rc; }
+    LibCfg& g = c->cfg;
+    g.npl = 1; g.nhs = 0; g.hasv = 1;
+    (void)hipFree(c->d_tiles); c->d_tiles = nullptr;
+    c->metric = 2;
+    const int K = (g.P + 31) / 32;
+    c->u8_K = K;
+    c->u8_KC = K < 128 ? K : 128;                                       // 1 KB of LDS per K-step: at most 128 KB of operand rows per chunk
+    c->u8_nchunk = (K + c->u8_KC - 1) / c->u8_KC;
+    c->u8_KC = (K + c->u8_nchunk - 1) / c->u8_nchunk;                  // (chunks of equal length)
+    c->nchunk_cap = c->u8_nchunk;
+    c->tile_bytes = (size_t)(g.Fpad / 32) * K * 1024;
+    HIP_TRY(c, hipMalloc(&c->d_u8tiles, c->tile_bytes));
+    HIP_TRY(c, hipMalloc(&c->d_u8raw, (size_t)kMaxHeadings * g.P));
+    HIP_TRY(c, hipMalloc(&c->d_u8prep, (size_t)2 * K * 1024));
+    HIP_TRY(c, hipMalloc(&c->d_u8part, (size_t)c->u8_nchunk * kMaxHeadings * g.Fpad * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_vnorm, (size_t)g.Fpad * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc(&c->d_pnorm, (size_t)kMaxHeadings * sizeof(unsigned long long)));
+    unsigned char* d_raw = nullptr;
+    HIP_TRY(c, hipMalloc(&d_raw, (size_t)F * g.P));
+    hipError_t e = hipMemsetAsync(c->d_vnorm, 0, (size_t)g.Fpad * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_raw, views, (size_t)F * g.P, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const long long total = (g.Fpad / 32) * (long long)K * 64;
+        hipLaunchKernelGGL(k_retile_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_u8tiles, c->d_vnorm, c->cfg, K);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_raw);
+    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "ssd_u8 ingest: %s", hipGetErrorString(e)); }
+    c->delta = 0.0;                                                     // exact integers: ties go by index (k_tail's exact rule)
+    return DV_OK;
+}
+
+static int upload_patches_u8(dv_ctx* c, const uint8_t* patches, int A) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib || c->metric != 2) return fail(c, DV_ERR_STATE, "no ssd_u8 library set (call dv_set_library_u8 first)");
+    if (A < 1 || A > kMaxHeadings) return fail(c, DV_ERR_INVALID, "ssd_u8: n_headings %d outside [1, %d]", A, kMaxHeadings);
+    if (!patches) return fail(c, DV_ERR_INVALID, "patches is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_u8raw, patches, (size_t)A * c->cfg.P, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_pnorm, 0, (size_t)kMaxHeadings * sizeof(unsigned long long), c->stream));
+    c->A = A; c->n_agents = 1; c->A_agent = A; c->patches_sensed = false;
+    c->APAD = A <= 32 ? 32 : 64;
+    const int passes = c->APAD / 32;
+    const long long total = (long long)passes * c->u8_K * 64;
+    hipLaunchKernelGGL(k_prep_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_u8raw, c->d_u8prep, c->d_pnorm, c->cfg, c->u8_K, A,
+                       passes);
+    HIP_TRY(c, hipGetLastError());
+    return DV_OK;
+}
+
+extern "C" int dv_step_u8(dv_ctx* c, const uint8_t* patches, int A, uint32_t flags, dv_step_result* result, double* scene_ssd) {
+    int rc = upload_patches_u8(c, patches, A);
+    if (rc) return rc;
+    if (!result) return fail(c, DV_ERR_INVALID, "result is NULL");
+    rc = enqueue_step(c, flags, scene_ssd != nullptr);
+    if (rc) return rc;
+    rc = wait_step(c, result, scene_ssd);
+    if (rc) return rc;
+    negate_result(result);
+    if (scene_ssd) for (int64_t f = 0; f < c->cfg.F; ++f) scene_ssd[f] = -scene_ssd[f];
+    return DV_OK;
+}
+
 // ------------------------------------------------------------------ sensor model
 static int check_step_args(dv_ctx* c, int A);
 static int prep_patches(dv_ctx* c, int A);
@@ -1313,7 +1396,7 @@ static int prep_patches(dv_ctx* c, int A) { return launch_patch_prep(c, 0, nullp
 static int check_step_args(dv_ctx* c, int A) {
     if (!c) return DV_ERR_INVALID;
     if (!c->have_lib) return fail(c, DV_ERR_STATE, "no library set (call dv_set_library first)");
-    if (c->metric != 0) return fail(c, DV_ERR_STATE, "the resident library is ssd_f32; use the _f32 entry points");
+    if (c->metric != 0) return fail(c, DV_ERR_STATE, "the resident library is ssd_f32 / ssd_u8; use the _f32 / _u8 entry points");
     if (A < 1 || A > kMaxHeadings) return fail(c, DV_ERR_INVALID, "n_headings %d outside [1, %d]", A, kMaxHeadings);
     return DV_OK;
 }
@@ -1720,6 +1803,40 @@ static int launch_scoring(dv_ctx* c, bool with_combine = true) {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
     }
     int n_partial = 0;
+    if (c->metric == 2) {
+        // one pass of 32 headings at a time over the whole library; a workgroup of 8 waves per CU (its operand rows take up to 128 KB
+        // of LDS), two view groups per wave where the library fills every CU with such ranges, one below that; the ranges cut evenly
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_ssd_u8_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_ssd_u8_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_set = true;
+        }
+        const long long G32 = g.Fpad / 32;
+        const int tl = G32 >= 256 * 16 ? 2 : 1;
+        long long n_items = (G32 + 8 * tl - 1) / (8 * tl);
+        if (n_items < 256) n_items = G32 < 256 ? G32 : 256;
+        else n_items = (n_items + 255) / 256 * 256;                    // whole rounds of the 256 workgroups, every range the same size
+        const unsigned grid = (unsigned)(n_items < 256 ? n_items : 256);
+        const size_t lds = (size_t)c->u8_KC * 1024;
+        for (int a_off = 0; a_off < c->APAD; a_off += 32) {
+            const uint4* rows = c->d_u8prep + (size_t)(a_off / 32) * c->u8_K * 64;
+            if (tl == 2)
+                hipLaunchKernelGGL((k_ssd_u8_mfma<2>), dim3(grid), dim3(512), lds, c->stream, c->d_u8tiles, rows, c->d_u8part, c->cfg, c->u8_K, c->u8_KC,
+                                   c->u8_nchunk, c->APAD, a_off, n_items);
+            else
+                hipLaunchKernelGGL((k_ssd_u8_mfma<1>), dim3(grid), dim3(512), lds, c->stream, c->d_u8tiles, rows, c->d_u8part, c->cfg, c->u8_K, c->u8_KC,
+                                   c->u8_nchunk, c->APAD, a_off, n_items);
+        }
+        HIP_TRY(c, hipGetLastError());
+        if (prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
+        n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
+        hipLaunchKernelGGL(k_combine_u8, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_u8part, c->d_vnorm, c->d_pnorm,
+                           c->d_fam, c->d_pmax, c->d_state, c->cfg, c->u8_nchunk, c->APAD, c->n_agents);
+        HIP_TRY(c, hipGetLastError());
+        c->n_partial = n_partial;
+        return DV_OK;
+    }
     if (c->metric == 1) {
         if (c->exact) {
             hipLaunchKernelGGL(k_exact_all_f32, dim3((unsigned)(g.Fpad / 64), (unsigned)((c->A + 3) / 4)), dim3(64, 4), 0, c->stream,
@@ -1780,7 +1897,7 @@ static int launch_scoring(dv_ctx* c, bool with_combine = true) {
 // (exact scores, ssd_f32, batched passes) the release / acquire pair of the memory model is kept.
 static int step_fenced(const dv_ctx* c) {
     if (c->fenced_env >= 0) return c->fenced_env;
-    return (c->exact || c->metric == 1 || c->n_agents > 1) ? 1 : 0;
+    return (c->exact || c->metric != 0 || c->n_agents > 1) ? 1 : 0;
 }
 
 // One step on the resident patches: scoring (2 launches) + k_tail.  The result record lands in mapped host memory.
@@ -1857,7 +1974,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
         hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
                            c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result + c->result_slot,
                            c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,
-                           c->A_agent, c->delta, scene_on, c->exact, force, ++c->seq,
+                           c->A_agent, c->delta, scene_on, (c->exact || c->metric == 2) ? 1 : 0, force, ++c->seq,
                            c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr, c->metric == 1 ? 3e-6 : 0.0, step_fenced(c));
     }
     HIP_TRY(c, hipGetLastError());
@@ -2059,6 +2176,19 @@ extern "C" int dv_resolve_enqueue(dv_ctx* c) {
 
 extern "C" int dv_score_f32(dv_ctx* c, const float* patch, double* ssdbuf) {
     int rc = upload_patches_f32(c, patch, 1);
+    if (rc) return rc;
+    if (!ssdbuf) return fail(c, DV_ERR_INVALID, "ssdbuf is NULL");
+    rc = launch_scoring(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(ssdbuf, c->d_fam, (size_t)c->cfg.F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int64_t f = 0; f < c->cfg.F; ++f) ssdbuf[f] = -ssdbuf[f];
+    c->step_pending = false;
+    return DV_OK;
+}
+
+extern "C" int dv_score_u8(dv_ctx* c, const uint8_t* patch, double* ssdbuf) {
+    int rc = upload_patches_u8(c, patch, 1);
     if (rc) return rc;
     if (!ssdbuf) return fail(c, DV_ERR_INVALID, "ssdbuf is NULL");
     rc = launch_scoring(c);

@@ -62,6 +62,8 @@ struct LibCfg {
     double wv;          // 1 - cw            (util.pyx:69)
 };
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
 // Per-heading constants of a patch preparation (PrepAcc, k_patch_prep): a heading's sum is kept as kAccWays partial sums, each in
 // a cache line of its own (kAccStride ints apart) -- the blocks of a heading add to them with atomics, and atomics to ONE line
 // serialise in L2.
@@ -1714,6 +1716,182 @@ k_combine_f32(const double* __restrict__ part, double* __restrict__ fam, unsigne
     }
 }
 
+// ------------------------------------------------------------------ ssd_u8 metric: exact SSD of uint8 views on the int8 matrix cores
+// The same `ssds` (navsim/util.pyx:171-184: sum over i,j of (a[i,j] - b[i,j])**2) for single-channel uint8 views.  Squared
+// differences ARE bilinear once expanded, and in integers the expansion loses nothing:
+//     sum (a - b)^2 = sum a'^2 + sum b'^2 - 2 sum a' b',     a' = a - 128, b' = b - 128 in [-128, 127]
+// -- the cross term is an int8 GEMM (headings x views x pixels, int32 accumulate: |sum| <= P * 2^14, P <= 131 072), the norms are
+// per-view and per-heading constants.  Every score is the exact integer the reference's float64 loop produces for uint8 inputs
+// (all of its partial sums are integers below 2^53), so ties are decided by index (k_tail's exact rule) and nothing is re-scored.
+// Layouts (one K-step = 32 pixels = one v_mfma_i32_32x32x32_i8):
+//   u8tiles[g][k][lane] : uint4 = 16 pixels 32 k + 16 (lane >> 5) .. of view 32 g + (lane & 31), bytes x ^ 0x80 (= x - 128 as an
+//                         int8); bytes past the last pixel or view are 0 (they add nothing to any sum).  (View groups an odd number
+//                         of rows apart instead of K measured the same: 200 000 views x 128x128, 634 against 642 us);
+//   u8prep[pass][k][lane] : the same of heading 32 pass + (lane & 31): the A operand of a pass over the library;
+//   vnorm[f], pnorm[a] : sum of (x - 128)^2.
+// One byte per pixel crosses HBM per pass of 32 headings; the kernel is bound by that stream (one MFMA per KB of library).
+__global__ void __launch_bounds__(256)
+k_retile_u8(const unsigned char* __restrict__ raw, uint4* __restrict__ tiles, unsigned long long* __restrict__ vnorm, LibCfg c, int K) {
+    const long long total = (c.Fpad / 32) * (long long)K * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long r = t >> 6;
+    const int k = (int)(r % K);
+    const long long f = (r / K) * 32 + (lane & 31);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    unsigned long long nrm = 0;
+    if (f < c.F) {
+        const int px0 = 32 * k + 16 * (lane >> 5);
+        for (int i = 0; i < 16; ++i) {
+            if (px0 + i < c.P) {
+                const unsigned x = raw[f * (long long)c.P + px0 + i];
+                const int d = (int)x - 128;
+                nrm += (unsigned long long)(d * d);
+                w[i >> 2] |= (x ^ 0x80u) << (8 * (i & 3));
+            }
+        }
+        if (nrm) atomicAdd(&vnorm[f], nrm);
+    }
+    tiles[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// u8prep and pnorm of the resident patches (pnorm zeroed by the caller).  grid = ceil(passes * K * 64 / 256).
+__global__ void __launch_bounds__(256)
+k_prep_u8(const unsigned char* __restrict__ raw, uint4* __restrict__ prep, unsigned long long* __restrict__ pnorm, LibCfg c, int K, int A, int passes) {
+    const long long total = (long long)passes * K * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long r = t >> 6;
+    const int k = (int)(r % K);
+    const int a = (int)(r / K) * 32 + (lane & 31);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    unsigned long long nrm = 0;
+    if (a < A) {
+        const int px0 = 32 * k + 16 * (lane >> 5);
+        for (int i = 0; i < 16; ++i) {
+            if (px0 + i < c.P) {
+                const unsigned x = raw[(long long)a * c.P + px0 + i];
+                const int d = (int)x - 128;
+                nrm += (unsigned long long)(d * d);
+                w[i >> 2] |= (x ^ 0x80u) << (8 * (i & 3));
+            }
+        }
+        if (nrm) atomicAdd(&pnorm[a], nrm);
+    }
+    prep[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// The cross terms of one pass (32 headings at a_off) over the library.  A workgroup of 8 waves keeps the pass's operand rows of a
+// chunk of KC K-steps in LDS (KC KB) and walks its items -- the library cut evenly into n_items ranges of at most 8 TL view groups,
+// TL per wave (nothing but the stream sets this kernel's time, so every CU should stream the same share) -- through that chunk
+// before it loads the next: the library crosses HBM once per pass, and part[chunk][heading][view] (int32) takes the chunk's sums.
+// A wave streams its view groups' rows (1 KB per wave-instruction, consecutive K-steps consecutive in memory) into registers eight
+// K-steps ahead: two sets of TL x 8 rows alternate, so 16 KB per wave are on their way while the other 16 KB are multiplied.
+template <int TL>
+__global__ void __launch_bounds__(512)
+k_ssd_u8_mfma(const uint4* __restrict__ tiles, const uint4* __restrict__ prep, int* __restrict__ part, LibCfg c, int K, int KC, int nchunk,
+              int apad_total, int a_off, long long n_items) {
+    extern __shared__ uint4 lds_rows[];                       // [KC][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long G32 = c.Fpad / 32;
+    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int k0 = ch * KC, kn = (K - k0) < KC ? (K - k0) : KC;
+        __syncthreads();                                       // everybody is done with the chunk before
+        for (int i = tid; i < kn * 64; i += 512) lds_rows[i] = prep[(long long)k0 * 64 + i];
+        __syncthreads();
+        for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+            const uint4* base[TL];
+            long long gidx[TL];
+            bool live[TL];
+            const long long g0 = (item * G32) / n_items, g1 = ((item + 1) * G32) / n_items;
+#pragma unroll
+            for (int t = 0; t < TL; ++t) {
+                const long long g = g0 + wave * TL + t;
+                live[t] = g < g1;
+                gidx[t] = live[t] ? g : G32 - 1;               // a slot without a view group re-reads the last one (never stored)
+                base[t] = tiles + (gidx[t] * K + k0) * 64 + lane;
+            }
+            v16i_t acc[TL];
+#pragma unroll
+            for (int t = 0; t < TL; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+            v4i_t buf[2][TL][8];
+            auto load = [&](v4i_t (&dst)[TL][8], int kb) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kb + j < kn ? kb + j : kn - 1;   // (past the chunk: its last row again, not multiplied)
+#pragma unroll
+                    for (int t = 0; t < TL; ++t) dst[t][j] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(base[t] + (long long)k * 64));
+                }
+            };
+            auto multiply = [&](const v4i_t (&src)[TL][8], int kb) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (kb + j < kn) {
+                        const v4i_t a = *reinterpret_cast<const v4i_t*>(&lds_rows[(kb + j) * 64 + lane]);
+#pragma unroll
+                        for (int t = 0; t < TL; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, src[t][j], acc[t], 0, 0, 0);      // headings x views
+                    }
+                }
+            };
+            load(buf[0], 0);
+            for (int kb = 0; kb < kn; kb += 16) {
+                if (kb + 8 < kn) load(buf[1], kb + 8);
+                multiply(buf[0], kb);
+                if (kb + 16 < kn) load(buf[0], kb + 16);
+                if (kb + 8 < kn) multiply(buf[1], kb + 8);
+            }
+#pragma unroll
+            for (int t = 0; t < TL; ++t) {
+                if (!live[t]) continue;
+                int* dst = part + ((long long)ch * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < rows) dst[(long long)m * c.Fpad] = acc[t][r];
+                }
+            }
+        }
+    }
+}
+
+// fam[a][f] = -(vnorm[f] + pnorm[a] - 2 * sum over chunks of part): the exact SSD, negated like ssd_f32's; per-block maxima as in k_combine.
+__global__ void __launch_bounds__(256)
+k_combine_u8(const int* __restrict__ part, const unsigned long long* __restrict__ vnorm, const unsigned long long* __restrict__ pnorm,
+             double* __restrict__ fam, unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD,
+             int n_agents) {
+    __shared__ unsigned long long wmax[4];
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x, n_agents);
+    unsigned long long key = 0;
+    if (f < c.F) {
+        long long dot = 0;
+        for (int ch = 0; ch < nchunk; ++ch) dot += (long long)part[((long long)ch * APAD + a) * c.Fpad + f];
+        const long long ssd = (long long)vnorm[f] + (long long)pnorm[a] - 2 * dot;
+        const double val = -(double)ssd;
+        fam[(long long)a * c.Fpad + f] = val;
+        key = ordered_key(val);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmax[0];
+        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+        blockmax[(long long)a * gridDim.x + blockIdx.x] = m;
+    }
+}
+
 // Every (heading, view) SSD exact (overflow fallback / exact mode of the f32 metric).  grid = (G, ceil(A/4)), block (64,4).
 __global__ void __launch_bounds__(256)
 k_exact_all_f32(const float4* __restrict__ ftiles, const float* __restrict__ raw_patches, double* __restrict__ fam,
@@ -2260,8 +2438,6 @@ k_bitpack_code(const uint4* __restrict__ btiles, unsigned* __restrict__ ctiles, 
     }
 }
 
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 

@@ -136,6 +136,9 @@ PROTOTYPES = {
     "dv_score_f32": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float), _f64p]),
     "dv_step_f32": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_uint32,
                                    ctypes.POINTER(StepResult), _f64p]),
+    "dv_set_library_u8": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "dv_score_u8": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
+    "dv_step_u8": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
     "dv_upload_patches": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int]),
     "dv_generate_patches": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int]),
     "dv_step_enqueue": (ctypes.c_int, [_ctx_p, ctypes.c_uint32]),

@@ -303,6 +303,39 @@ class FamiliarityEngine(object):
                     angle_ssd=d["angle_familiarity"], angle_view=d["angle_view"], n_candidates=d["n_candidates"],
                     flags=d["flags"], scene_ssd=scene)
 
+    # -- ssd_u8 metric: exact SSD of uint8 views on the int8 matrix cores -------------------------------
+    def set_library_u8(self, views, first_view=0):
+        """views: uint8[F,h,w]; scores are the exact integer sums of squared differences (navsim/util.pyx:171-184 on uint8 data)."""
+        views = N.as_u8(views, "views")
+        if views.ndim != 3:
+            raise ValueError("views must be uint8[F,h,w], got shape %r" % (views.shape,))
+        F, h, w = views.shape
+        self._check(self._lib.dv_set_library_u8(self._ctx, N.u8ptr(views), F, h, w, int(first_view)), "dv_set_library_u8")
+        self.n_views, self.shape = F, (h, w)
+
+    def score_u8(self, patch, ssdbuf=None):
+        patch = N.as_u8(patch, "patch")
+        if tuple(patch.shape) != self.shape:
+            raise ValueError("patch has shape %r, expected %r" % (patch.shape, self.shape))
+        if ssdbuf is None:
+            ssdbuf = np.empty(self.n_views, dtype=np.float64)
+        self._check(self._lib.dv_score_u8(self._ctx, N.u8ptr(patch), N.f64ptr(ssdbuf)), "dv_score_u8")
+        return ssdbuf
+
+    def step_u8(self, patches, want_scene=False):
+        """Least-SSD heading over uint8 patches [A,h,w]: dict with angle_ssd, best_idex, best_view, step_ssd (exact integers)."""
+        patches = N.as_u8(patches, "patches")
+        if patches.ndim != 3 or tuple(patches.shape[1:]) != self.shape:
+            raise ValueError("patches must be uint8[A,%d,%d]" % self.shape)
+        r = N.StepResult()
+        scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
+        self._check(self._lib.dv_step_u8(self._ctx, N.u8ptr(patches), patches.shape[0], 0, ctypes.byref(r),
+                                         N.f64ptr(scene) if want_scene else None), "dv_step_u8")
+        d = self._result_dict(r, scene)
+        return dict(best_idex=d["best_idex"], best_view=d["best_view"], step_ssd=d["step_familiarity"],
+                    angle_ssd=d["angle_familiarity"], angle_view=d["angle_view"], n_candidates=d["n_candidates"],
+                    flags=d["flags"], scene_ssd=scene)
+
     def resolve(self):
         r = N.StepResult()
         self._check(self._lib.dv_resolve(self._ctx, ctypes.byref(r)), "dv_resolve")

@@ -575,6 +575,107 @@ def test_ssd_f32_ties_and_duplicates(eng):
     assert r["best_idex"] == 0 and r["best_view"] == 20 and r["step_ssd"] == 0.0
 
 
+def _ssd_u8_reference(lib, patches):
+    """[A, F] exact integer SSDs: the oracle's ssds (navsim/util.pyx:171-184) on the float64 upcast where the case is small enough,
+    int64 arithmetic (equal to it: every partial sum of ssds is an integer below 2^53) everywhere."""
+    l = lib.reshape(len(lib), -1).astype(np.int64)
+    p = patches.reshape(len(patches), -1).astype(np.int64)
+    want = np.stack([((l - p[a]) ** 2).sum(axis=1) for a in range(len(p))]).astype(np.float64)
+    for a, f in ((0, 0), (len(p) - 1, len(l) - 1), (len(p) // 2, len(l) // 3)):
+        assert oracle.ssds(patches[a].astype(np.float64), lib[f].astype(np.float64)) == want[a, f]
+    return want
+
+
+@pytest.mark.parametrize("F,h,w,A", [(1, 1, 1, 1), (31, 5, 7, 3), (33, 8, 4, 32), (700, 12, 20, 33), (2049, 32, 32, 16), (5000, 64, 64, 64),
+                                      (300, 70, 67, 9), (1000, 100, 50, 40)])
+def test_ssd_u8_metric_is_exact(eng, F, h, w, A):
+    """ssd_u8 (int8 matrix cores, k_ssd_u8_mfma): every score equals the reference's ssds on the same uint8 data bit for bit,
+    ragged sizes (pixels not a multiple of 32, views not of 32, 1..64 headings = one and two passes, more than one LDS chunk of
+    K-steps at 70x67 and 100x50), extreme bytes included; the decision is the first heading, then the first view, of the minimum."""
+    rng = np.random.default_rng(F * 11 + A)
+    lib = rng.integers(0, 256, (F, h, w), dtype=np.uint8)
+    patches = rng.integers(0, 256, (A, h, w), dtype=np.uint8)
+    lib[F // 2] = 255
+    patches[0] = 0                                            # the largest differences there are
+    if F > 100:
+        patches[A // 2] = lib[F // 3]
+        patches[A // 2, 0, 0] ^= 1                           # a near match: SSD 1
+    want = _ssd_u8_reference(lib, patches)
+    eng.set_library_u8(lib)
+    r = eng.step_u8(patches, want_scene=True)
+    best_a = int(np.argmin(want.min(axis=1)))
+    assert r["best_idex"] == best_a and r["best_view"] == int(np.argmin(want[best_a]))
+    assert np.array_equal(np.array(r["angle_ssd"]), want.min(axis=1))
+    assert [int(v) for v in r["angle_view"]] == [int(np.argmin(want[a])) for a in range(A)]
+    assert np.array_equal(r["scene_ssd"], want.max(axis=0))
+    assert r["step_ssd"] == want.min()
+    for a in (0, A - 1):
+        assert np.array_equal(eng.score_u8(patches[a]), want[a])
+    with pytest.raises(ValueError):
+        eng.set_library_u8(lib.astype(np.float32))
+    with pytest.raises((ValueError, navsim_amd.EngineError)):
+        eng.step(np.zeros((2, h, w, 3), dtype=np.uint8))            # sads_hsv entry point on an ssd_u8 library
+    with pytest.raises((ValueError, navsim_amd.EngineError)):
+        eng.step_f32(np.zeros((2, h, w), dtype=np.float32))
+
+
+def test_ssd_u8_ties_go_to_the_first_heading_and_view(eng):
+    rng = np.random.default_rng(8)
+    lib = rng.integers(0, 256, (900, 9, 11), dtype=np.uint8)
+    lib[700] = lib[40]
+    lib[41] = lib[40]                                        # three identical views
+    patches = rng.integers(0, 256, (12, 9, 11), dtype=np.uint8)
+    patches[7] = lib[700]
+    patches[3] = lib[41]                                     # two headings at SSD 0: heading 3 and view 40 win
+    eng.set_library_u8(lib)
+    r = eng.step_u8(patches)
+    assert (r["best_idex"], r["best_view"], r["step_ssd"]) == (3, 40, 0.0)
+    assert int(r["angle_view"][7]) == 40
+    lib[:] = lib[0]                                          # a library of duplicates: every heading ties on every view
+    eng.set_library_u8(lib)
+    r = eng.step_u8(patches)
+    want = _ssd_u8_reference(lib, patches)
+    assert r["best_idex"] == int(np.argmin(want[:, 0])) and r["best_view"] == 0
+
+
+def test_ssd_u8_full_size_properties():
+    """ssd_u8 on BASELINE configs[1]'s shape (64x64, 50 000 views; 16 and 64 headings): planted copies win at their headings with
+    the exact SSDs of the reference on the planted pairs and on sampled views, and complementing every byte (x -> 255 - x) of both
+    operands leaves every SSD unchanged."""
+    F, h, w = 50000, 64, 64
+    rng = np.random.default_rng(3)
+    lib = rng.integers(0, 256, (F, h, w), dtype=np.uint8)
+    eng = navsim_amd.FamiliarityEngine(0)
+    try:
+        eng.set_library_u8(lib)
+        for A in (16, 64):
+            patches = rng.integers(0, 256, (A, h, w), dtype=np.uint8)
+            patches[A - 3] = lib[31337]
+            patches[A - 3, 5, 5] ^= 0x10
+            patches[2] = lib[49999]
+            patches[2, :2] = 255 - patches[2, :2]
+            r = eng.step_u8(patches, want_scene=True)
+            assert (r["best_idex"], r["best_view"]) == (A - 3, 31337) and r["step_ssd"] == 256.0
+            assert int(r["angle_view"][2]) == 49999
+            for a, f in ((A - 3, 31337), (2, 49999), (0, 12345), (A - 1, 0)):
+                want = oracle.ssds(patches[a].astype(np.float64), lib[f].astype(np.float64))
+                if (a, f) in ((A - 3, 31337), (2, 49999)):
+                    assert r["angle_ssd"][a] == want
+                assert eng.score_u8(patches[a])[f] == want
+            sample = rng.integers(0, F, 64)
+            l = lib[sample].reshape(64, -1).astype(np.int64)
+            p = patches.reshape(A, -1).astype(np.int64)
+            want_max = np.stack([((l - p[a]) ** 2).sum(axis=1) for a in range(A)]).max(axis=0)
+            assert np.array_equal(r["scene_ssd"][sample], want_max.astype(np.float64))
+            if A == 16:
+                first, p16 = np.array(r["angle_ssd"]), patches
+        eng.set_library_u8(255 - lib)
+        r = eng.step_u8(255 - p16)
+        assert np.array_equal(np.array(r["angle_ssd"]), first) and (r["best_idex"], r["best_view"]) == (13, 31337)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("A", [5, 16, 30, 64])
 def test_every_workgroup_shape_gives_identical_results(A):
     """The scoring kernel's forms (1 single-wave, 2 four waves + LDS sums, 3/4 heading ways, 5 packed accumulators;
