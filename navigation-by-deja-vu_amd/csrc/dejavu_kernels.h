@@ -30,10 +30,15 @@ namespace dv {
 // Diagnostic builds only (tools/exp/stamps.py compiles a copy with -DDEJAVU_STAMPS): wall-clock stamps (100 MHz counter)
 // of the matrix-core kernel's phases per workgroup, in a buffer nothing else reads.  The product build has no stamps.
 #ifdef DEJAVU_STAMPS
+#ifdef DEJAVU_EXP_FIN
+#define DV_EXP_FIN_ON 1
+#else
+#define DV_EXP_FIN_ON 0
+#endif
 __device__ unsigned long long g_dv_stamps[256 * 8];
 // (slots 6 and 7: the shader-clock counter beside stamps 1 and 2 -- the clock the CU held during the first item's loop)
 #define DV_STAMP(i) do { if (threadIdx.x == 0) { g_dv_stamps[(blockIdx.x & 255) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-    if ((i) == 1 || (i) == 2) g_dv_stamps[(blockIdx.x & 255) * 8 + 5 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    if (((i) == 1 || (i) == 2) && !DV_EXP_FIN_ON) g_dv_stamps[(blockIdx.x & 255) * 8 + 5 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define DV_STAMP(i) do { } while (0)
 #endif
@@ -2504,7 +2509,7 @@ constexpr int kFuseQueue = 256;
 constexpr int kFuseBlk = 2 * 8 * 32 + 4 * 32 + 2 * kFuseQueue + 2;      // 8-byte words in front of the workgroup's running summary
 constexpr int kFuseScratchBytes = (kFuseBlk + 2 * 32) * 8;
 
-template <int TILES, int NW, typename HsOf, typename VOf>
+template <int TILES, int NW, bool FAST = false, typename HsOf, typename VOf>
 __device__ __forceinline__ void
 fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&live)[TILES],
              unsigned long long* scratch, const LibCfg& c, const FuseArgs& fz, int a_off, int has_hs_sum, long long gq, int lane, int wave,
@@ -2566,6 +2571,47 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     // "within the margin of the final smallest": the smallest only falls) -- rare, and only then are the entries walked
     // again to queue those within the margin of the final smallest.
     bool near = false;
+    // First in fp32 (a quarter of the instructions' cost): sc to ~2.4e-7 relative (four roundings of non-negative terms), its
+    // smallest and second smallest value per lane.  Where the second smallest clears the smallest by more than both errors and the
+    // margin -- every lane of the wave, nearly always -- the fp32 minimum IS the fp64 one, nothing else lies within the margin of it,
+    // and the one fp64 evaluation of that entry gives exactly what the walk below gives.  Otherwise the wave takes the walk.
+    // (tools/exp/stamps.py -DDEJAVU_EXP_FIN: the fp64 walk was 3.4-3.9 us of the finishing's 4.6-5.2.)
+    bool walked = false;
+    if constexpr (FAST) {
+        const float whs32 = (float)c.whs, wv32 = (float)c.wv;
+        const float kInfF = __int_as_float(0x7f800000);
+        const float margin32 = (float)margin * 1.01f + 1e-30f;
+        float m32 = kInfF, s32 = kInfF;
+        int mi = 0, m_shs = 0, m_sv = 0;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int vv = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int shs = hsc + (has_hs_sum ? hs_of(t, r) : 0);
+                const int sv = vc + (c.hasv ? v_of(t, r) : 0);
+                float e = whs32 * (float)shs;
+                if (c.hasv) e = __builtin_fmaf(wv32, (float)sv, e);
+                e = vv < nreal[t] ? e : kInfF;
+                const bool less = e < m32;                     // "<" keeps the first minimum
+                s32 = less ? m32 : (e < s32 ? e : s32);
+                m_shs = less ? shs : m_shs;
+                m_sv = less ? sv : m_sv;
+                mi = less ? t * 32 + vv : mi;
+                m32 = less ? e : m32;
+            }
+        const bool unclear = m32 != kInfF && s32 <= m32 * 1.000002f + margin32;
+        if (!__any(unclear)) {
+            if (m32 != kInfF) {
+                double sc = c.whs * (double)m_shs;
+                if (c.hasv) sc = sc + c.wv * (double)m_sv;
+                bs = sc;
+                bi = mi;
+            }
+            walked = true;
+        }
+    }
+    if (!walked) {
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -2575,6 +2621,7 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
             near |= less ? (bs <= sc + margin) : (sc <= bs + margin && sc != kInf);
             if (less) { bs = sc; bi = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
         }
+    }
     if (__any(near)) {
         const double lim = bs + margin;
 #pragma unroll
@@ -2602,6 +2649,9 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
                 }
             }
     }
+#ifdef DEJAVU_EXP_FIN
+    if (threadIdx.x == 0 && gq == 0) g_dv_stamps[(blockIdx.x & 255) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
     unsigned long long own_v = ~0ull;                          // the view of the lane's smallest
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
@@ -2670,6 +2720,9 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
         __hip_atomic_store(&abest[n], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // clear for the next call (this wave alone touches it)
     }
     __syncthreads();
+#ifdef DEJAVU_EXP_FIN
+    if (threadIdx.x == 0 && gq == 0) g_dv_stamps[(blockIdx.x & 255) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
     auto list = [&](int m, double sc, unsigned long long f) {  // heading a_off + m of the pass, an entry within the loose bound
         const unsigned long long k = ordered_key((double)c.P - sc / 255.);
         if (k >= thr_key[m] && f != item_view[m]) {
@@ -2875,8 +2928,8 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
                     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(lds_ring + RD * SLOT16);
                     auto of_tot = [&](int t, int r) -> int { return tot[t][r]; };
                     auto of_park = [&](int t, int r) -> int { return parkr[t][r]; };
-                    if (seg == 0) fused_finish<TILES, NW>(of_tot, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin);
-                    else fused_finish<TILES, NW>(of_park, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin);
+                    if (seg == 0) fused_finish<TILES, NW, false>(of_tot, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin);
+                    else fused_finish<TILES, NW, false>(of_park, of_tot, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin);
                     ++nfin;
                 }
             }
@@ -3183,7 +3236,7 @@ sad_ring_fp4(const uint4* __restrict__ btiles, const uint4* __restrict__ coef4, 
             auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
             auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
             if (item == blockIdx.x) DV_STAMP(3);
-            fused_finish<TILES, NW>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin++);
+            fused_finish<TILES, NW, false>(of_hs, of_v, gidx, live, scratch, c, fz, a_off, has_hs_sum, gq, lane, wave, nfin++);
             if (item == blockIdx.x) DV_STAMP(4);
         }
     }
@@ -3564,14 +3617,14 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
             if constexpr (HT == 1) {
                 auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
                 auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
-                fused_finish<TL, NW>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off, has_hs_sum, j, lane, wave, (int)(j & 1), NC, loader, hconst[0]);
+                fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off, has_hs_sum, j, lane, wave, (int)(j & 1), NC, loader, hconst[0]);
             } else {
 #pragma unroll
                 for (int h = 0; h < HT; ++h) {
                     auto of_hs = [&](int, int r) -> int { return tot_hs[h][r]; };
                     auto of_v = [&](int, int r) -> int { return tot_v[h][r]; };
                     if (a_off + 32 * h < fz.A_real)                     // (uniform: a heading tile without headings has nothing to finish)
-                        fused_finish<TL, NW>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, loader,
+                        fused_finish<TL, NW, false>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, loader,
                                              hconst[h], scratch0 + kFuseBlk + h * 64);
                 }
             }

@@ -39,6 +39,11 @@ for i, n in enumerate(names):
 for i in range(1, 6):
     d = (st[:, i] - st[:, i - 1]) / 100.0
     print("phase %d->%d: median %7.2f us  max %7.2f" % (i - 1, i, np.median(d), d.max()))
-clk = (st[:, 7] - st[:, 6]) / np.maximum(st[:, 2] - st[:, 1], 1) * 100.0
-print("shader clock during the first item's loop: median %.0f MHz  min %.0f  max %.0f" % (np.median(clk), clk.min(), clk.max()))
+if os.environ.get("STAMPS_FIN"):          # a build with -DDEJAVU_EXP_FIN: slots 6, 7 = inside the first item's fused finishing
+    for a, b, what in ((3, 6, "entries walked (this wave)"), (6, 7, "hand-over, item summary, thresholds (two barriers)"), (7, 4, "candidates listed, last barrier")):
+        d = (st[:, b] - st[:, a]) / 100.0
+        print("finishing, %-52s median %6.2f us  max %6.2f" % (what + ":", np.median(d), d.max()))
+else:
+    clk = (st[:, 7] - st[:, 6]) / np.maximum(st[:, 2] - st[:, 1], 1) * 100.0
+    print("shader clock during the first item's loop: median %.0f MHz  min %.0f  max %.0f" % (np.median(clk), clk.min(), clk.max()))
 eng.close()
