@@ -6,7 +6,7 @@ library resident in HBM (patch preparation, scoring kernel, per-view/per-heading
 resolver, result read-back), i.e. what replaces navsim/NavBySceneFamiliarity.py:283-316 +
 navsim/util.pyx:31-73.  Every timed step scores FRESH patches (generated on the device from seed + step, as the
 reference senses new patches at every step, NavBySceneFamiliarity.py:289-299), so the per-step preparation
-kernels (k_patch_prep, k_coef_image) are inside the timed region; `scoring_only` repeats the measurement on
+kernel (k_patch_prep: patches, coefficient images, constants) is inside the timed region; `scoring_only` repeats the measurement on
 resident patches (the figure rounds 1-2 reported as the headline).
 
 Workload at N=1: BASELINE.json configs[2] -- 128x128 sensor, 500 000 stored views, 32 headings (the largest
@@ -530,7 +530,7 @@ def main():
 
     def one_step(fresh=None):
         if fresh is not None:
-            eng.generate_patches(fresh, A)            # new patches in HBM (same on every rank): k_patch_prep + k_coef_image
+            eng.generate_patches(fresh, A)            # new patches in HBM (same on every rank): k_patch_prep
         if exchange is not None:
             return exchange.step()
         if use_dist:
@@ -612,8 +612,8 @@ def main():
             "config": {
                 "workload": workload,
                 "views_per_gpu": F, "total_views": world * F, "headings": A, "sensor": [w, h],
-                "timed_region": "per step: fresh patches made in HBM (k_patch_prep, generator mode) + their coefficient "
-                                "image (k_coef_image) + scoring kernel + reductions + decision + result read-back.  The "
+                "timed_region": "per step: fresh patches made in HBM with their coefficient images and constants "
+                                "(k_patch_prep, generator mode) + scoring kernel + reductions + decision + result read-back.  The "
                                 "sensor model proper (k_patch_prep in sensing mode: same kernel, landscape fetches instead "
                                 "of the generator) is timed in the `agent` block; the per-view scene_familiarity output "
                                 "(plot-only in the reference, NavBySceneFamiliarity.py:301-303) is not produced",
@@ -632,7 +632,7 @@ def main():
             },
             "nav_steps_per_s": args.steps / dt,
             "scoring_only": {"value": comparisons / dt_resident, "ms_per_step": dt_resident / args.steps * 1e3,
-                             "what": "the same K steps on resident patches (no k_patch_prep / k_coef_image): the figure "
+                             "what": "the same K steps on resident patches (no k_patch_prep): the figure "
                                      "rounds 1-2 reported as the headline"},
             "layout": {
                 "chosen": ("thermometer bit planes on the matrix cores" if shape == 6 else "byte planes, v_sad_u8"),
