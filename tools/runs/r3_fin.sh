@@ -1,3 +1,4 @@
+# Build first: STAMPS_SO=libdejavu_stamps_fin.so python3 tools/exp/stamps.py build -DDEJAVU_EXP_FIN
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/fin
 timeout -k 5 700 python -m pytest tests -m gpu -q -x > gpurun_out/fin/pytest.log 2>&1
