@@ -1123,11 +1123,6 @@ __device__ __forceinline__ void fold_and_decide(const unsigned long long* __rest
     __shared__ unsigned s_ntmp;
     __shared__ int s_serr;
     __shared__ StepResultDev s_res;
-    if (tid < kMaxHeadings) { s_amax[tid] = 0; s_aview[tid] = ~0ull; }
-    if (tid == 0) s_ncount = 0;
-    if (tid == 64) s_ntmp = __hip_atomic_load(&st->ntmp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 128) s_serr = sense_err ? (int)((*sense_err >> agent) & 1ull) : 0;          // bit = agent of the pass
-    __syncthreads();
     const int G = blockDim.x / A;                       // thread groups; thread (a, r) walks blocks r, r+G, ...
     const int a = tid % A, r = tid / A;
     const bool active = r < G;
@@ -1138,15 +1133,22 @@ __device__ __forceinline__ void fold_and_decide(const unsigned long long* __rest
     unsigned long long k8[kBatch], v8[kBatch];
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) { k8[j] = 0; v8[j] = ~0ull; }
+    if (active && single) {                             // (requested in front of the barrier: in the same round trip as ntmp and the error bit)
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int b = (r + j * G < nb) ? r + j * G : nb - 1;                   // clamped: no conditional loads
+            k8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 0) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 1) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid < kMaxHeadings) { s_amax[tid] = 0; s_aview[tid] = ~0ull; }
+    if (tid == 0) s_ncount = 0;
+    if (tid == 64) s_ntmp = __hip_atomic_load(&st->ntmp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 128) s_serr = sense_err ? (int)((*sense_err >> agent) & 1ull) : 0;          // bit = agent of the pass
+    __syncthreads();
     if (active) {
         unsigned long long lk = 0;
         if (single) {
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const int b = (r + j * G < nb) ? r + j * G : nb - 1;               // clamped: no conditional loads
-                k8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 0) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v8[j] = __hip_atomic_load(&bsum[((long long)b * 2 + 1) * A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 if (r + j * G >= nb) k8[j] = 0;                                     // a clamped repeat: not an entry
