@@ -247,7 +247,7 @@ int dv_step_f32(dv_ctx *ctx, const float *patches, int n_headings, uint32_t flag
 
 /* ---- ssd_u8 metric (the same `ssds`, navsim/util.pyx:171-184, for uint8 views) ---- */
 /*
- * views: uint8[F,h,w] single channel, h * w <= 131072.  Scores are the EXACT integer sums of squared differences -- what ssds()
+ * views: uint8[F,h,w] single channel, h * w <= 131071.  Scores are the EXACT integer sums of squared differences -- what ssds()
  * returns for the same data as float64 -- computed on the int8 matrix cores (sum (a-b)^2 = sum a'^2 + sum b'^2 - 2 sum a'b' with
  * a' = a - 128).  Ties go to the first heading, then the first view; nothing is re-scored.  Up to DV_MAX_HEADINGS headings per step,
  * 32 per pass over the library (one byte per pixel).  Results as dv_step_f32's.

@@ -944,7 +944,7 @@ extern "C" int dv_set_library_u8(dv_ctx* c, const uint8_t* views, int64_t F, int
     int rc = check_lib_args(c, F, h, w, 0.0);
     if (rc) return rc;
     if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
-    if ((long long)h * w > 131072) return fail(c, DV_ERR_INVALID, "ssd_u8: %d x %d pixels: the int32 cross terms hold at most 131072", h, w);
+    if ((long long)h * w > 131071) return fail(c, DV_ERR_INVALID, "ssd_u8: %d x %d pixels: the int32 cross terms hold at most 131071", h, w);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     rc = alloc_library(c, F, h, w, 0.0, first, 0, nullptr, 0);       // common per-step buffers (fam, state, records)

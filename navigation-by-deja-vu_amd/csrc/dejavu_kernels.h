@@ -1727,7 +1727,7 @@ k_combine_f32(const double* __restrict__ part, double* __restrict__ fam, unsigne
 // The same `ssds` (navsim/util.pyx:171-184: sum over i,j of (a[i,j] - b[i,j])**2) for single-channel uint8 views.  Squared
 // differences ARE bilinear once expanded, and in integers the expansion loses nothing:
 //     sum (a - b)^2 = sum a'^2 + sum b'^2 - 2 sum a' b',     a' = a - 128, b' = b - 128 in [-128, 127]
-// -- the cross term is an int8 GEMM (headings x views x pixels, int32 accumulate: |sum| <= P * 2^14, P <= 131 072), the norms are
+// -- the cross term is an int8 GEMM (headings x views x pixels, int32 accumulate: |sum| <= P * 2^14, P <= 131 071), the norms are
 // per-view and per-heading constants.  Every score is the exact integer the reference's float64 loop produces for uint8 inputs
 // (all of its partial sums are integers below 2^53), so ties are decided by index (k_tail's exact rule) and nothing is re-scored.
 // Layouts (one K-step = 32 pixels = one v_mfma_i32_32x32x32_i8):

@@ -638,6 +638,27 @@ def test_ssd_u8_ties_go_to_the_first_heading_and_view(eng):
     assert r["best_idex"] == int(np.argmin(want[:, 0])) and r["best_view"] == 0
 
 
+def test_ssd_u8_largest_patch_and_extreme_bytes(eng):
+    """The int32 cross terms at their limit: 131 071 pixels of bytes 0 (a' = -128 everywhere: the largest products) and 255, thirty
+    LDS chunks of K-steps; one pixel more is refused."""
+    h, w = 131071, 1
+    lib = np.zeros((40, h, w), dtype=np.uint8)
+    lib[7] = 255
+    lib[9, ::2] = 255
+    patches = np.zeros((3, h, w), dtype=np.uint8)
+    patches[1] = 255
+    patches[2, 1::2] = 255
+    eng.set_library_u8(lib)
+    r = eng.step_u8(patches, want_scene=True)
+    want = _ssd_u8_reference(lib, patches)
+    assert np.array_equal(np.array(r["angle_ssd"]), want.min(axis=1)) and np.array_equal(r["scene_ssd"], want.max(axis=0))
+    assert want.max() == 131071 * 255.0 ** 2 and (r["best_idex"], r["best_view"]) == (0, 0)
+    for a in range(3):
+        assert np.array_equal(eng.score_u8(patches[a]), want[a])
+    with pytest.raises((ValueError, navsim_amd.EngineError)):
+        eng.set_library_u8(np.zeros((2, 131072, 1), dtype=np.uint8))
+
+
 def test_ssd_u8_full_size_properties():
     """ssd_u8 on BASELINE configs[1]'s shape (64x64, 50 000 views; 16 and 64 headings): planted copies win at their headings with
     the exact SSDs of the reference on the planted pairs and on sampled views, and complementing every byte (x -> 255 - x) of both

@@ -295,6 +295,24 @@ def test_fp4_form_identity_and_plan():
         assert [b0 | b1, b1, b2, b0 & b2] == [int(level >= t) for t in (1, 2, 3, 4)]
 
 
+def test_ssd_u8_expansion_is_exact():
+    """What k_ssd_u8_mfma rests on (csrc/dejavu_kernels.h, "ssd_u8 metric"): with a' = a - 128 stored as the byte a ^ 0x80 read as
+    an int8, sum (a-b)^2 = sum a'^2 + sum b'^2 - 2 sum a'b' in integers, equal to the oracle's ssds (navsim/util.pyx:171-184) on the
+    same uint8 data; and the cross term of the largest allowed patch (131 071 pixels of extreme bytes) still fits an int32."""
+    rng = np.random.default_rng(12)
+    for shape in ((1, 1), (7, 5), (33, 31), (64, 64)):
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = rng.integers(0, 256, shape, dtype=np.uint8)
+        if a.size > 2:
+            a.flat[0], b.flat[0], a.flat[1], b.flat[1] = 0, 255, 255, 0
+        a8 = (a ^ 0x80).view(np.int8).astype(np.int64)
+        b8 = (b ^ 0x80).view(np.int8).astype(np.int64)
+        assert np.array_equal(a8, a.astype(np.int64) - 128)
+        got = (a8 * a8).sum() + (b8 * b8).sum() - 2 * (a8 * b8).sum()
+        assert got == oracle.ssds(a.astype(np.float64), b.astype(np.float64)) == ((a.astype(np.int64) - b.astype(np.int64)) ** 2).sum()
+    assert 131071 * 128 * 128 <= 2 ** 31 - 1 < 131072 * 128 * 128      # |sum a'b'| <= P * 2^14 (both bytes 0 everywhere): P <= 131 071
+
+
 def test_experiment_helpers_match_the_reference(manifest, golden):
     """scripts/run_experiment.py's helpers, pinned by the reference's own outputs (tests/golden/make_golden.py imports
     the script; t7_experiment.npz): training-path generator and path chopping bit for bit, the result row of
