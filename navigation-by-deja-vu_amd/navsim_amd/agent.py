@@ -425,7 +425,13 @@ class NavBySceneFamiliarity(object):
                 if engine is self._engine:
                     # patches are sensed on the GPU, straight into the scoring kernel's operand layout
                     self._check_bounds(position)
-                    res = engine.sense_step(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi),
+                    if not self.track_scene_familiarity and hasattr(engine, "sense_step_into"):
+                        # (the same device step through the engine's lean binding: no per-step record, views or dictionary)
+                        best_idex = engine.sense_step_into(position[0], position[1], self.angle, self.angle_offsets,
+                                                           self.angle_familiarity)
+                        res = None
+                    else:
+                        res = engine.sense_step(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi),
                                             want_scene=self.track_scene_familiarity)
                 else:
                     patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)
@@ -438,14 +444,15 @@ class NavBySceneFamiliarity(object):
                 self.scene_familiarity[:] = np.inf
                 self._scene_is_inf = True
                 raise
-            self.angle_familiarity[:] = res["angle_familiarity"]
+            if res is not None:
+                self.angle_familiarity[:] = res["angle_familiarity"]
+                best_idex = res["best_idex"]
             if self.track_scene_familiarity:
                 self.scene_familiarity[:] = res["scene_familiarity"]
                 self._scene_is_inf = False
             elif not self._scene_is_inf:
                 self.scene_familiarity[:] = np.inf              # not tracked: stays at the reference's reset value
                 self._scene_is_inf = True
-            best_idex = res["best_idex"]
         else:
             # any other plug-in: the reference's loop, one model call per heading
             self.scene_familiarity[:] = np.inf

@@ -24,6 +24,7 @@ class FamiliarityEngine(object):
         self.device = int(device)
         self.n_views = 0
         self.shape = None
+        self._step_state = None                  # sense_step_into's result record and angle buffer
         if exact:
             self.set_exact(True)
 
@@ -169,6 +170,26 @@ class FamiliarityEngine(object):
                                                   N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, ctypes.byref(r),
                                                   N.f64ptr(scene) if want_scene else None), "dv_sense_step")
         return self._result_dict(r, scene)
+
+    def sense_step_into(self, x, y, angle, offsets, out_fam):
+        """The agent's step as it runs thousands of times per second: headings (angle + offsets) mod 2 pi, sensed and scored,
+        per-heading familiarities written into out_fam; returns the chosen heading's index.  Same call as sense_step(...,
+        want_scene=False) -- dv_sense_step -- through ONE result record and ONE angle buffer kept for the engine's lifetime
+        (no per-step allocations, views or dictionaries on the host side)."""
+        st = self._step_state
+        if st is None or len(st[0]) != len(offsets):
+            res = N.StepResult()
+            buf = np.empty(len(offsets), dtype=np.float64)
+            st = self._step_state = (buf, N.f64ptr(buf), res, ctypes.byref(res),
+                                     np.frombuffer(res, dtype=np.float64, count=len(offsets), offset=56))
+        buf, bufp, res, resp, fam = st
+        np.add(offsets, angle, out=buf)
+        np.mod(buf, 2 * np.pi, out=buf)
+        rc = self._lib.dv_sense_step(self._ctx, x, y, bufp, len(buf), 0, resp, None)
+        if rc:
+            self._check_sense(rc, "dv_sense_step")
+        out_fam[:] = fam
+        return res.best_heading
 
     def sense_step_batch(self, x, y, angles, force_resolve=False):
         """Ensemble step on the device: agent i at (x[i], y[i]) looking along angles[i][0..A) -> list of result dicts."""
