@@ -396,7 +396,7 @@ class NavBySceneFamiliarity(object):
             self._engine.path_error_enqueue(self.position[0], self.position[1],
                                             self.coverage_threshold_factor * self.step_size)
             self._pending_errors += 1
-            if np.isfinite(self.max_distance_to_training_path):
+            if math.isfinite(self.max_distance_to_training_path):
                 self._collect_errors()                           # may raise TooFarFromTrainingPathException here (:264)
             return
         delta = self.training_path - self.position
@@ -480,7 +480,9 @@ class NavBySceneFamiliarity(object):
 
         if not fake:
             self.update_error()
-            if np.linalg.norm(self.training_path[-1] - self.position) <= self.threshold_factor * self.step_size:
+            # np.linalg.norm of the 2-vector (:325-326) without its wrapper: the same dot product, the same square root
+            d = self.training_path[-1] - self.position
+            if math.sqrt(d.dot(d)) <= self.threshold_factor * self.step_size:
                 raise ReachedEndOfTrainingPathException()
 
     # ---- ensembles: several agents on one engine and one library (navsim_amd/ensemble.py) --------------------

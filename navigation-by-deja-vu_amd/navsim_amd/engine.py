@@ -25,6 +25,8 @@ class FamiliarityEngine(object):
         self.n_views = 0
         self.shape = None
         self._step_state = None                  # sense_step_into's result record and angle buffer
+        self._err_out = ctypes.c_double()        # path_error_wait's answer
+        self._err_out_ref = ctypes.byref(self._err_out)
         if exact:
             self.set_exact(True)
 
@@ -458,11 +460,15 @@ class FamiliarityEngine(object):
         self._check(self._lib.dv_set_training_path(self._ctx, N.f64ptr(pts), pts.shape[0]), "dv_set_training_path")
 
     def path_error_enqueue(self, x, y, reach):
-        self._check(self._lib.dv_path_error_enqueue(self._ctx, float(x), float(y), float(reach)), "dv_path_error_enqueue")
+        rc = self._lib.dv_path_error_enqueue(self._ctx, x, y, reach)
+        if rc:
+            self._check(rc, "dv_path_error_enqueue")
 
     def path_error_wait(self):
-        out = ctypes.c_double()
-        self._check(self._lib.dv_path_error_wait(self._ctx, ctypes.byref(out)), "dv_path_error_wait")
+        out = self._err_out
+        rc = self._lib.dv_path_error_wait(self._ctx, self._err_out_ref)
+        if rc:
+            self._check(rc, "dv_path_error_wait")
         return out.value
 
     def path_coverage(self, n):
