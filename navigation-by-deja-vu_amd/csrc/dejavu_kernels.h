@@ -2747,6 +2747,13 @@ fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&
     __syncthreads();               // the scratch is reused by the next item
 }
 
+// What a wave without sums does while the others finish an item: fused_finish's three workgroup barriers, raw (nothing waits for the
+// LDS-DMA a loader wave has in flight for the next item).
+__device__ __forceinline__ void fused_finish_idle() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_barrier();
+}
+
 // The workgroup's running summary (fused_finish): cleared before its first item, written after its last --
 // bsum[agent][workgroup][2][A_agent], nb = gridDim.x summaries per agent.
 __device__ __forceinline__ void fused_block_begin(unsigned long long* scratch, bool first = true) {
@@ -3380,11 +3387,36 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
         lslot = lslot + 1 == RD ? 0 : lslot + 1;
         if (++lst == nst) { lst = 0; ++li; loader_item(); }
     };
+    // The two kinds of waves run SEPARATE item loops that meet at the barriers: what a loader keeps across an item (its pointers, its
+    // place in the stream) is then not live through the consumers' loop and the other way round -- with ONE loop around both bodies
+    // the allocator spilled loader values into the stage loop as soon as the finishing grew, and the s_waitcnt vmcnt(0) behind every
+    // reload drained the LDS-DMA stream each stage (two heading tiles: 1.14 -> 1.96 ms per ensemble step).
     if (loader) {
         loader_item();
 #pragma unroll
         for (int r = 0; r < RD - 1; ++r) issue_stage();
-    }
+        for (long long j = 0; j < n_mine; ++j) {
+            for (int st = 0; st < nst; ++st) {
+                // this wave's rows of stage (j, st) have landed once only the younger stages' instructions are outstanding ...
+#ifdef DEJAVU_EXP_SKIP          // (timing experiments of tools/exp/stamps.py: bit 0 leaves out the coefficient rows, bit 1 the library rows)
+                constexpr int XC = (DEJAVU_EXP_SKIP & 1) ? 0 : SK * HT, XL = (DEJAVU_EXP_SKIP & 2) ? 0 : SK * TL, XLC = (DEJAVU_EXP_SKIP & 2) ? 0 : 3 * TL;
+                if (CODE && young_code) wait_vmcnt_le<XC + XLC>();
+                else wait_vmcnt_le<(XC + XL) * (RD - 2)>();
+#else
+                if (CODE && young_code) wait_vmcnt_le<PERC>();
+                else wait_vmcnt_le<PER * (RD - 2)>();
+#endif
+                __builtin_amdgcn_s_barrier();                           // ... everybody's have; nobody still reads the slot before it
+                issue_stage();                                          // (may belong to the next item: its pipeline fill)
+            }
+            if constexpr (FUSE) {                                       // the barriers of the consumers' finishing (fused_finish: three per call)
+#pragma unroll
+                for (int h = 0; h < HT; ++h)
+                    if (HT == 1 || a_off + 32 * h < fz.A_real) fused_finish_idle();
+            }
+        }
+        wait_vmcnt_le<0>();                                             // the re-reads past the last item
+    } else {
 
     int cslot = 0;                                                      // ring slot of the consumers' current stage
     int nfin = 0;                                                       // fused_finish calls so far (HT = 2: their parity)
@@ -3392,7 +3424,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
     int hconst[HT][2];                                                  // this lane's heading constants (fused_finish), per heading tile
 #pragma unroll
     for (int h = 0; h < HT; ++h) { hconst[h][0] = 0; hconst[h][1] = 0; }
-    if (FUSE && !loader) {
+    if (FUSE) {
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             const int a = a_off + 32 * h + (lane & 31), ac = a < fz.A_real ? a : fz.A_real - 1;
@@ -3408,7 +3440,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
 #pragma unroll
         for (int t = 0; t < TL; ++t) {
             const long long g = g0 + wave * TL + t;
-            live[t] = !loader && g < g1;
+            live[t] = g < g1;
             gidx[t] = live[t] ? g : g0;
         }
         // integer sums of the item: [u][r], u = view group t (HT = 1) or heading tile h (HT = 2)
@@ -3417,21 +3449,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { tot_hs[u][r] = 0; tot_v[u][r] = 0; }
-        if (loader) {
-            for (int st = 0; st < nst; ++st) {
-                // this wave's rows of stage (j, st) have landed once only the younger stages' instructions are outstanding ...
-#ifdef DEJAVU_EXP_SKIP          // (timing experiments of tools/exp/stamps.py: bit 0 leaves out the coefficient rows, bit 1 the library rows)
-                constexpr int XC = (DEJAVU_EXP_SKIP & 1) ? 0 : SK * HT, XL = (DEJAVU_EXP_SKIP & 2) ? 0 : SK * TL, XLC = (DEJAVU_EXP_SKIP & 2) ? 0 : 3 * TL;
-                if (CODE && young_code) wait_vmcnt_le<XC + XLC>();
-                else wait_vmcnt_le<(XC + XL) * (RD - 2)>();
-#else
-                if (CODE && young_code) wait_vmcnt_le<PERC>();
-                else wait_vmcnt_le<PER * (RD - 2)>();
-#endif
-                __builtin_amdgcn_s_barrier();                           // ... everybody's have; nobody still reads the slot before it
-                issue_stage();                                          // (may belong to the next item: its pipeline fill)
-            }
-        } else {
+        {
             v16f_t acc[2][4];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -3619,21 +3637,21 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
             if constexpr (HT == 1) {
                 auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
                 auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
-                fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off, has_hs_sum, j, lane, wave, (int)(j & 1), NC, loader, hconst[0]);
+                fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off, has_hs_sum, j, lane, wave, (int)(j & 1), NC, false, hconst[0]);
             } else {
 #pragma unroll
                 for (int h = 0; h < HT; ++h) {
                     auto of_hs = [&](int, int r) -> int { return tot_hs[h][r]; };
                     auto of_v = [&](int, int r) -> int { return tot_v[h][r]; };
                     if (a_off + 32 * h < fz.A_real)                     // (uniform: a heading tile without headings has nothing to finish)
-                        fused_finish<TL, NW, false>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, loader,
+                        fused_finish<TL, NW, false>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, false,
                                              hconst[h], scratch0 + kFuseBlk + h * 64);
                 }
             }
             if (j == 0) DV_STAMP(4);
         }
     }
-    if (loader) wait_vmcnt_le<0>();                                     // the re-reads past the last item
+    }                                                                   // (consumers)
     if constexpr (FUSE) {
 #pragma unroll
         for (int h = 0; h < HT; ++h)
