@@ -3644,7 +3644,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                     auto of_hs = [&](int, int r) -> int { return tot_hs[h][r]; };
                     auto of_v = [&](int, int r) -> int { return tot_v[h][r]; };
                     if (a_off + 32 * h < fz.A_real)                     // (uniform: a heading tile without headings has nothing to finish)
-                        fused_finish<TL, NW, false>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, false,
+                        fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, false,
                                              hconst[h], scratch0 + kFuseBlk + h * 64);
                 }
             }
