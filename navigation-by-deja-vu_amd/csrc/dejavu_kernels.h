@@ -2515,18 +2515,13 @@ template <int TILES, int NW, bool FAST = false, typename HsOf, typename VOf>
 __device__ __forceinline__ void
 fused_finish(HsOf hs_of, VOf v_of, const long long (&gidx)[TILES], const bool (&live)[TILES],
              unsigned long long* scratch, const LibCfg& c, const FuseArgs& fz, int a_off, int has_hs_sum, long long gq, int lane, int wave,
-             int parity, int n_entry_waves = NW, bool idle = false, const int* consts = nullptr, unsigned long long* blk = nullptr) {
+             int parity, int n_entry_waves = NW, const int* consts = nullptr, unsigned long long* blk = nullptr) {
     static_assert(NW == 8, "scratch layout");
     // Three workgroup barriers per call.  What a call needs cleared on entry is cleared by the call before it (fused_block_begin
     // before the first): abest by wave 0, which alone touches it, and the queue counter of the NEXT call's parity -- the callers
     // alternate `parity`, so a counter is cleared two barriers before anybody adds to it again.
-    // Waves that hold no sums (the loader waves of sad_lc_fp4) only keep the barriers: raw ones, so that nothing waits for the
-    // LDS-DMA they have in flight for the next item.  Waves [0, n_entry_waves) hold the entries.
-    if (idle) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_barrier();
-        return;
-    }
+    // Waves that hold no sums (the loader waves of sad_lc_fp4) keep the barriers with fused_finish_idle.  Waves [0, n_entry_waves)
+    // hold the entries.
     unsigned long long* sum_sc = scratch;                      // [NW][32] bits of the (non-negative) sc: bit order = value order
     unsigned long long* sum_view = sum_sc + NW * 32;
     unsigned long long* item_view = sum_view + NW * 32;        // [32]
@@ -3637,14 +3632,14 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
             if constexpr (HT == 1) {
                 auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };
                 auto of_v = [&](int t, int r) -> int { return tot_v[t][r]; };
-                fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off, has_hs_sum, j, lane, wave, (int)(j & 1), NC, false, hconst[0]);
+                fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off, has_hs_sum, j, lane, wave, (int)(j & 1), NC, hconst[0]);
             } else {
 #pragma unroll
                 for (int h = 0; h < HT; ++h) {
                     auto of_hs = [&](int, int r) -> int { return tot_hs[h][r]; };
                     auto of_v = [&](int, int r) -> int { return tot_v[h][r]; };
                     if (a_off + 32 * h < fz.A_real)                     // (uniform: a heading tile without headings has nothing to finish)
-                        fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC, false,
+                        fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC,
                                              hconst[h], scratch0 + kFuseBlk + h * 64);
                 }
             }
