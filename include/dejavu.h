@@ -232,6 +232,34 @@ int dv_step_batch(dv_ctx *ctx, const uint8_t *patches, int n_agents, int n_headi
 /* Re-run the exact resolver on the candidates of the last step (sharded runs, cross-rank ties). */
 int dv_resolve(dv_ctx *ctx, dv_step_result *result);
 
+/* ---- steps of ANY number of headings ------------------------------------ */
+/*
+ * The reference takes any n_test_angles (NavBySceneFamiliarity.py:62,87-88; its loop :289 runs over all of them, its default
+ * is 60); dv_step / dv_sense_step hold at most DV_MAX_HEADINGS because their result record is a fixed structure.  The wide
+ * forms take 1 <= n_headings <= DV_MAX_WIDE_HEADINGS: the headings are scored DV_MAX_HEADINGS per library pass (the passes
+ * enqueued back to back, their records collected afterwards) and the passes' decisions merged on the host by the rule of
+ * NavBySceneFamiliarity.py:313-315 -- the first heading attaining the maximum; where two passes' maxima lie within the
+ * candidate window of each other the passes concerned are re-scored by the exact resolver first and the exact values
+ * compared, so best_heading is bit-identical to np.argmax of the reference for any n_headings.
+ * angle_fam[n_headings] (caller-allocated) receives every heading's maximum, angle_view[n_headings] (may be NULL) its first
+ * view, scene_fam[F] (may be NULL) the minimum over ALL headings per view (:301-303).
+ */
+#define DV_MAX_WIDE_HEADINGS 4096
+typedef struct dv_wide_result {
+    int32_t best_heading;       /* index into the n_headings headings */
+    uint32_t flags;             /* DV_RES_* of the pass that won */
+    int64_t best_view;
+    double best_fam;
+    int32_t n_headings;
+    int32_t n_passes;           /* library passes this step took (re-scored passes not counted) */
+    int32_t n_contending;       /* passes whose maximum lay within the candidate window of the overall one */
+    int32_t reserved;
+} dv_wide_result;
+int dv_step_wide(dv_ctx *ctx, const uint8_t *patches, int n_headings, uint32_t flags, dv_wide_result *result,
+                 double *angle_fam, int64_t *angle_view, double *scene_fam);
+int dv_sense_step_wide(dv_ctx *ctx, double x, double y, const double *angles, int n_headings, uint32_t flags,
+                       dv_wide_result *result, double *angle_fam, int64_t *angle_view, double *scene_fam);
+
 /* ---- ssd_f32 metric (the reference's `ssds`, navsim/util.pyx:171-184) ---- */
 /*
  * views: float32[F,h,w] single channel.  Scores are sums of squared differences (smaller = more familiar):
@@ -241,6 +269,9 @@ int dv_resolve(dv_ctx *ctx, dv_step_result *result);
  * best_heading = first heading attaining the overall minimum; scene_ssd[f] = max over headings.
  */
 int dv_set_library_f32(dv_ctx *ctx, const float *views, int64_t n_views, int h, int w, int64_t first_view);
+/* Same library as navsim_amd.synth.synth_views_f32(seed, n_views, h, w, first_view), generated on the GPU (BASELINE.json
+ * configs[2] in its literal form is 500 000 x 128x128 float32 = 32.8 GB: made where it is scored, not uploaded). */
+int dv_generate_library_f32(dv_ctx *ctx, uint64_t seed, int64_t n_views, int h, int w, int64_t first_view);
 int dv_score_f32(dv_ctx *ctx, const float *patch, double *ssdbuf);
 int dv_step_f32(dv_ctx *ctx, const float *patches, int n_headings, uint32_t flags, dv_step_result *result,
                 double *scene_ssd);
@@ -256,6 +287,18 @@ int dv_set_library_u8(dv_ctx *ctx, const uint8_t *views, int64_t n_views, int h,
 int dv_score_u8(dv_ctx *ctx, const uint8_t *patch, double *ssdbuf);
 int dv_step_u8(dv_ctx *ctx, const uint8_t *patches, int n_headings, uint32_t flags, dv_step_result *result,
                double *scene_ssd);
+/*
+ * The ssd_u8 metric behind the sensor model: what the agent's step needs when SSD is its familiarity plug-in
+ * (navsim_amd.util.ssd_familiarity).  `channel` (0 H, 1 S, 2 V) picks the byte of each sensed HSV pixel that is compared.
+ * dv_set_library_u8_from_poses = train_from_path (NavBySceneFamiliarity.py:118-140) on the device: senses n poses, hands back
+ * familiar_scenes (out_views: uint8[n, sensor_h, sensor_w, 3], may be NULL) and ingests the chosen channel as the ssd_u8 library.
+ * dv_sense_step_u8 = dv_sense_step for that library: the A heading patches are sensed at (x, y), their channel scored on the
+ * int8 matrix cores, the least-SSD heading decided on the device; DV_ERR_INDEX like the reference's IndexError.
+ */
+int dv_set_library_u8_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n, int channel,
+                                 int64_t first_view, uint8_t *out_views);
+int dv_sense_step_u8(dv_ctx *ctx, double x, double y, const double *angles, int n_headings, int channel, uint32_t flags,
+                     dv_step_result *result, double *scene_ssd);
 
 /* ---- resident / asynchronous form (benchmarks, pipelined callers) ------ */
 /* Upload patches and prepare their device layout; no host synchronisation. */

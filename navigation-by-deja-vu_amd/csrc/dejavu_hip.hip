@@ -1,11 +1,15 @@
 // dejavu_hip.hip -- host side of libdejavu_hip.so: the C ABI of include/dejavu.h.
 //
 // One context = one GPU = one stream.  All device buffers are allocated when the library is set (nothing is
-// allocated inside a step), results come back through one pinned, mapped host record that the host polls, and a
-// step is two launches on one stream:
-//   k_sad_tiles (the HBM stream, integer partial sums) -> k_finish (sums -> scores, reductions, decision)
-// plus, only when near-ties need exact re-scoring, k_resolve -> k_decide.  (dv_score, the exact mode and ssd_f32 keep
-// scores in fam[]: scoring kernel -> k_combine / k_exact_all -> k_tail.)
+// allocated inside a step) and results come back through one pinned, mapped host record that the host polls.  A
+// single-agent step on the default path is three launches on one stream:
+//   k_patch_prep (sensing / upload / generator -> raw bytes, byte operands, coefficient images, per-heading constants)
+//   -> k_sad_mfma_dual (bit tiles on the matrix cores, scores finished in its epilogue: one summary per workgroup)
+//   -> k_fold (folds the <= 256 summaries, decides, writes the record)
+// Libraries the bit planes cannot describe, steps that want scene_fam and K-chunked small libraries end in k_finish
+// (sums -> scores, reductions, decision) behind k_sad_tiles / k_sad_packed / k_sad_generic or the unfused matrix-core
+// pass; dv_score, the exact mode, ssd_f32 and ssd_u8 keep scores in fam[] (scoring kernel -> k_combine* / k_exact_all
+// -> k_tail).  Only when near-ties need exact re-scoring: k_resolve -> k_decide.
 #include "dejavu_kernels.h"
 #include "../../include/dejavu.h"
 
@@ -160,6 +164,13 @@ struct dv_ctx {
     int vcode_env = 0;
     int last_form = 0;                        // DV_FORM_* of the last integer scoring pass (fp4 bit: the fp4 image existed)
     int fuse_env = 1;                         // DEJAVU_FUSE=0: one-chunk matrix-core passes leave their sums to k_finish instead of finishing them
+    int lc_env = 1;                           // DEJAVU_LC: 0 every wave loads and multiplies, 1 loader / consumer waves (stages of 4, ring of 3), 2 (stages of 2, ring of 5)
+    int ht_env = 2;                           // DEJAVU_HT=1: 64 resident headings as two passes instead of two heading tiles per view group
+    int ring_env = 0;                         // DEJAVU_RING: ring shapes of the round-2 body (A/B)
+    int mixed_env = 1;                        // DEJAVU_MIXED=0: no mixed layout (many saturation values keep the byte path)
+    int tune_all_env = 0;                     // DEJAVU_TUNE_ALL=1: time every byte-path shape even when the matrix-core pass already beats their byte bound
+    int fail_alloc_env = 0;                   // DEJAVU_TEST_FAIL_ALLOC=n: the n-th allocation of an ssd_u8 / ssd_f32 ingest fails (tests of the clean-up path)
+    int lib_allocs = 0;                       // ... counted here
     int fused_nb = 0;                         // summaries per agent it left
     int group_pad_kb = -1;                    // DEJAVU_GPAD, see group_stride
     int allow_signed = 1;                     // DEJAVU_SIGNED=0 keeps two one-hot saturation planes even when one signed plane would do
@@ -298,6 +309,12 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_SIGNED", c->allow_signed, 0, 1);
     env_int("DEJAVU_GPAD", c->group_pad_kb, 0, 4096);
     env_int("DEJAVU_SPIN", c->spin_wait, 0, 1);
+    env_int("DEJAVU_LC", c->lc_env, 0, 2);
+    env_int("DEJAVU_HT", c->ht_env, 1, 2);
+    env_int("DEJAVU_RING", c->ring_env, 0, 2);
+    env_int("DEJAVU_MIXED", c->mixed_env, 0, 1);
+    env_int("DEJAVU_TUNE_ALL", c->tune_all_env, 0, 1);
+    env_int("DEJAVU_TEST_FAIL_ALLOC", c->fail_alloc_env, 0, 64);
     *out = c;
     return DV_OK;
 }
@@ -482,7 +499,6 @@ static int build_bit_planes(dv_ctx* c) {
     b.nbp = g.npl;
     int t = 0;
     bool mixed = false;
-    static const int mixed_env = getenv("DEJAVU_MIXED") ? atoi(getenv("DEJAVU_MIXED")) : 1;
     for (int bp = 0; bp < g.npl; ++bp) {
         if (bp == g.nhs) b.T[0] = t;                                   // HS planes come first
         int lmin = 0, lmax = 0;
@@ -491,7 +507,7 @@ static int build_bit_planes(dv_ctx* c) {
             // Too many levels.  A saturation plane: the MIXED layout keeps ALL saturation planes as bytes (scored with v_sad_u8 by
             // k_sad_tiles) and makes bit planes of the value plane only, scored on the matrix cores; the two passes meet in
             // k_finish (launch_int_scoring).  The value plane: byte path.
-            if (bp >= g.nhs || !g.hasv || !mixed_env) return DV_OK;
+            if (bp >= g.nhs || !g.hasv || !c->mixed_env) return DV_OK;
             mixed = true;
             t = 0;
             for (int k = 0; k < g.nhs; ++k) { b.lmin[k] = 0; b.lmax[k] = 255; }
@@ -609,9 +625,12 @@ static int enqueue_bit_prep(dv_ctx* c, bool force = false) {             // (the
 }
 
 // ------------------------------------------------------------------ library
+// metric 1 / 2 (ssd_f32 / ssd_u8): the common per-step buffers only (scores, state, candidates, records); the HSV tiles, the
+// byte-path operands and partial sums and the k_finish / k_fold summaries are not allocated (their ingests add their own).
 static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t first,
-                         int n_hues, const unsigned char* hues, int generic, int max_s = 255) {
+                         int n_hues, const unsigned char* hues, int generic, int max_s = 255, int metric = 0) {
     free_library(c);
+    c->metric = metric;
     LibCfg& g = c->cfg;
     g = LibCfg{};
     g.F = F;
@@ -639,9 +658,11 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
     const double n = (double)g.P;
     c->delta = 4.0 * (n + 8.0) * std::ldexp(1.0, -53) * n;
 
-    HIP_TRY(c, hipMalloc(&c->d_tiles, c->tile_bytes));
-    HIP_TRY(c, hipMalloc(&c->d_raw_patches, (size_t)kMaxHeadings * g.P * 3));
-    HIP_TRY(c, hipMalloc(&c->d_prep, (size_t)g.npl * g.Q * 4 * kMaxHeadings * sizeof(unsigned)));
+    if (metric == 0) {
+        HIP_TRY(c, hipMalloc(&c->d_tiles, c->tile_bytes));
+        HIP_TRY(c, hipMalloc(&c->d_raw_patches, (size_t)kMaxHeadings * g.P * 3));
+        HIP_TRY(c, hipMalloc(&c->d_prep, (size_t)g.npl * g.Q * 4 * kMaxHeadings * sizeof(unsigned)));
+    }
     HIP_TRY(c, hipMalloc(&c->d_acc, 2 * sizeof(PrepAcc)));
     HIP_TRY(c, hipMalloc(&c->d_one, sizeof(unsigned)));
     c->acc_parity = 0;
@@ -657,16 +678,18 @@ static int alloc_library(dv_ctx* c, int64_t F, int h, int w, double cw, int64_t 
         c->nchunk_cap = (int)n;
         c->nchunk = 1;
     }
-    HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nchunk_cap * 2 * kMaxHeadings * g.Fpad * sizeof(unsigned)));
+    if (metric == 0) HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nchunk_cap * 2 * kMaxHeadings * g.Fpad * sizeof(unsigned)));
     HIP_TRY(c, hipMalloc(&c->d_pmax, (size_t)kMaxHeadings * (g.Fpad / 64) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_fam, (size_t)kMaxHeadings * g.Fpad * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_scene, (size_t)g.Fpad * sizeof(double)));
     // per-agent state of a batched pass: up to kMaxHeadings agents (one heading each)
     HIP_TRY(c, hipMalloc(&c->d_state, kMaxHeadings * sizeof(StepState)));
     // summaries per agent: one per 256 views (k_finish) or one per workgroup of a fused scoring pass (at most 256: launch_mfma_dual_f)
-    HIP_TRY(c, hipMalloc(&c->d_bsum, (size_t)std::max<long long>((g.F + 255) / 256, 256) * 2 * kMaxHeadings * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMalloc(&c->d_bsum2, (size_t)kFoldSlices * 2 * kMaxHeadings * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMalloc(&c->d_ctmp, (size_t)kMaxHeadings * kTmpCap * 2 * sizeof(unsigned long long)));
+    if (metric == 0) {
+        HIP_TRY(c, hipMalloc(&c->d_bsum, (size_t)std::max<long long>((g.F + 255) / 256, 256) * 2 * kMaxHeadings * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc(&c->d_bsum2, (size_t)kFoldSlices * 2 * kMaxHeadings * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc(&c->d_ctmp, (size_t)kMaxHeadings * kTmpCap * 2 * sizeof(unsigned long long)));
+    }
     HIP_TRY(c, hipMalloc(&c->d_cand, (size_t)kMaxHeadings * kCandCap * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&c->d_cand_exact, (size_t)kMaxHeadings * kCandCap * sizeof(double)));
     HIP_TRY(c, hipMalloc(&c->d_record, (size_t)kMaxHeadings * (3 + 4 * kMaxHeadings) * sizeof(double)));
@@ -851,6 +874,29 @@ extern "C" int dv_set_library(dv_ctx* c, const uint8_t* views, int64_t F, int h,
 }
 
 // ------------------------------------------------------------------ ssd_f32 metric
+// Allocations of the ssd_f32 / ssd_u8 ingests behind alloc_library: any failure frees the whole half-built library (the
+// context is then without a library: the step calls answer DV_ERR_STATE) and reports DV_ERR_OOM / DV_ERR_HIP.
+template <class T>
+static hipError_t lib_malloc(dv_ctx* c, T** p, size_t bytes) {
+    if (c->fail_alloc_env > 0 && ++c->lib_allocs == c->fail_alloc_env) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+static int lib_fail(dv_ctx* c, hipError_t e, const char* what) {
+    (void)hipGetLastError();
+    free_library(c);
+    return fail(c, e == hipErrorOutOfMemory ? DV_ERR_OOM : DV_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+static int alloc_f32_buffers(dv_ctx* c) {
+    const LibCfg& g = c->cfg;
+    c->lib_allocs = 0;
+    hipError_t e = lib_malloc(c, &c->d_ftiles, c->tile_bytes);
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_fraw, (size_t)kMaxHeadings * g.P * sizeof(float));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_fprep, (size_t)g.Q * 4 * kMaxHeadings * sizeof(float));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_fpart, (size_t)c->nchunk_cap * kMaxHeadings * g.Fpad * sizeof(double));
+    if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 buffers");
+    return DV_OK;
+}
+
 static void negate_result(dv_step_result* r) {
     r->best_fam = -r->best_fam;
     r->approx_max = -r->approx_max;
@@ -860,21 +906,15 @@ static void negate_result(dv_step_result* r) {
     }
 }
 
-extern "C" int dv_set_library_f32(dv_ctx* c, const float* views, int64_t F, int h, int w, int64_t first) {
-    int rc = check_lib_args(c, F, h, w, 0.0);
-    if (rc) return rc;
-    if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    rc = alloc_library(c, F, h, w, 0.0, first, 0, nullptr, 0);       // common per-step buffers (fam, state, records)
+// Common buffers, layout constants and the ssd_f32 buffers of a library of F float32 views (no views yet).
+static int prepare_f32_library(dv_ctx* c, int64_t F, int h, int w, int64_t first) {
+    int rc = alloc_library(c, F, h, w, 0.0, first, 0, nullptr, 0, 255, 1);       // common per-step buffers (fam, state, records)
     if (rc) { free_library(c); return rc; }
     LibCfg& g = c->cfg;
     g.Q = (g.P + 3) / 4;                                              // 4 float pixels per 16-byte chunk
     g.npl = 1; g.nhs = 0; g.hasv = 1;
-    (void)hipFree(c->d_tiles); c->d_tiles = nullptr;
     g.gstride = group_stride(c, (long long)g.Q);
     c->tile_bytes = (size_t)(g.Fpad / 64) * g.gstride * sizeof(float4);
-    c->metric = 1;
     {
         const long long G = g.Fpad / 64;
         long long n = (256ll * 28 + G - 1) / G;
@@ -884,23 +924,47 @@ extern "C" int dv_set_library_f32(dv_ctx* c, const float* views, int64_t F, int 
         if (n < 1) n = 1;
         c->nchunk_cap = (int)n;
     }
-    HIP_TRY(c, hipMalloc(&c->d_ftiles, c->tile_bytes));
-    HIP_TRY(c, hipMalloc(&c->d_fraw, (size_t)kMaxHeadings * g.P * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&c->d_fprep, (size_t)g.Q * 4 * kMaxHeadings * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&c->d_fpart, (size_t)c->nchunk_cap * kMaxHeadings * g.Fpad * sizeof(double)));
+    // fp32 accumulation over 8 pixels, then double: relative error of a score <= 1e-6 (bound), typically 1e-7
+    c->delta = 0.0;
+    return alloc_f32_buffers(c);
+}
+
+extern "C" int dv_set_library_f32(dv_ctx* c, const float* views, int64_t F, int h, int w, int64_t first) {
+    int rc = check_lib_args(c, F, h, w, 0.0);
+    if (rc) return rc;
+    if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = prepare_f32_library(c, F, h, w, first);
+    if (rc) return rc;
+    const LibCfg& g = c->cfg;
     float* d_raw = nullptr;
-    HIP_TRY(c, hipMalloc(&d_raw, (size_t)F * g.P * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(d_raw, views, (size_t)F * g.P * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    hipError_t e = lib_malloc(c, &d_raw, (size_t)F * g.P * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_raw, views, (size_t)F * g.P * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         const long long total = (g.Fpad / 64) * (long long)g.Q * 64;
         hipLaunchKernelGGL(k_retile_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_ftiles, c->cfg);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_raw);
-    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "ssd_f32 ingest: %s", hipGetErrorString(e)); }
-    // fp32 accumulation over 16 pixels, then double: relative error of a score <= ~1.3e-6 (bound), typically 1e-7
-    c->delta = 0.0;
+    if (d_raw) (void)hipFree(d_raw);
+    if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 ingest");
+    return DV_OK;
+}
+
+extern "C" int dv_generate_library_f32(dv_ctx* c, uint64_t seed, int64_t F, int h, int w, int64_t first) {
+    int rc = check_lib_args(c, F, h, w, 0.0);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = prepare_f32_library(c, F, h, w, first);
+    if (rc) return rc;
+    const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.Q * 64;
+    hipLaunchKernelGGL(k_generate_tiles_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_ftiles, c->cfg,
+                       (unsigned long long)seed);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 generator");
     return DV_OK;
 }
 
@@ -940,19 +1004,12 @@ extern "C" int dv_step_f32(dv_ctx* c, const float* patches, int A, uint32_t flag
 
 // ------------------------------------------------------------------ ssd_u8 metric
 // Exact SSD of single-channel uint8 views on the int8 matrix cores (k_ssd_u8_mfma); results as ssd_f32's.
-extern "C" int dv_set_library_u8(dv_ctx* c, const uint8_t* views, int64_t F, int h, int w, int64_t first) {
-    int rc = check_lib_args(c, F, h, w, 0.0);
-    if (rc) return rc;
-    if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
-    if ((long long)h * w > 131071) return fail(c, DV_ERR_INVALID, "ssd_u8: %d x %d pixels: the int32 cross terms hold at most 131071", h, w);
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    rc = alloc_library(c, F, h, w, 0.0, first, 0, nullptr, 0);       // common per-step buffers (fam, state, records)
+// Ingest of a raw single-channel library already on the device (uint8[F][h*w]); frees nothing of the caller's.
+static int ingest_u8(dv_ctx* c, const unsigned char* d_raw, int64_t F, int h, int w, int64_t first) {
+    int rc = alloc_library(c, F, h, w, 0.0, first, 0, nullptr, 0, 255, 2);       // common per-step buffers (fam, state, records)
     if (rc) { free_library(c); return rc; }
     LibCfg& g = c->cfg;
     g.npl = 1; g.nhs = 0; g.hasv = 1;
-    (void)hipFree(c->d_tiles); c->d_tiles = nullptr;
-    c->metric = 2;
     const int K = (g.P + 31) / 32;
     c->u8_K = K;
     c->u8_KC = K < 128 ? K : 128;                                       // 1 KB of LDS per K-step: at most 128 KB of operand rows per chunk
@@ -960,25 +1017,52 @@ extern "C" int dv_set_library_u8(dv_ctx* c, const uint8_t* views, int64_t F, int
     c->u8_KC = (K + c->u8_nchunk - 1) / c->u8_nchunk;                  // (chunks of equal length)
     c->nchunk_cap = c->u8_nchunk;
     c->tile_bytes = (size_t)(g.Fpad / 32) * K * 1024;
-    HIP_TRY(c, hipMalloc(&c->d_u8tiles, c->tile_bytes));
-    HIP_TRY(c, hipMalloc(&c->d_u8raw, (size_t)kMaxHeadings * g.P));
-    HIP_TRY(c, hipMalloc(&c->d_u8prep, (size_t)2 * K * 1024));
-    HIP_TRY(c, hipMalloc(&c->d_u8part, (size_t)c->u8_nchunk * kMaxHeadings * g.Fpad * sizeof(int)));
-    HIP_TRY(c, hipMalloc(&c->d_vnorm, (size_t)g.Fpad * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMalloc(&c->d_pnorm, (size_t)kMaxHeadings * sizeof(unsigned long long)));
-    unsigned char* d_raw = nullptr;
-    HIP_TRY(c, hipMalloc(&d_raw, (size_t)F * g.P));
-    hipError_t e = hipMemsetAsync(c->d_vnorm, 0, (size_t)g.Fpad * sizeof(unsigned long long), c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_raw, views, (size_t)F * g.P, hipMemcpyHostToDevice, c->stream);
+    c->lib_allocs = 0;
+    hipError_t e = lib_malloc(c, &c->d_u8tiles, c->tile_bytes);
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_u8raw, (size_t)kMaxHeadings * g.P);
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_u8prep, (size_t)2 * K * 1024);
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_u8part, (size_t)c->u8_nchunk * kMaxHeadings * g.Fpad * sizeof(int));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_vnorm, (size_t)g.Fpad * sizeof(unsigned long long));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_pnorm, (size_t)kMaxHeadings * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_vnorm, 0, (size_t)g.Fpad * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) {
         const long long total = (g.Fpad / 32) * (long long)K * 64;
         hipLaunchKernelGGL(k_retile_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_u8tiles, c->d_vnorm, c->cfg, K);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_raw);
-    if (e != hipSuccess) { free_library(c); return fail(c, DV_ERR_HIP, "ssd_u8 ingest: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return lib_fail(c, e, "ssd_u8 ingest");
     c->delta = 0.0;                                                     // exact integers: ties go by index (k_tail's exact rule)
+    return DV_OK;
+}
+
+extern "C" int dv_set_library_u8(dv_ctx* c, const uint8_t* views, int64_t F, int h, int w, int64_t first) {
+    int rc = check_lib_args(c, F, h, w, 0.0);
+    if (rc) return rc;
+    if (!views) return fail(c, DV_ERR_INVALID, "views is NULL");
+    if ((long long)h * w > 131071) return fail(c, DV_ERR_INVALID, "ssd_u8: %d x %d pixels: the int32 cross terms hold at most 131071", h, w);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_library(c);
+    unsigned char* d_raw = nullptr;
+    HIP_TRY(c, hipMalloc(&d_raw, (size_t)F * h * w));
+    hipError_t e = hipMemcpyAsync(d_raw, views, (size_t)F * h * w, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { (void)hipFree(d_raw); return fail(c, DV_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+    rc = ingest_u8(c, d_raw, F, h, w, first);
+    (void)hipFree(d_raw);
+    return rc;
+}
+
+// Operand rows and norms of the A resident single-channel patches (d_u8raw) for the matrix-core pass.
+static int prep_patches_u8(dv_ctx* c, int A) {
+    HIP_TRY(c, hipMemsetAsync(c->d_pnorm, 0, (size_t)kMaxHeadings * sizeof(unsigned long long), c->stream));
+    c->A = A; c->n_agents = 1; c->A_agent = A;
+    c->APAD = A <= 32 ? 32 : 64;
+    const int passes = c->APAD / 32;
+    const long long total = (long long)passes * c->u8_K * 64;
+    hipLaunchKernelGGL(k_prep_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_u8raw, c->d_u8prep, c->d_pnorm, c->cfg, c->u8_K, A,
+                       passes);
+    HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
 
@@ -989,21 +1073,76 @@ static int upload_patches_u8(dv_ctx* c, const uint8_t* patches, int A) {
     if (!patches) return fail(c, DV_ERR_INVALID, "patches is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_u8raw, patches, (size_t)A * c->cfg.P, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_pnorm, 0, (size_t)kMaxHeadings * sizeof(unsigned long long), c->stream));
-    c->A = A; c->n_agents = 1; c->A_agent = A; c->patches_sensed = false;
-    c->APAD = A <= 32 ? 32 : 64;
-    const int passes = c->APAD / 32;
-    const long long total = (long long)passes * c->u8_K * 64;
-    hipLaunchKernelGGL(k_prep_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_u8raw, c->d_u8prep, c->d_pnorm, c->cfg, c->u8_K, A,
-                       passes);
-    HIP_TRY(c, hipGetLastError());
-    return DV_OK;
+    c->patches_sensed = false;
+    return prep_patches_u8(c, A);
 }
 
 extern "C" int dv_step_u8(dv_ctx* c, const uint8_t* patches, int A, uint32_t flags, dv_step_result* result, double* scene_ssd) {
     int rc = upload_patches_u8(c, patches, A);
     if (rc) return rc;
     if (!result) return fail(c, DV_ERR_INVALID, "result is NULL");
+    rc = enqueue_step(c, flags, scene_ssd != nullptr);
+    if (rc) return rc;
+    rc = wait_step(c, result, scene_ssd);
+    if (rc) return rc;
+    negate_result(result);
+    if (scene_ssd) for (int64_t f = 0; f < c->cfg.F; ++f) scene_ssd[f] = -scene_ssd[f];
+    return DV_OK;
+}
+
+// The ssd_u8 metric behind the sensor model (the agent's step when SSD is its familiarity plug-in): train_from_path and the
+// heading loop on the device, the compared channel taken out of the sensed HSV bytes by k_take_channel.
+extern "C" int dv_set_library_u8_from_poses(dv_ctx* c, const double* x, const double* y, const double* angle, int64_t n, int channel,
+                                            int64_t first, uint8_t* out_views) {
+    if (!c || !x || !y || !angle) return DV_ERR_INVALID;
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    if (channel < 0 || channel > 2) return fail(c, DV_ERR_INVALID, "channel %d outside [0, 2]", channel);
+    int rc = check_lib_args(c, n, c->sensor.sh, c->sensor.sw, 0.0);
+    if (rc) return rc;
+    if ((long long)c->sensor.sh * c->sensor.sw > 131071) return fail(c, DV_ERR_INVALID, "ssd_u8: at most 131071 pixels per view");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_library(c);
+    const long long n_px = (long long)n * c->sensor.sh * c->sensor.sw;
+    rc = ensure_sense_buffer(c, (size_t)n_px * 3);
+    if (rc) return rc;
+    rc = enqueue_sense(c, x, y, angle, n, c->d_sense);
+    if (rc) return rc;
+    if (out_views) HIP_TRY(c, hipMemcpyAsync(out_views, c->d_sense, (size_t)n_px * 3, hipMemcpyDeviceToHost, c->stream));
+    rc = check_sense_error(c);
+    if (rc) return rc;
+    unsigned char* d_raw = nullptr;
+    HIP_TRY(c, hipMalloc(&d_raw, (size_t)n_px));
+    hipLaunchKernelGGL(k_take_channel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, c->d_sense, d_raw, n_px, channel);
+    if (hipGetLastError() != hipSuccess) { (void)hipFree(d_raw); return fail(c, DV_ERR_HIP, "k_take_channel launch failed"); }
+    rc = ingest_u8(c, d_raw, n, c->sensor.sh, c->sensor.sw, first);
+    (void)hipFree(d_raw);
+    return rc;
+}
+
+extern "C" int dv_sense_step_u8(dv_ctx* c, double x, double y, const double* angles, int A, int channel, uint32_t flags,
+                                dv_step_result* result, double* scene_ssd) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib || c->metric != 2) return fail(c, DV_ERR_STATE, "no ssd_u8 library set (call dv_set_library_u8 first)");
+    if (A < 1 || A > kMaxHeadings) return fail(c, DV_ERR_INVALID, "ssd_u8: n_headings %d outside [1, %d]", A, kMaxHeadings);
+    if (channel < 0 || channel > 2) return fail(c, DV_ERR_INVALID, "channel %d outside [0, 2]", channel);
+    if (!angles || !result) return fail(c, DV_ERR_INVALID, "angles or result is NULL");
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    if (c->sensor.sw != c->w || c->sensor.sh != c->h)
+        return fail(c, DV_ERR_STATE, "sensor is %dx%d but the library holds %dx%d views", c->sensor.sw, c->sensor.sh, c->w, c->h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const long long n_px = (long long)A * c->cfg.P;
+    int rc = ensure_sense_buffer(c, (size_t)kMaxHeadings * c->cfg.P * 3);      // (sized once for any heading count: no allocation in later steps)
+    if (rc) return rc;
+    double xs[kMaxHeadings], ys[kMaxHeadings];
+    for (int a = 0; a < A; ++a) { xs[a] = x; ys[a] = y; }
+    rc = enqueue_sense(c, xs, ys, angles, A, c->d_sense);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_take_channel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, c->d_sense, c->d_u8raw, n_px, channel);
+    HIP_TRY(c, hipGetLastError());
+    c->patches_sensed = true;                                  // k_tail reads k_sense's error word (sense_err_ptr)
+    rc = prep_patches_u8(c, A);
+    if (rc) return rc;
     rc = enqueue_step(c, flags, scene_ssd != nullptr);
     if (rc) return rc;
     rc = wait_step(c, result, scene_ssd);
@@ -1397,7 +1536,8 @@ static int check_step_args(dv_ctx* c, int A) {
     if (!c) return DV_ERR_INVALID;
     if (!c->have_lib) return fail(c, DV_ERR_STATE, "no library set (call dv_set_library first)");
     if (c->metric != 0) return fail(c, DV_ERR_STATE, "the resident library is ssd_f32 / ssd_u8; use the _f32 / _u8 entry points");
-    if (A < 1 || A > kMaxHeadings) return fail(c, DV_ERR_INVALID, "n_headings %d outside [1, %d]", A, kMaxHeadings);
+    if (A < 1 || A > kMaxHeadings)
+        return fail(c, DV_ERR_INVALID, "n_headings %d outside [1, %d] (dv_step_wide / dv_sense_step_wide take more)", A, kMaxHeadings);
     return DV_OK;
 }
 
@@ -1428,6 +1568,12 @@ static int resident_waves_per_cu(const void* kernel) {
     if (per_simd > 7) per_simd = 7;
     if (per_simd < 1) per_simd = 1;
     return 4 * per_simd;
+}
+
+static bool kernel_uses_scratch(const void* kernel) {
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, kernel) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.localSizeBytes > 0;
 }
 
 // Grid of the scoring kernels: workgroups of `wpb` waves, never more than are resident at once, walking the items
@@ -1628,12 +1774,19 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     // 0.432 ms with two, 0.474 ms with one; 500 000 views: two)
     // DEJAVU_LC (A/B): 0 = every wave loads and multiplies (sad_ring_fp4); 1 = loader and consumer waves, stage of 4 K-steps, ring of 3
     // (sad_lc_fp4; ranges of 8 view groups whatever the library's size); 2 = the same with stages of 2 K-steps, ring of 5
-    static const int lc = getenv("DEJAVU_LC") ? atoi(getenv("DEJAVU_LC")) : 1;
+    const int lc = c->lc_env;
     const bool use_lc = lc != 0 && c->fp4_ok && !c->mfma_tiles_env;
     int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (use_lc ? 1 : (G32 >= 16ll * 320 ? 2 : 1));
+    // (never by default a variant the compiler could only build with scratch: its fused form keeps a few item-level pointers
+    // there in this build -- tests/test_host_logic.py:test_shipped_scoring_kernels_use_no_scratch lists what is guarded)
+    if (tiles == 2 && !c->mfma_tiles_env) {
+        static const bool spills[2] = {kernel_uses_scratch((const void*)k_sad_mfma_dual<1, 3, 2, 3, 2, false, 0, 3, false, 1>),
+                                       kernel_uses_scratch((const void*)k_sad_mfma_dual<1, 3, 2, 3, 2, true, 0, 3, false, 1>)};
+        const bool will_fuse = c->fuse_request && c->fuse_env && !c->mfma_chunk_env && item_groups(G32, 16) >= 160;
+        if (spills[will_fuse ? 1 : 0]) tiles = 1;
+    }
     // DEJAVU_HT=1 (A/B): 64 resident headings as two passes over the library instead of two heading tiles per view group in one
-    static const int ht_env = getenv("DEJAVU_HT") ? atoi(getenv("DEJAVU_HT")) : 2;
-    const bool two_tiles = use_lc && c->APAD == 64 && ht_env == 2;
+    const bool two_tiles = use_lc && c->APAD == 64 && c->ht_env == 2;
     const long long GQ = item_groups(G32, two_tiles ? 4 : 8 * tiles);
     int nchunk = 1;
     if (c->mfma_chunk_env) {
@@ -1651,7 +1804,7 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     // <int8 stage, ring | fp4 stage, ring (thermometer rows) | fp4 stage, ring (code rows), view groups per wave>.  Measured in
     // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
     // x 64x64 x 16 headings <4, 2> 46.7 us; fp4 <2, 3> 0.95 ms and <2, 4> 34.5 us.
-    static const int ring = getenv("DEJAVU_RING") ? atoi(getenv("DEJAVU_RING")) : 0;                // A/B of ring shapes
+    const int ring = c->ring_env;                                                                   // A/B of ring shapes
     if (two_tiles && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, true, 2>(c, nchunk, has_hs);
     else if (two_tiles) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, false, 2>(c, nchunk, has_hs);
     else if (use_lc && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, true>(c, nchunk, has_hs);
@@ -1740,14 +1893,23 @@ static int tune_workgroup_shape(dv_ctx* c) {
     HIP_TRY(c, hipEventCreate(&ev[0]));
     HIP_TRY(c, hipEventCreate(&ev[1]));
     const int cls = apad_class(c->APAD);
+    for (int i = 0; i < 6; ++i) c->tuned_us[cls][i] = 0.f;
     float best = 0.f;
+    bool timed_any = false;
     int rc = DV_OK, pick = 1, np = 0;
     // the timing passes never finish their scores themselves: a fused epilogue appends candidates that only k_fold
     // clears, and the shapes are compared on scoring + k_combine
     const bool fuse_request = c->fuse_request;
     c->fuse_request = false;
-    for (int sh = 1; sh <= kMaxShape && rc == DV_OK; ++sh) {
+    // The matrix-core pass (shape 6) is timed first; a byte-plane shape is then timed only if it could win at all: it
+    // streams tile_bytes per pass, so it cannot take less than tile_bytes / 8 TB/s (500 000 views x 128x128: 2 ms against
+    // 0.95 ms measured -- the ~16 byte-path launches of 4.7-5.7 ms each that used to open the first step are skipped).
+    float mfma_ms = -1.f;
+    const float byte_bound_ms = (float)((double)c->tile_bytes / 8.0e12 * 1e3);
+    for (int k = 0; k < kMaxShape && rc == DV_OK; ++k) {
+        const int sh = k == 0 ? kMaxShape : k;                        // 6, 1, 2, 3, 4, 5
         if (!shape_valid(c, cls, sh)) continue;
+        if (sh != kMaxShape && mfma_ms >= 0.f && byte_bound_ms > mfma_ms && !c->tune_all_env) continue;
         c->force_shape = sh;
         rc = launch_int_scoring(c, nullptr, &np);                     // warm: code objects, caches
         if (rc == DV_OK && hipEventRecord(ev[0], c->stream) != hipSuccess) rc = DV_ERR_HIP;
@@ -1758,7 +1920,9 @@ static int tune_workgroup_shape(dv_ctx* c) {
         if (rc == DV_OK && hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) rc = DV_ERR_HIP;
         if (rc == DV_OK) {
             c->tuned_us[cls][sh - 1] = ms * 1e3f / 3.f;
-            if (sh == 1 || ms < best) { best = ms; pick = sh; }
+            if (!timed_any || ms < best) { best = ms; pick = sh; }
+            timed_any = true;
+            if (sh == kMaxShape) mfma_ms = ms / 3.f;
         }
     }
     c->force_shape = 0;
@@ -1772,7 +1936,7 @@ static int tune_workgroup_shape(dv_ctx* c) {
     if (getenv("DEJAVU_VERBOSE")) {
         fprintf(stderr, "[dejavu] %d resident headings, us per scoring pass by workgroup shape:", c->APAD);
         for (int sh = 1; sh <= kMaxShape; ++sh)
-            if (shape_valid(c, cls, sh)) fprintf(stderr, " %d: %.1f", sh, c->tuned_us[cls][sh - 1]);
+            if (shape_valid(c, cls, sh) && c->tuned_us[cls][sh - 1] > 0.f) fprintf(stderr, " %d: %.1f", sh, c->tuned_us[cls][sh - 1]);
         fprintf(stderr, " -> shape %d\n", pick);
     }
     return DV_OK;
@@ -1893,11 +2057,22 @@ static int launch_scoring(dv_ctx* c, bool with_combine = true) {
     return DV_OK;
 }
 
+// k_sense's / k_patch_prep's "ran off the landscape" word of the resident patches (nullptr: they were not sensed).
+static const unsigned long long* sense_err_ptr(const dv_ctx* c) {
+    if (!c->patches_sensed) return nullptr;
+    return c->metric == 2 ? c->d_sense_err : &c->d_acc[c->acc_parity].err;
+}
+
 // The arrival ticket of k_finish / k_tail without fences saves ~1.5 us of a ~100 us single-agent step; everywhere else
 // (exact scores, ssd_f32, batched passes) the release / acquire pair of the memory model is kept.
 static int step_fenced(const dv_ctx* c) {
     if (c->fenced_env >= 0) return c->fenced_env;
-    return (c->exact || c->metric != 0 || c->n_agents > 1) ? 1 : 0;
+    if (c->exact || c->metric != 0 || c->n_agents > 1) return 1;
+    // single-agent integer path: unfenced only where the ~1.5 us pair is a visible share of the step -- scoring passes
+    // estimated under 200 us (bytes streamed at 4 TB/s; the byte path and the mixed layout at 500 000 views x 128x128 take
+    // 3-5 ms and are fenced)
+    const double bytes = (c->bits_ok && !c->mixed) ? (double)c->btile_bytes : (double)c->tile_bytes;
+    return bytes / 4.0e12 >= 200e-6 ? 1 : 0;
 }
 
 // One step on the resident patches: scoring (2 launches) + k_tail.  The result record lands in mapped host memory.
@@ -1919,8 +2094,16 @@ static void launch_fold(dv_ctx* c, int nb, StepResultDev* outp, double* recp, in
     int threads = 1024;
     if ((long long)nb * c->A_agent <= 256ll * 16) threads = 256;
     else if ((long long)nb * c->A_agent <= 512ll * 16) threads = 512;
-    hipLaunchKernelGGL(k_fold, dim3(1, (unsigned)c->n_agents), dim3((unsigned)threads), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state,
-                       outp, recp, c->cfg, c->A_agent, c->delta, force, seq, serr, nb);
+    const dim3 grid(1, (unsigned)c->n_agents);
+    if (threads == 256)
+        hipLaunchKernelGGL(k_fold<256>, grid, dim3(256), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state, outp, recp, c->cfg, c->A_agent,
+                           c->delta, force, seq, serr, nb);
+    else if (threads == 512)
+        hipLaunchKernelGGL(k_fold<512>, grid, dim3(512), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state, outp, recp, c->cfg, c->A_agent,
+                           c->delta, force, seq, serr, nb);
+    else
+        hipLaunchKernelGGL(k_fold<1024>, grid, dim3(1024), 0, c->stream, sums, c->d_ctmp, c->d_cand, c->d_state, outp, recp, c->cfg, c->A_agent,
+                           c->delta, force, seq, serr, nb);
 }
 
 template <int NT>
@@ -1933,7 +2116,7 @@ static void launch_finish(dv_ctx* c, int want_scene, int force) {
     const long long per_block = 256 * vb;
     const unsigned nb = (unsigned)((g.F + per_block - 1) / per_block);
     const int separate = nb > 256 ? 1 : 0;
-    const unsigned long long* serr = c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr;
+    const unsigned long long* serr = sense_err_ptr(c);
     StepResultDev* outp = c->d_result + c->result_slot;
     double* recp = c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings);
     ++c->seq;
@@ -1966,7 +2149,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     Range range("dv:finish");
     if (c->epilogue_fused) {
         launch_fold(c, c->fused_nb, c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), force, ++c->seq,
-                    c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr);
+                    sense_err_ptr(c));
     } else if (fused) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
         else launch_finish<2>(c, scene_on, force);
@@ -1975,7 +2158,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
                            c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result + c->result_slot,
                            c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,
                            c->A_agent, c->delta, scene_on, (c->exact || c->metric == 2) ? 1 : 0, force, ++c->seq,
-                           c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr, c->metric == 1 ? 3e-6 : 0.0, step_fenced(c));
+                           sense_err_ptr(c), c->metric == 1 ? 3e-6 : 0.0, step_fenced(c));
     }
     HIP_TRY(c, hipGetLastError());
     if (want_scene)
@@ -1987,6 +2170,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
 
 // Rare path: re-score one agent's listed candidates with the exact kernel and decide on those values.
 static int enqueue_resolve(dv_ctx* c, int agent = 0) {
+    if (c->metric == 2) return DV_OK;                      // ssd_u8: every score is the exact integer already, nothing to re-score
     const size_t co = (size_t)agent * kCandCap;
     if (c->metric == 1)
         hipLaunchKernelGGL(k_resolve_f32, dim3(256), dim3(64), 0, c->stream, c->d_ftiles,
@@ -1999,7 +2183,7 @@ static int enqueue_resolve(dv_ctx* c, int agent = 0) {
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state + agent, c->d_cand + co, c->d_cand_exact + co,
                        c->d_result + agent, c->d_record + (size_t)agent * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta,
-                       c->patches_sensed ? &c->d_acc[c->acc_parity].err : nullptr, agent);
+                       sense_err_ptr(c), agent);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
@@ -2135,11 +2319,150 @@ extern "C" int dv_step_batch(dv_ctx* c, const uint8_t* patches, int n_agents, in
     });
 }
 
+// Steps of any number of headings: passes of at most kMaxHeadings, merged by the rule of NavBySceneFamiliarity.py:313-315.
+// `stage(first, n)` makes headings [first, first + n) the resident patches.  Without scene_fam the passes are enqueued back to
+// back (each with its own result record, `result_slot`) and collected afterwards; a pass whose near-ties need the exact resolver
+// or whose candidate list overflowed is run again on its own through the synchronous path, as run_batch does.
+template <class Stage>
+static int run_wide(dv_ctx* c, int A, uint32_t flags, dv_wide_result* out, double* angle_fam, int64_t* angle_view, double* scene_fam,
+                    Stage stage) {
+    struct Pass { int first, n, seq; dv_step_result r; };
+    const int npass = (A + kMaxHeadings - 1) / kMaxHeadings;
+    std::vector<Pass> ps((size_t)npass);
+    for (int p = 0; p < npass; ++p) {
+        ps[p].first = p * kMaxHeadings;
+        ps[p].n = A - ps[p].first < kMaxHeadings ? A - ps[p].first : kMaxHeadings;
+    }
+    int rc = DV_OK;
+    auto index_error = [&]() { return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)"); };
+    auto run_sync = [&](Pass& p, uint32_t fl, double* scene) -> int {
+        int r2 = stage(p.first, p.n);
+        if (r2) return r2;
+        c->result_slot = 0;
+        r2 = enqueue_step(c, fl, scene != nullptr);
+        if (r2) return r2;
+        r2 = finish_pass(c);
+        if (r2) return r2;
+        if (c->h_result[0].flags & kResSenseError) return index_error();
+        copy_result(c, 0, &p.r);
+        if (scene) memcpy(scene, c->h_scene, (size_t)c->cfg.F * sizeof(double));
+        return DV_OK;
+    };
+    if (scene_fam) {
+        // the per-view minimum over ALL headings (:301-303): pass by pass, merged on the host (the reference only plots it)
+        std::vector<double> tmp;
+        for (int p = 0; p < npass; ++p) {
+            if (p == 1) tmp.resize((size_t)c->cfg.F);
+            rc = run_sync(ps[p], flags, p == 0 ? scene_fam : tmp.data());
+            if (rc) return rc;
+            if (p > 0) for (int64_t f = 0; f < c->cfg.F; ++f) scene_fam[f] = tmp[(size_t)f] < scene_fam[f] ? tmp[(size_t)f] : scene_fam[f];
+        }
+    } else {
+        for (int p = 0; p < npass; ++p) {
+            rc = stage(ps[p].first, ps[p].n);
+            if (rc) break;
+            c->result_slot = p;
+            rc = enqueue_step(c, flags, false);
+            ps[p].seq = c->seq;
+            if (rc) break;
+        }
+        c->result_slot = 0;
+        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+        bool polled = c->spin_wait != 0;
+        for (int p = 0; p < npass; ++p)
+            if (polled && !spin_for_records(c, p, 1, ps[p].n, ps[p].seq)) polled = false;
+        if (!polled) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<int> again;
+        for (int p = 0; p < npass; ++p) {
+            const unsigned fl = c->h_result[p].flags;
+            if (fl & kResSenseError) return index_error();
+            if (fl & (kResNeedsResolve | DV_RES_OVERFLOW)) { again.push_back(p); continue; }
+            memcpy(&ps[p].r, &c->h_result[p], sizeof(dv_step_result));
+        }
+        for (int p : again) {
+            rc = run_sync(ps[p], flags, nullptr);
+            if (rc) return rc;
+        }
+    }
+    // merge: the passes whose maximum lies within the candidate window of the overall one contend; with more than one of them
+    // every contender's candidates are re-scored exactly (forced resolver) and the exact maxima compared, first pass on ties --
+    // passes are in heading order, so this is the first heading attaining the maximum
+    double M = -std::numeric_limits<double>::infinity();
+    for (const Pass& p : ps) M = p.r.approx_max > M ? p.r.approx_max : M;
+    const double window = c->delta + (c->metric == 1 ? 3e-6 * std::fabs(M) : 0.0);
+    std::vector<int> cont;
+    for (int p = 0; p < npass; ++p) if (ps[p].r.approx_max >= M - window) cont.push_back(p);
+    if (cont.size() > 1)
+        for (int p : cont)
+            if (!(ps[p].r.flags & (DV_RES_RESOLVED | DV_RES_EXACT_ALL))) {
+                rc = run_sync(ps[p], flags | DV_STEP_FORCE_RESOLVE, nullptr);
+                if (rc) return rc;
+            }
+    int win = cont[0];
+    for (int p : cont) if (ps[p].r.best_fam > ps[win].r.best_fam) win = p;
+    const dv_step_result& w = ps[win].r;
+    out->best_heading = ps[win].first + w.best_heading;
+    out->flags = w.flags & ~kResNeedsResolve;
+    out->best_view = w.best_view;
+    out->best_fam = w.best_fam;
+    out->n_headings = A;
+    out->n_passes = npass;
+    out->n_contending = (int)cont.size();
+    out->reserved = 0;
+    for (const Pass& p : ps)
+        for (int a = 0; a < p.n; ++a) {
+            angle_fam[p.first + a] = p.r.angle_fam[a];
+            if (angle_view) angle_view[p.first + a] = p.r.angle_view[a];
+        }
+    return DV_OK;
+}
+
+static int check_wide_args(dv_ctx* c, int A, const dv_wide_result* result, const double* angle_fam) {
+    if (!c) return DV_ERR_INVALID;
+    if (!c->have_lib) return fail(c, DV_ERR_STATE, "no library set (call dv_set_library first)");
+    if (c->metric != 0) return fail(c, DV_ERR_STATE, "the wide steps score sads_hsv libraries");
+    if (A < 1 || A > DV_MAX_WIDE_HEADINGS) return fail(c, DV_ERR_INVALID, "n_headings %d outside [1, %d]", A, DV_MAX_WIDE_HEADINGS);
+    if (!result || !angle_fam) return fail(c, DV_ERR_INVALID, "result or angle_fam is NULL");
+    return DV_OK;
+}
+
+extern "C" int dv_step_wide(dv_ctx* c, const uint8_t* patches, int A, uint32_t flags, dv_wide_result* result, double* angle_fam,
+                            int64_t* angle_view, double* scene_fam) {
+    int rc = check_wide_args(c, A, result, angle_fam);
+    if (rc) return rc;
+    if (!patches) return fail(c, DV_ERR_INVALID, "patches is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t heading_bytes = (size_t)c->cfg.P * 3;
+    return run_wide(c, A, flags, result, angle_fam, angle_view, scene_fam, [&](int first, int n) {
+        if (hipMemcpyAsync(c->d_raw_patches, patches + (size_t)first * heading_bytes, (size_t)n * heading_bytes, hipMemcpyHostToDevice,
+                           c->stream) != hipSuccess)
+            return fail(c, DV_ERR_HIP, "dv_step_wide: patch upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return prep_patches(c, n);
+    });
+}
+
+extern "C" int dv_sense_step_wide(dv_ctx* c, double x, double y, const double* angles, int A, uint32_t flags, dv_wide_result* result,
+                                  double* angle_fam, int64_t* angle_view, double* scene_fam) {
+    int rc = check_wide_args(c, A, result, angle_fam);
+    if (rc) return rc;
+    if (!angles) return fail(c, DV_ERR_INVALID, "angles is NULL");
+    if (!c->have_sensor) return fail(c, DV_ERR_STATE, "sensor not configured");
+    if (c->sensor.sw != c->w || c->sensor.sh != c->h)
+        return fail(c, DV_ERR_STATE, "sensor is %dx%d but the library holds %dx%d views", c->sensor.sw, c->sensor.sh, c->w, c->h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_wide(c, A, flags, result, angle_fam, angle_view, scene_fam, [&](int first, int n) {
+        PoseSet poses;
+        for (int a = 0; a < n; ++a) poses.p[a] = make_pose(x, y, angles[first + a]);
+        for (int a = n; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
+        return sense_prep_launch(c, poses, 1, n);
+    });
+}
+
 extern "C" int dv_resolve(dv_ctx* c, dv_step_result* result) {
     if (!c || !result) return DV_ERR_INVALID;
     if (!c->have_lib || !c->step_pending) return fail(c, DV_ERR_STATE, "no step to resolve");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!(c->h_result->flags & (DV_RES_EXACT_ALL | DV_RES_RESOLVED))) {
+    if (c->metric != 2 && !(c->h_result->flags & (DV_RES_EXACT_ALL | DV_RES_RESOLVED))) {
         int rc = enqueue_resolve(c);
         if (rc) return rc;
     }

@@ -1110,6 +1110,7 @@ constexpr int kTmpCap = 4096;       // entries of the shared extra-candidate lis
 // result record.  Run by the last block to arrive (small libraries) or by k_fold, a kernel of its own with 1024 threads
 // behind k_finish (large libraries: the kernel boundary replaces the arrival ticket, and four times the threads walk the
 // summaries).  Generic in blockDim.x.
+template <int kBatch = 16>
 __device__ __forceinline__ void fold_and_decide(const unsigned long long* __restrict__ bsum, const unsigned long long* __restrict__ ctmp,
                                                 unsigned long long* __restrict__ cand, StepState* __restrict__ st,
                                                 StepResultDev* __restrict__ out, double* __restrict__ rec, const LibCfg& c, int A,
@@ -1126,7 +1127,7 @@ __device__ __forceinline__ void fold_and_decide(const unsigned long long* __rest
     const int G = blockDim.x / A;                       // thread groups; thread (a, r) walks blocks r, r+G, ...
     const int a = tid % A, r = tid / A;
     const bool active = r < G;
-    constexpr int kBatch = 16;                          // summaries requested before the first is used
+    // kBatch: summaries requested before the first is used (16; 8 in the 1024-thread k_fold, whose 128 registers per lane 16 did not fit)
     // Up to kBatch blocks per thread (50 000 views x 16 headings: 13): maxima AND first views are fetched in one
     // round trip and stay in registers for the second pass.  Longer lists are walked twice.
     const bool single = nb <= G * kBatch;
@@ -1410,13 +1411,16 @@ k_finish(const unsigned* __restrict__ part, const int* __restrict__ hsconst, con
     fold_and_decide(bsum, ctmp, cand, st, out, rec, c, A, delta, force, seq, sense_err, agent, nb);
 }
 
-// fold_and_decide as its own launch: grid (1, agents), 1024 threads.
-__global__ void __launch_bounds__(1024)
+// fold_and_decide as its own launch: grid (1, agents), NT threads (launch_fold picks 256 / 512 / 1024 by the length of the list).
+// One instantiation per thread count, so that the 256-thread form of every single-agent step is not held to the 128 registers
+// per lane of a 1024-thread workgroup (it kept six of them in scratch: tools/kernel_resources.py).
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_fold(unsigned long long* __restrict__ bsum, unsigned long long* __restrict__ ctmp, unsigned long long* __restrict__ cand,
        StepState* __restrict__ st, StepResultDev* __restrict__ out, double* __restrict__ rec, LibCfg c, int A, double delta, int force,
        int seq, const unsigned long long* __restrict__ sense_err, int nb) {
     const int agent = blockIdx.y;
-    fold_and_decide(bsum + (long long)agent * nb * 2 * A, ctmp + (long long)agent * kTmpCap * 2, cand + (long long)agent * kCandCap,
+    fold_and_decide<(NT > 512 ? 8 : 16)>(bsum + (long long)agent * nb * 2 * A, ctmp + (long long)agent * kTmpCap * 2, cand + (long long)agent * kCandCap,
                     st + agent, out + agent, rec + (long long)agent * (3 + 4 * kMaxHeadings), c, A, delta, force, seq, sense_err, agent, nb);
 }
 
@@ -1591,6 +1595,27 @@ __global__ void k_retile_f32(const float* __restrict__ raw, float4* __restrict__
     ftiles[(r / c.Q) * c.gstride + (long long)q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// Synthetic float32 library straight into ftiles: view f, pixel p <- the top 24 bits of splitmix64((first+f)*P + p + seed*GOLDEN)
+// as a float in [0, 1) (exact in fp32) -- navsim_amd/synth.py:synth_views_f32 makes the same values.
+__global__ void k_generate_tiles_f32(float4* __restrict__ ftiles, LibCfg c, unsigned long long seed) {
+    const long long total = (c.Fpad / 64) * (long long)c.Q * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long r = t >> 6;
+    const int q = (int)(r % c.Q);
+    const long long f = (r / c.Q) * 64 + lane;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f < c.F) {
+        const unsigned long long base = (unsigned long long)(c.first + f) * (unsigned long long)c.P + seed * 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < 4; ++i) {
+            const int px = q * 4 + i;
+            if (px < c.P) v[i] = (float)(splitmix64(base + (unsigned long long)px) >> 40) * (1.0f / 16777216.0f);
+        }
+    }
+    ftiles[(r / c.Q) * c.gstride + (long long)q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // fprep[q][j][a] = patch pixel 4q + j of heading a: wave-uniform, read with scalar loads into SGPRs.
 __global__ void k_prep_f32(const float* __restrict__ raw, float* __restrict__ fprep, LibCfg c, int A, int APAD) {
     const long long total = (long long)c.Q * 4 * APAD;
@@ -1761,6 +1786,13 @@ k_retile_u8(const unsigned char* __restrict__ raw, uint4* __restrict__ tiles, un
         if (nrm) atomicAdd(&vnorm[f], nrm);
     }
     tiles[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// One byte of every sensed HSV pixel (the channel the ssd_u8 plug-in compares): uint8[n_px][3] -> uint8[n_px].
+__global__ void __launch_bounds__(256)
+k_take_channel(const unsigned char* __restrict__ hsv, unsigned char* __restrict__ out, long long n_px, int channel) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_px) out[t] = hsv[t * 3 + channel];
 }
 
 // u8prep and pnorm of the resident patches (pnorm zeroed by the caller).  grid = ceil(passes * K * 64 / 256).
@@ -2914,9 +2946,11 @@ sad_ring_i8(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, in
                 for (int t = 0; t < TILES; ++t) {
                     if (live[t]) {
                         int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+                        int half = lane >> 5;                       // opaque: the row addresses are not hoisted out of the item loop (sad_lc_fp4's store_sums)
+                        asm volatile("" : "+v"(half));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
                             if (m < rows) dst[(long long)m * c.Fpad] = tot[t][r];
                         }
                     }
@@ -3227,9 +3261,11 @@ sad_ring_fp4(const uint4* __restrict__ btiles, const uint4* __restrict__ coef4, 
                         if (seg == 0 ? !has_hs_sum : !c.hasv) continue;
                         const int type_row = seg ? has_hs_sum : 0;
                         int* dst = part + ((long long)(ch * nsum + type_row) * apad_total + a_off) * c.Fpad + gidx[t] * 32 + (lane & 31);
+                        int half = lane >> 5;                       // opaque, as above
+                        asm volatile("" : "+v"(half));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
                             if (m < rows) dst[(long long)m * c.Fpad] = seg ? tot_v[t][r] : tot_hs[t][r];
                         }
                     }
@@ -3444,6 +3480,29 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { tot_hs[u][r] = 0; tot_v[u][r] = 0; }
+        // Unfused passes (k_finish behind the kernel: want_scene steps, the mixed layout) store a segment's sums as soon as its
+        // accumulators are flushed -- the saturation sums at the segment boundary, not at the item's end: kept live through the V
+        // stages beside the 128 accumulators, the operand buffers and the stores' addresses they cost the loop 36-76 bytes of
+        // scratch per lane (tools/kernel_resources.py; tests/test_host_logic.py now refuses any)
+        auto store_sums = [&](const int (&tot)[2][16], int seg) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = HT == 1 ? u : 0, h = HT == 1 ? 0 : u;
+                const int rows = (apad_total - a_off - 32 * h) < 32 ? (apad_total - a_off - 32 * h) : 32;
+                if (!live[t]) continue;
+                const int type_row = seg ? has_hs_sum : 0;
+                int* dst = part + ((long long)type_row * apad_total + a_off + 32 * h) * c.Fpad + gidx[t] * 32 + (lane & 31);
+                // (the lane's row offset is made opaque here: the sixteen 64-bit row addresses are loop invariants, and hoisted out of the
+                // item loop they sat in 32 registers through the stage loop -- the spills tools/kernel_resources.py showed)
+                int half = lane >> 5;
+                asm volatile("" : "+v"(half));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < rows) dst[(long long)m * c.Fpad] = tot[u][r];
+                }
+            }
+        };
         {
             v16f_t acc[2][4];
 #pragma unroll
@@ -3595,6 +3654,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
             run_stages(0, hs_end, IntC<0>{});
             if (hs_end > 0 && hs_end < nst) {
                 flush(tot_hs, b.wacc[0], false);
+                if constexpr (!FUSE) store_sums(tot_hs, 0);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -3606,28 +3666,14 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
             else run_stages(hs_end, nst, IntC<0>{});
             if (hs_end < nst) flush(tot_v, b.wacc[1], codev);           // what the accumulators hold at the end: the V segment's sums,
             else flush(tot_hs, b.wacc[0], false);                       // unless there are no V K-steps
+            if constexpr (!FUSE) {
+                // (a sum without K-steps is stored as the zeros it was initialised to: the mixed layout's saturation rows, a constant value plane)
+                if (has_hs_sum && !(hs_end > 0 && hs_end < nst)) store_sums(tot_hs, 0);
+                if (c.hasv) store_sums(tot_v, 1);
+            }
         }
         if (j == 0) DV_STAMP(2);
-        if constexpr (!FUSE) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = HT == 1 ? u : 0, h = HT == 1 ? 0 : u;
-                const int rows = (apad_total - a_off - 32 * h) < 32 ? (apad_total - a_off - 32 * h) : 32;
-                if (live[t]) {
-#pragma unroll
-                    for (int seg = 0; seg < 2; ++seg) {
-                        if (seg == 0 ? !has_hs_sum : !c.hasv) continue;
-                        const int type_row = seg ? has_hs_sum : 0;
-                        int* dst = part + ((long long)type_row * apad_total + a_off + 32 * h) * c.Fpad + gidx[t] * 32 + (lane & 31);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            if (m < rows) dst[(long long)m * c.Fpad] = seg ? tot_v[u][r] : tot_hs[u][r];
-                        }
-                    }
-                }
-            }
-        } else {
+        if constexpr (FUSE) {
             if (j == 0) DV_STAMP(3);
             if constexpr (HT == 1) {
                 auto of_hs = [&](int t, int r) -> int { return tot_hs[t][r]; };

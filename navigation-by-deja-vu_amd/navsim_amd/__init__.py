@@ -9,7 +9,7 @@ scripts/run_experiment.py:84).  Scoring runs only on the GPU through libdejavu_h
 from .agent import (NavBySceneFamiliarity, StopNavigationException, ReachedEndOfTrainingPathException,
                     NavigatingFailedException, TooFarFromTrainingPathException,
                     OutOfLandscapeBoundsException, fill_sensor_from, downscale_chem)
-from .util import sads_familiarity, hip_sads_familiarity
+from .util import sads_familiarity, hip_sads_familiarity, ssd_familiarity
 from .engine import FamiliarityEngine
 from ._native import EngineError
 from . import synth
@@ -19,6 +19,6 @@ from .ensemble import NavEnsemble
 __all__ = [
     "NavBySceneFamiliarity", "StopNavigationException", "ReachedEndOfTrainingPathException",
     "NavigatingFailedException", "TooFarFromTrainingPathException", "OutOfLandscapeBoundsException",
-    "sads_familiarity", "hip_sads_familiarity", "FamiliarityEngine", "EngineError",
+    "sads_familiarity", "hip_sads_familiarity", "ssd_familiarity", "FamiliarityEngine", "EngineError",
     "fill_sensor_from", "downscale_chem", "synth", "run_experiment", "run_ensemble", "chop_path_to_len", "NavEnsemble",
 ]

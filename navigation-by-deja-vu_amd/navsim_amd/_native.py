@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdejavu_hip.so")
 
 DV_MAX_HEADINGS = 64
 DV_MAX_HUE_PLANES = 4
+DV_MAX_WIDE_HEADINGS = 4096
 DV_STEP_FORCE_RESOLVE = 1
 DV_STEP_WANT_SCENE = 2
 DV_RES_RESOLVED = 1
@@ -42,6 +43,19 @@ class StepResult(ctypes.Structure):
         ("angle_view", ctypes.c_int64 * DV_MAX_HEADINGS),
         ("exact_fam", ctypes.c_double * DV_MAX_HEADINGS),
         ("exact_view", ctypes.c_int64 * DV_MAX_HEADINGS),
+    ]
+
+
+class WideResult(ctypes.Structure):
+    _fields_ = [
+        ("best_heading", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("best_view", ctypes.c_int64),
+        ("best_fam", ctypes.c_double),
+        ("n_headings", ctypes.c_int32),
+        ("n_passes", ctypes.c_int32),
+        ("n_contending", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -131,14 +145,21 @@ PROTOTYPES = {
     "dv_step_batch": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
                                      ctypes.POINTER(StepResult)]),
     "dv_resolve": (ctypes.c_int, [_ctx_p, ctypes.POINTER(StepResult)]),
+    "dv_step_wide": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(WideResult), _f64p, _i64p, _f64p]),
+    "dv_sense_step_wide": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, _f64p, ctypes.c_int, ctypes.c_uint32,
+                                          ctypes.POINTER(WideResult), _f64p, _i64p, _f64p]),
     "dv_set_library_f32": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int64]),
+    "dv_generate_library_f32": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "dv_score_f32": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float), _f64p]),
     "dv_step_f32": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_uint32,
                                    ctypes.POINTER(StepResult), _f64p]),
     "dv_set_library_u8": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "dv_score_u8": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
     "dv_step_u8": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
+    "dv_set_library_u8_from_poses": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, _u8p]),
+    "dv_sense_step_u8": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, _f64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                        ctypes.POINTER(StepResult), _f64p]),
     "dv_upload_patches": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int]),
     "dv_generate_patches": (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int]),
     "dv_step_enqueue": (ctypes.c_int, [_ctx_p, ctypes.c_uint32]),
@@ -231,3 +252,11 @@ def u8ptr(a):
 
 def f64ptr(a):
     return a.ctypes.data_as(_f64p)
+
+
+def i64ptr(a):
+    return a.ctypes.data_as(_i64p)
+
+
+# byte offset of the per-heading arrays inside a step record (angle_fam, angle_view, exact_fam, exact_view follow one another)
+RESULT_ARRAYS_OFFSET = StepResult.angle_fam.offset

@@ -226,8 +226,12 @@ class NavBySceneFamiliarity(object):
             for pt in points:
                 self._check_bounds(pt)
             # sensed and ingested on the device; familiar_scenes comes back for the API
-            self.familiar_scenes[...] = self._engine.set_library_from_poses(
-                points[:, 0], points[:, 1], view_headings, self.familiarity_model.chem_weight)
+            if getattr(self.familiarity_model, "metric", "sads_hsv") == "ssd":
+                self.familiar_scenes[...] = self._engine.set_library_u8_from_poses(
+                    points[:, 0], points[:, 1], view_headings, self.familiarity_model.channel)
+            else:
+                self.familiar_scenes[...] = self._engine.set_library_from_poses(
+                    points[:, 0], points[:, 1], view_headings, self.familiarity_model.chem_weight)
         else:
             for i in range(n):
                 self.familiar_scenes[i] = self.get_sensor_mat(points[i], view_headings[i])
@@ -260,16 +264,26 @@ class NavBySceneFamiliarity(object):
         headings = np.arctan2(steps[:, 1], steps[:, 0])
         view_headings = headings[np.minimum(np.arange(n), n - 2)]
         engine = getattr(self._familiarity_func, "engine", None)
-        if self._engine is not None and engine is self._engine:
+        ssd = str(getattr(self._familiarity_func, "metric", "")).startswith("ssd")
+        if self._engine is not None and engine is self._engine and not ssd:
             for pt in points:
                 self._check_bounds(pt)
             new_views = self._engine.append_library_from_poses(points[:, 0], points[:, 1], view_headings)
+        elif ssd:
+            # the SSD libraries have no append: sense the new views and ingest everything again
+            new_views = np.stack([self.get_sensor_mat(points[i], view_headings[i]) for i in range(n)])
+            both = np.concatenate([self.familiar_scenes, new_views])
+            if self._familiarity_func.metric == "ssd_u8":
+                engine.set_library_u8(np.ascontiguousarray(both[..., self._familiarity_func.channel]))
+            else:
+                engine.set_library_f32(np.ascontiguousarray(both[..., self._familiarity_func.channel]
+                                                            if both.ndim == 4 else both))
         else:
             new_views = np.stack([self.get_sensor_mat(points[i], view_headings[i]) for i in range(n)])
             if engine is not None and hasattr(engine, "append_library"):
                 engine.append_library(new_views)
         self.familiar_scenes = np.concatenate([self.familiar_scenes, new_views])
-        if engine is None or not hasattr(engine, "append_library"):
+        if engine is None or (not ssd and not hasattr(engine, "append_library")):
             self._familiarity_func = self.familiarity_model(self.familiar_scenes)     # any other plug-in: hand it all views again
         self.training_path_length = self.training_path_length + np.sum(np.linalg.norm(steps, axis=1))
         self.training_path = np.concatenate([self.training_path, points])
@@ -419,7 +433,10 @@ class NavBySceneFamiliarity(object):
 
         func = self._familiarity_func
         engine = getattr(func, "engine", None)
-        if engine is not None:
+        if engine is not None and str(getattr(func, "metric", "")).startswith("ssd"):
+            self._step_ssd(func, engine, position)
+            best_idex = self.last_scored_idex
+        elif engine is not None:
             # one fused device step for all headings: kernel + min-merge + max + argmax (:289-315)
             try:
                 if engine is self._engine:
@@ -467,6 +484,35 @@ class NavBySceneFamiliarity(object):
             best_idex = np.argmax(self.angle_familiarity)
 
         self._move(best_idex, fake)
+
+    def _step_ssd(self, func, engine, position):
+        """The heading loop (:289-315) with the SSD plug-in (util.ssd_familiarity): ONE device step -- sense, score on the matrix
+        cores, decide -- when the sensor model runs on the GPU; familiarity = -SSD, so the reference's max / argmax hold."""
+        angles = (self.angle + self.angle_offsets) % (2 * np.pi)
+        try:
+            if engine is self._engine:
+                self._check_bounds(position)
+                res = engine.sense_step_u8(position[0], position[1], angles, func.channel,
+                                           want_scene=self.track_scene_familiarity)
+            else:
+                patches = np.stack([self.get_sensor_mat(position, a) for a in angles])
+                planes = np.ascontiguousarray(patches[..., func.channel] if patches.ndim == 4 else patches)
+                if func.metric == "ssd_u8":
+                    res = engine.step_u8(planes, want_scene=self.track_scene_familiarity)
+                else:
+                    res = engine.step_f32(planes, want_scene=self.track_scene_familiarity)
+        except Exception:
+            self.scene_familiarity[:] = np.inf
+            self._scene_is_inf = True
+            raise
+        np.negative(res["angle_ssd"], out=self.angle_familiarity)
+        if self.track_scene_familiarity:
+            np.negative(res["scene_ssd"], out=self.scene_familiarity)     # min over headings of -SSD = -(max over headings of SSD)
+            self._scene_is_inf = False
+        elif not self._scene_is_inf:
+            self.scene_familiarity[:] = np.inf
+            self._scene_is_inf = True
+        self.last_scored_idex = res["best_idex"]
 
     def _move(self, best_idex, fake=False):
         """The part of a step after the heading is chosen (:316-329): turn, advance, book-keeping, stop conditions."""

@@ -166,6 +166,10 @@ class FamiliarityEngine(object):
     def sense_step(self, x, y, angles, want_scene=True, force_resolve=False):
         """Sense the heading patches at (x, y) and score them: one call for an agent step's device work."""
         angles = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+        if len(angles) > N.DV_MAX_HEADINGS:
+            return self._wide(lambda flags, res, fam, view, scene: self._lib.dv_sense_step_wide(
+                self._ctx, float(x), float(y), N.f64ptr(angles), len(angles), flags, res, fam, view, scene),
+                len(angles), want_scene, force_resolve, "dv_sense_step_wide")
         r = N.StepResult()
         scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
         self._check_sense(self._lib.dv_sense_step(self._ctx, float(x), float(y), N.f64ptr(angles), len(angles),
@@ -178,12 +182,19 @@ class FamiliarityEngine(object):
         per-heading familiarities written into out_fam; returns the chosen heading's index.  Same call as sense_step(...,
         want_scene=False) -- dv_sense_step -- through ONE result record and ONE angle buffer kept for the engine's lifetime
         (no per-step allocations, views or dictionaries on the host side)."""
+        if len(offsets) > N.DV_MAX_HEADINGS:
+            # more headings than one library pass holds: the wide step (passes merged in the library, same decision rule)
+            res = self.sense_step(x, y, (angle + offsets) % (2 * np.pi), want_scene=False)
+            out_fam[:] = res["angle_familiarity"]
+            return res["best_idex"]
+        if out_fam.shape != (len(offsets),):
+            raise ValueError("out_fam has shape %r, expected (%d,)" % (out_fam.shape, len(offsets)))
         st = self._step_state
         if st is None or len(st[0]) != len(offsets):
             res = N.StepResult()
             buf = np.empty(len(offsets), dtype=np.float64)
             st = self._step_state = (buf, N.f64ptr(buf), res, ctypes.byref(res),
-                                     np.frombuffer(res, dtype=np.float64, count=len(offsets), offset=56))
+                                     np.frombuffer(res, dtype=np.float64, count=len(offsets), offset=N.RESULT_ARRAYS_OFFSET))
         buf, bufp, res, resp, fam = st
         np.add(offsets, angle, out=buf)
         np.mod(buf, 2 * np.pi, out=buf)
@@ -247,10 +258,10 @@ class FamiliarityEngine(object):
     @staticmethod
     def _result_dict(r, scene):
         A = r.n_headings
-        # views of the record's four per-heading arrays ([4][64] 8-byte values after the 56-byte header); every step
+        # views of the record's four per-heading arrays ([4][64] 8-byte values after the header); every step
         # has its own record, which the views keep alive
         M = N.DV_MAX_HEADINGS
-        f64 = np.frombuffer(r, dtype=np.float64, count=4 * M, offset=56)
+        f64 = np.frombuffer(r, dtype=np.float64, count=4 * M, offset=N.RESULT_ARRAYS_OFFSET)
         i64 = f64.view(np.int64)
         return dict(best_idex=r.best_heading, best_view=r.best_view, step_familiarity=r.best_fam,
                     angle_familiarity=f64[:A], angle_view=i64[M:M + A],
@@ -264,12 +275,29 @@ class FamiliarityEngine(object):
         if patches.ndim != 4:
             raise ValueError("patches must be uint8[A,h,w,3]")
         self._patch_shape_ok(patches, (patches.shape[0],))
+        if patches.shape[0] > N.DV_MAX_HEADINGS:
+            return self._wide(lambda flags, res, fam, view, scene: self._lib.dv_step_wide(
+                self._ctx, N.u8ptr(patches), patches.shape[0], flags, res, fam, view, scene),
+                patches.shape[0], want_scene, force_resolve, "dv_step_wide")
         r = N.StepResult()
         scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
         self._check(self._lib.dv_step(self._ctx, N.u8ptr(patches), patches.shape[0],
                                       N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, ctypes.byref(r),
                                       N.f64ptr(scene) if want_scene else None), "dv_step")
         return self._result_dict(r, scene)
+
+    def _wide(self, call, A, want_scene, force_resolve, what):
+        """A step of more than DV_MAX_HEADINGS headings (the reference takes any n_test_angles, NavBySceneFamiliarity.py:62,289):
+        ceil(A / 64) library passes merged inside the library; same keys as a single-pass step's result."""
+        res = N.WideResult()
+        fam = np.empty(A, dtype=np.float64)
+        view = np.empty(A, dtype=np.int64)
+        scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
+        self._check_sense(call(N.DV_STEP_FORCE_RESOLVE if force_resolve else 0, ctypes.byref(res), N.f64ptr(fam), N.i64ptr(view),
+                               N.f64ptr(scene) if want_scene else None), what)
+        return dict(best_idex=res.best_heading, best_view=res.best_view, step_familiarity=res.best_fam, angle_familiarity=fam,
+                    angle_view=view, flags=res.flags, n_passes=res.n_passes, n_contending=res.n_contending,
+                    scene_familiarity=scene)
 
     def step_batch(self, patches, force_resolve=False):
         """Ensemble step: patches uint8[N, A, h, w, 3] -> list of N result dicts (one library pass per 64/A agents)."""
@@ -300,6 +328,12 @@ class FamiliarityEngine(object):
         fp = views.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
         self._check(self._lib.dv_set_library_f32(self._ctx, fp, F, h, w, int(first_view)), "dv_set_library_f32")
         self.n_views, self.shape = F, (h, w)
+
+    def generate_library_f32(self, seed, n_views, h, w, first_view=0):
+        """Same values as synth.synth_views_f32(seed, n_views, h, w, first_view), generated in HBM."""
+        self._check(self._lib.dv_generate_library_f32(self._ctx, int(seed), int(n_views), int(h), int(w), int(first_view)),
+                    "dv_generate_library_f32")
+        self.n_views, self.shape = int(n_views), (int(h), int(w))
 
     def score_f32(self, patch, ssdbuf=None):
         patch = self._f32(patch, "patch")
@@ -335,6 +369,32 @@ class FamiliarityEngine(object):
         F, h, w = views.shape
         self._check(self._lib.dv_set_library_u8(self._ctx, N.u8ptr(views), F, h, w, int(first_view)), "dv_set_library_u8")
         self.n_views, self.shape = F, (h, w)
+
+    def set_library_u8_from_poses(self, x, y, angle, channel=2, first_view=0, want_views=True):
+        """train_from_path for the ssd_u8 plug-in on the device: sense the poses, ingest their `channel` bytes as the library;
+        returns familiar_scenes (uint8[n,h,w,3]) when want_views."""
+        x, y, angle = self._pose_arrays(x, y, angle)
+        h, w = self.sensor_shape
+        views = np.empty((len(x), h, w, 3), dtype=np.uint8) if want_views else None
+        self._check_sense(self._lib.dv_set_library_u8_from_poses(self._ctx, N.f64ptr(x), N.f64ptr(y), N.f64ptr(angle), len(x),
+                                                                 int(channel), int(first_view),
+                                                                 N.u8ptr(views) if want_views else None),
+                          "dv_set_library_u8_from_poses")
+        self.n_views, self.shape = len(x), (h, w)
+        return views
+
+    def sense_step_u8(self, x, y, angles, channel=2, want_scene=False):
+        """dv_sense_step for an ssd_u8 library: the heading patches sensed at (x, y), their `channel` bytes scored on the int8
+        matrix cores, the least-SSD heading decided on the device.  Result as step_u8's."""
+        angles = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+        r = N.StepResult()
+        scene = np.empty(self.n_views, dtype=np.float64) if want_scene else None
+        self._check_sense(self._lib.dv_sense_step_u8(self._ctx, float(x), float(y), N.f64ptr(angles), len(angles), int(channel), 0,
+                                                     ctypes.byref(r), N.f64ptr(scene) if want_scene else None), "dv_sense_step_u8")
+        d = self._result_dict(r, scene)
+        return dict(best_idex=d["best_idex"], best_view=d["best_view"], step_ssd=d["step_familiarity"],
+                    angle_ssd=d["angle_familiarity"], angle_view=d["angle_view"], n_candidates=d["n_candidates"],
+                    flags=d["flags"], scene_ssd=scene)
 
     def score_u8(self, patch, ssdbuf=None):
         patch = N.as_u8(patch, "patch")

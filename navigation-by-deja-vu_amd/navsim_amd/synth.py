@@ -65,6 +65,19 @@ def synth_views(seed, n_views, h, w, first_view=0, full_range_s=False):
     return out.reshape(n_views, h, w, 3)
 
 
+def synth_views_f32(seed, n_views, h, w, first_view=0):
+    """float32[n_views, h, w] views for the ssd_f32 metric: pixel value = top 24 bits of its hash word / 2**24, in [0, 1)
+    and exact in float32 -- the same values as the HIP generator (dv_generate_library_f32: k_generate_tiles_f32)."""
+    npx = h * w
+    out = np.empty((n_views, npx), dtype=np.float32)
+    slab = max(1, (1 << 22) // npx)
+    for f0 in range(0, n_views, slab):
+        f1 = min(n_views, f0 + slab)
+        z = _pixel_words(seed, (first_view + f0) * npx, (f1 - f0) * npx)
+        out[f0:f1] = ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(f1 - f0, npx)
+    return out.reshape(n_views, h, w)
+
+
 def synth_patches(seed, n_headings, h, w, full_range_s=False):
     """uint8[A, h, w, 3] sensor patches: the same distribution, stream seed+1."""
     return synth_views(seed + 1, n_headings, h, w, full_range_s=full_range_s)

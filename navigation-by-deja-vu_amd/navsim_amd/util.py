@@ -2,6 +2,8 @@
 
 Reference: navsim/util.pyx:10-25 (`sads_familiarity(chem_weight)` -> `internal(scenes)` -> `func`).
 """
+import numpy as np
+
 from .engine import FamiliarityEngine
 
 
@@ -47,3 +49,67 @@ def sads_familiarity(chem_weight=0.0, device=0, exact=False):
 
 
 hip_sads_familiarity = sads_familiarity
+
+
+def ssd_familiarity(channel=2, device=0):
+    """The north star's literal metric -- the pixel-wise sum of squared differences, the reference's `ssds`
+    (navsim/util.pyx:171-184) -- as a familiarity plug-in of the reference's shape (util.pyx:10-25):
+
+    stage 1  ssd_familiarity(channel)                  picks the compared channel of HSV scenes (0 H, 1 S, 2 V)
+    stage 2  model(scenes) -> func                     uploads the library once:
+                 uint8[F,h,w,3] / uint8[F,h,w]         -> the ssd_u8 metric: exact integer sums on the int8 matrix cores
+                 float32[F,h,w]                        -> the ssd_f32 metric (within 1e-6 relative of ssds on the upcast data)
+    func(scene, fambuf: float64[F])                    writes fambuf[f] = -SSD(scene, view f) in place: the most familiar view
+                                                       is the one with the least SSD, as np.max / np.argmax of the agent's loop
+                                                       (NavBySceneFamiliarity.py:313,315) expect
+    func.max_familiarity = 0.0                         (an identical scene)
+
+    Extras carried by `func` for the agent's fused step: func.engine, func.metric ("ssd_u8" / "ssd_f32"), func.channel.
+    """
+    if channel not in (0, 1, 2):
+        raise ValueError("channel must be 0 (H), 1 (S) or 2 (V), got %r" % (channel,))
+
+    def plane(a, lead):
+        """The compared plane of a scene array: [.., h, w, 3] -> [.., h, w]; a single-channel array as it is."""
+        a = np.asarray(a)
+        if a.ndim == lead + 3:
+            a = a[..., channel]
+        if a.ndim != lead + 2:
+            raise ValueError("scene array has shape %r" % (a.shape,))
+        return np.ascontiguousarray(a)
+
+    def bind(engine, metric):
+        def func(scene, fambuf):
+            if not (isinstance(fambuf, np.ndarray) and fambuf.dtype == np.float64):
+                raise ValueError("Buffer dtype mismatch for fambuf, expected 'double'")
+            p = plane(scene, 0)
+            if metric == "ssd_u8":
+                engine.score_u8(p, fambuf)
+            else:
+                engine.score_f32(p, fambuf)
+            np.negative(fambuf, out=fambuf)
+
+        func.max_familiarity = 0.0
+        func.engine = engine
+        func.metric = metric
+        func.channel = channel
+        return func
+
+    def ssd_familiarity_internal(scenes):
+        scenes = np.asarray(scenes)
+        engine = FamiliarityEngine(device=device)
+        if scenes.dtype == np.uint8:
+            engine.set_library_u8(plane(scenes, 1))
+            return bind(engine, "ssd_u8")
+        if scenes.dtype == np.float32:
+            engine.set_library_f32(plane(scenes, 1))
+            return bind(engine, "ssd_f32")
+        engine.close()
+        raise ValueError("Buffer dtype mismatch, expected 'uint8_t' or 'float' but got '%s'" % scenes.dtype)
+
+    # hooks for navsim_amd.NavBySceneFamiliarity (landscape, sensor model and library on the GPU: see sads_familiarity)
+    ssd_familiarity_internal.make_engine = lambda: FamiliarityEngine(device=device)
+    ssd_familiarity_internal.from_engine = lambda engine, scenes: bind(engine, "ssd_u8")
+    ssd_familiarity_internal.metric = "ssd"
+    ssd_familiarity_internal.channel = channel
+    return ssd_familiarity_internal

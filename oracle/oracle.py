@@ -136,8 +136,7 @@ def int_sums(library, scene):
 _omp = None
 
 
-def step_fast(library, patches, chem_weight, threads):
-    """Multi-core integer form of the step (oracle_step_fast in liboracle_omp.so); bench.py's second CPU figure only."""
+def _omp_lib():
     global _omp
     if _omp is None:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle_omp.so")
@@ -147,6 +146,40 @@ def step_fast(library, patches, chem_weight, threads):
         _omp.oracle_step_fast.restype = ctypes.c_int
         _omp.oracle_step_fast.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _u8p, ctypes.c_int,
                                           ctypes.c_double, ctypes.c_int, _f64p, _i64p, ctypes.POINTER(ctypes.c_int32)]
+        _omp.oracle_synth_int_sums.restype = ctypes.c_int
+        _omp.oracle_synth_int_sums.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, _u8p, ctypes.c_int, _i64p, _i64p]
+    return _omp
+
+
+def have_omp():
+    return os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle_omp.so"))
+
+
+def synth_int_sums(seed, first_view, n_views, h, w, scene, full_range_s=False, threads=None):
+    """int_sums of `scene` against views [first_view, first_view + n_views) of navsim_amd.synth.synth_views(seed, ...),
+    regenerated view by view inside the C loop (dense checks of full-size synthetic libraries)."""
+    scene = _u8(scene)
+    assert scene.shape == (h, w, 3)
+    s_hs = np.empty(n_views, dtype=np.int64)
+    s_v = np.empty(n_views, dtype=np.int64)
+    if threads is None:
+        threads = max(1, min(32, os.cpu_count() or 1))
+    _omp_lib().oracle_synth_int_sums(int(seed), int(first_view), int(n_views), int(h), int(w), 1 if full_range_s else 0,
+                                     scene.ctypes.data_as(_u8p), int(threads), s_hs.ctypes.data_as(_i64p),
+                                     s_v.ctypes.data_as(_i64p))
+    return s_hs, s_v
+
+
+def fam_from_sums(s_hs, s_v, n_px, chem_weight):
+    """fam = P - (0.5 cw S_hs + (1 - cw) S_v) / 255 from the exact integer sums (util.pyx:59-73 with the per-pixel
+    division taken out of the loop: within ~1e-12 of the sequential doubles)."""
+    return float(n_px) - (0.5 * chem_weight * s_hs.astype(np.float64) + (1.0 - chem_weight) * s_v.astype(np.float64)) / 255.0
+
+
+def step_fast(library, patches, chem_weight, threads):
+    """Multi-core integer form of the step (oracle_step_fast in liboracle_omp.so); bench.py's second CPU figure only."""
+    _omp = _omp_lib()
     library = _u8(library)
     patches = _u8(patches)
     F, h, w, _ = library.shape

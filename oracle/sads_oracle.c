@@ -166,6 +166,46 @@ void oracle_int_sums(const uint8_t *library, int64_t F, int h, int w,
  */
 #ifdef ORACLE_WITH_OPENMP
 #include <omp.h>
+
+/*
+ * Dense check of a full-size SYNTHETIC library (tests/test_gpu_parity.py:test_dense_oracle_at_config_two): the integer sums
+ * of oracle_int_sums (util.pyx:48-56,69) for ONE scene against views [first, first + F) of the build's own synthetic
+ * library, each view regenerated on the fly from (seed, view index) -- the counter hash of navsim_amd/synth.py:synth_views
+ * (splitmix64 finaliser; the build's generator, no reference code) -- so that the 24.6 GB of a 500 000-view library of
+ * 128x128 sensors never exist in host memory.  tests/test_oracle_golden.py pins it to oracle_int_sums on synth_views output.
+ */
+static inline uint64_t synth_mix(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int oracle_synth_int_sums(uint64_t seed, int64_t first, int64_t F, int h, int w, int full_range_s,
+                          const uint8_t *scene, int threads, int64_t *s_hs, int64_t *s_v)
+{
+    static const int levels[5] = {0, 63, 127, 191, 255};
+    const int64_t npx = (int64_t)h * (int64_t)w;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int64_t f = 0; f < F; ++f) {
+        const uint64_t base = (uint64_t)(first + f) * (uint64_t)npx + seed * 0x9E3779B97F4A7C15ull;
+        int64_t hs = 0, v = 0;
+        for (int64_t p = 0; p < npx; ++p) {
+            const uint64_t z = synth_mix(base + (uint64_t)p);
+            const int V = levels[((z & 0xFFFFull) * 5ull) >> 16];
+            const int H = (int)((z >> 16) & 1ull) * 127;
+            const int S = full_range_s ? (int)((z >> 17) & 0x7Full) : (int)((z >> 17) & 1ull) * 127;
+            const int64_t o = p * 3;
+            hs += ((int)scene[o] == H) ? abs((int)scene[o + 1] - S) : (int)scene[o + 1] + S;
+            v += abs((int)scene[o + 2] - V);
+        }
+        s_hs[f] = hs;
+        s_v[f] = v;
+    }
+    return threads;
+}
+
 int oracle_step_fast(const uint8_t *library, int64_t F, int h, int w, const uint8_t *patches, int A,
                      double cw, int threads, double *angle_fam, int64_t *best_view, int32_t *best_heading)
 {

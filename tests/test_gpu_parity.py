@@ -288,8 +288,12 @@ def test_errors(eng):
     with pytest.raises(ValueError):
         eng.set_library(lib[..., :2], 0.0)
     eng.set_library(lib, 0.0)
-    with pytest.raises(ValueError):
-        eng.step(np.zeros((65, 4, 4, 3), dtype=np.uint8))
+    r = eng.step(np.zeros((65, 4, 4, 3), dtype=np.uint8))          # more than one library pass: the wide step (round 4)
+    assert r["n_passes"] == 2 and r["best_idex"] == 0
+    import ctypes
+    from navsim_amd import _native as N
+    big = np.zeros((65, 4, 4, 3), dtype=np.uint8)                     # dv_step itself still holds DV_MAX_HEADINGS at most
+    assert eng._lib.dv_step(eng._ctx, N.u8ptr(big), 65, 0, ctypes.byref(N.StepResult()), None) == -1
     with pytest.raises(ValueError):
         eng.step(np.zeros((2, 5, 4, 3), dtype=np.uint8))
     eng.clear_library()

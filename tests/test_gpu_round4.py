@@ -1,0 +1,491 @@
+"""GPU parity tests added in round 4: the dense full-library check at BASELINE configs[2], steps of more than 64 headings,
+the SSD familiarity plug-in behind the agent, ssd_f32 at configs[2]'s literal float32 size, the clean-up paths of the SSD
+ingests and the kernel knobs a context reads at creation.  Everything calls libdejavu_hip.so through navsim_amd (ctypes);
+the oracle (oracle/) is the checker only; nothing reads /root/reference.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import navsim_amd
+from navsim_amd import synth
+from navsim_amd import _native as N
+from oracle import oracle
+from tests.helpers import ENGINE_MODES, engine_mode
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _engine(env=None):
+    """An engine created under `env` (the context reads its knobs when it is created); the environment is put back."""
+    env = env or {}
+    before = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return navsim_amd.FamiliarityEngine(0)
+    finally:
+        for k, v in before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# ------------------------------------------------------------------ dense check at the size the headline is quoted on
+def _dense_fam(seed, F, h, w, cw, patch, full_range_s=False):
+    s_hs, s_v = oracle.synth_int_sums(seed, 0, F, h, w, patch, full_range_s=full_range_s)
+    return oracle.fam_from_sums(s_hs, s_v, h * w, cw)
+
+
+def test_dense_oracle_at_config_two():
+    """BASELINE configs[2] (128x128 sensor, 500 000 views, 32 headings), EVERY view against the oracle.
+
+    The sampled checks of test_large_library_properties see ~130 of the 500 000 views; the machinery that only exists at
+    this size (7.63 view-group ranges per workgroup, loaders running through item boundaries, the partial eighth round, the
+    accumulators changing hands at the segment boundary) deserves all of them.  The oracle's integer sums (util.pyx:48-56,69)
+    are computed for every view of the synthetic library, each view regenerated inside the C loop (oracle_synth_int_sums,
+    pinned to oracle_int_sums by tests/test_oracle_golden.py); fam = P - (0.5 cw S_hs + (1 - cw) S_v) / 255 is within 1e-12
+    of the reference's sequential doubles, and one unit of either sum moves a score by >= 5e-4, so rtol 1e-9 on ~16 000 is
+    a bit-level check of the sums.
+
+    (a) one-heading steps with want_scene: scene_familiarity[f] = fam[0, f] for ALL f -- an on-level patch (fp4 body of the
+        matrix-core kernel, unfused epilogue + k_finish) and an off-level one (its int8 body in the same launch);
+    (b) the step as it ships (32 headings, fused epilogue, k_fold): three headings' maxima and first maximisers against the
+        dense oracle's max / first argmax over all 500 000 views;
+    (c) the mixed layout (saturation 0..127 kept as byte planes, value bits on the matrix cores): one heading, all views."""
+    if not oracle.have_omp():
+        pytest.skip("oracle/liboracle_omp.so is not built")
+    F, h, w, A, seed, cw = 500000, 128, 128, 32, 777, 0.25
+    eng = navsim_amd.FamiliarityEngine(device=0)
+    try:
+        eng.generate_library(seed, F, h, w, cw)
+        patches = synth.synth_patches(seed, A, h, w)
+        patches[30] = synth.near_match_patch(synth.synth_views(seed, 1, h, w, first_view=3)[0], 130, fraction=0.01)
+        # (a) on-level patch: all 500 000 scores
+        r = eng.step(patches[7:8], want_scene=True)
+        form = eng.scoring_form()
+        assert form["matrix_cores"] and form["fp4"] and not form["fused_finish"], form
+        want = _dense_fam(seed, F, h, w, cw, patches[7])
+        np.testing.assert_allclose(r["scene_familiarity"], want, rtol=RTOL)
+        assert r["angle_view"][0] == int(np.argmax(want)) and r["best_view"] == int(np.argmax(want))
+        # ... and an off-level patch (bytes strictly inside the library's gaps): the int8 body of the same kernel
+        off = patches[7].copy()
+        off[::3, ::5, 2] = 100                                       # between the levels 63 and 127
+        off[1::4, 2::7, 1] = 50                                      # between the saturations 0 and 127
+        r = eng.step(off[None], want_scene=True)
+        form = eng.scoring_form()
+        assert form["matrix_cores"] and not form["fp4"], form
+        want = _dense_fam(seed, F, h, w, cw, off)
+        np.testing.assert_allclose(r["scene_familiarity"], want, rtol=RTOL)
+        assert r["angle_view"][0] == int(np.argmax(want))
+        # (b) the shipped step: fused epilogue + k_fold, 32 headings; three of them against every view
+        r = eng.step(patches, want_scene=False)
+        form = eng.scoring_form()
+        assert form["matrix_cores"] and form["fp4"] and form["fused_finish"], form
+        assert r["best_idex"] == 30 and r["best_view"] == 3
+        for a in (0, 13, 30):
+            want = _dense_fam(seed, F, h, w, cw, patches[a])
+            np.testing.assert_allclose(r["angle_familiarity"][a], want.max(), rtol=RTOL)
+            assert r["angle_view"][a] == int(np.argmax(want)), a
+        # (c) mixed layout
+        eng.generate_library(seed, F, h, w, cw, full_range_s=True)
+        assert eng.library_info()["mixed_layout"]
+        pm = synth.synth_patches(seed, 2, h, w, full_range_s=True)
+        r = eng.step(pm[1:2], want_scene=True)
+        want = _dense_fam(seed, F, h, w, cw, pm[1], full_range_s=True)
+        np.testing.assert_allclose(r["scene_familiarity"], want, rtol=RTOL)
+        assert r["angle_view"][0] == int(np.argmax(want))
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------ more than 64 headings
+@pytest.fixture(scope="module", params=ENGINE_MODES)
+def eng(request):
+    with engine_mode(request.param):
+        e = navsim_amd.FamiliarityEngine(device=0)
+    e.mode = request.param
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("A,F,h,w,cw", [(65, 700, 8, 8, 0.0), (90, 3000, 8, 8, 0.25), (130, 257, 9, 7, 1.0), (200, 3000, 16, 16, 0.4)])
+def test_wide_steps_match_the_reference(eng, A, F, h, w, cw):
+    """The reference takes any n_test_angles (NavBySceneFamiliarity.py:62,87-88; loop :289, argmax :315): steps of more than
+    DV_MAX_HEADINGS headings run as ceil(A / 64) library passes merged inside the library.  Small five-level sensors make
+    equal integer sums with ulp-different doubles common, so the passes' near-ties go through the exact
+    resolver; exact duplicates across passes must go to the first heading."""
+    lib = synth.synth_views(91, F, h, w)
+    patches = synth.synth_patches(91, A, h, w)
+    eng.set_library(lib, cw)
+    cases = []
+    cases.append(("random", patches.copy()))
+    p = patches.copy()
+    p[A - 3] = lib[F // 3]                                          # an exact copy in the LAST pass: the strict winner
+    cases.append(("winner in the last pass", p))
+    p = patches.copy()
+    p[A - 2] = lib[F // 2]
+    p[5] = lib[F // 5]                                              # exact copies in the first and the last pass: both score h*w
+    cases.append(("exact tie across passes", p))
+    p = patches.copy()
+    p[70 % A] = p[3]                                                # the same patch twice, one per pass
+    p[64] = p[0]
+    cases.append(("duplicate headings", p))
+    for name, pats in cases:
+        want = oracle.step(lib, pats, cw)
+        got = eng.step(pats, want_scene=True)
+        assert got["n_passes"] == (A + 63) // 64
+        assert got["best_idex"] == want["best_idex"], (name, got["best_idex"], want["best_idex"], got["n_contending"])
+        assert got["best_view"] == want["best_view"], name
+        np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+        np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=RTOL)
+        np.testing.assert_allclose(got["step_familiarity"], want["step_familiarity"], rtol=RTOL)
+        fast = eng.step(pats, want_scene=False)                      # the passes enqueued back to back
+        assert (fast["best_idex"], fast["best_view"]) == (want["best_idex"], want["best_view"]), name
+        np.testing.assert_allclose(fast["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+        forced = eng.step(pats, want_scene=False, force_resolve=True)
+        assert forced["best_idex"] == want["best_idex"] and forced["step_familiarity"] == want["step_familiarity"], name
+
+
+def test_wide_step_on_the_tie_stress_fixture(manifest):
+    """The golden tie-stress library (8x8 five-level views, 20 000 of them: hundreds of equal integer sums with different
+    doubles) with its 8 patches repeated over 72 headings in a rotated order: every pass holds every patch, so the maximum is
+    attained in both passes and the first heading must win on exact values."""
+    from tests.helpers import step_case_inputs
+    case = [c for c in manifest["t2_step"] if c["name"].startswith("s_ties")][0]
+    lib, patches = step_case_inputs(case)
+    A0 = patches.shape[0]
+    order = [(3 * i + 1) % A0 for i in range(72)]
+    pats = np.ascontiguousarray(patches[order])
+    want = oracle.step(lib, pats, case["chem_weight"])
+    for env in ({}, {"DEJAVU_SHAPE": "6", "DEJAVU_BITS": "2"}):
+        e = _engine(env)
+        try:
+            e.set_library(lib, case["chem_weight"])
+            got = e.step(pats, want_scene=False)
+            assert got["best_idex"] == want["best_idex"] and got["best_view"] == want["best_view"]
+            assert got["n_contending"] == 2
+            assert got["step_familiarity"] == want["step_familiarity"]         # exact after the forced resolve
+        finally:
+            e.close()
+
+
+def test_agent_with_ninety_test_angles():
+    """NavBySceneFamiliarity(n_test_angles=90) -- more than one library pass per step -- walks the trajectory of the same agent
+    scored by the oracle plug-in with the host sensor model (the reference's loop, one model call per heading)."""
+    land = synth.synth_landscape(8, 400, 4)
+    path = synth.sin_training_path(0.5, 60, 260, arclen=1.0)[:200]
+    kw = dict(n_test_angles=90, n_sensor_levels=5, saccade_degrees=180.)
+    dev = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, familiarity_model=navsim_amd.sads_familiarity(0.25),
+                                           track_scene_familiarity=False, **kw)
+    ref = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, familiarity_model=oracle.sads_familiarity(0.25),
+                                           use_gpu_sensor=False, **kw)
+    for nsf in (dev, ref):
+        nsf.train_from_path(path)
+        nsf.position, nsf.angle = (path[2][0] + 0.6, path[2][1] - 0.3), 0.8
+    assert np.array_equal(dev.familiar_scenes, ref.familiar_scenes)
+    for t in range(40):
+        dev.step_forward(fake=True)
+        ref.step_forward(fake=True)
+        assert dev.last_best_idex == ref.last_best_idex, t
+        assert dev.position == ref.position and dev.angle == ref.angle, t
+        np.testing.assert_allclose(dev.angle_familiarity, ref.angle_familiarity, rtol=RTOL)
+    dev.track_scene_familiarity = True                               # and the per-view minimum over all 90 headings
+    dev.step_forward(fake=True)
+    ref.step_forward(fake=True)
+    np.testing.assert_allclose(dev.scene_familiarity, ref.scene_familiarity, rtol=RTOL)
+    dev.clear_training()
+
+
+def test_wide_step_errors(eng):
+    lib = synth.synth_views(3, 100, 8, 8)
+    eng.set_library(lib, 0.0)
+    with pytest.raises(ValueError):
+        eng.step(np.zeros((N.DV_MAX_WIDE_HEADINGS + 1, 8, 8, 3), dtype=np.uint8))
+    r = eng.step(np.repeat(lib[17:18], 64 * 3, axis=0), want_scene=False)      # 192 identical headings: the first wins
+    assert (r["best_idex"], r["best_view"], r["n_passes"]) == (0, 17, 3)
+
+
+# ------------------------------------------------------------------ SSD as the agent's familiarity plug-in
+def _host_ssd_model(channel):
+    """The reference-shaped plug-in with `ssds` (navsim/util.pyx:171-184) as its metric, on the host: the checker of the device
+    plug-in.  uint8 differences squared and summed in float64 are exact integers, so NumPy's sum IS oracle.ssds' value (spot
+    checks below call oracle.ssds itself, which tests/test_oracle_golden.py pins to the reference's)."""
+    def model(scenes):
+        planes = scenes[..., channel].astype(np.float64)
+
+        def func(scene, fambuf):
+            d = planes - scene[..., channel].astype(np.float64)
+            fambuf[:] = -(d * d).sum(axis=(1, 2))
+        func.max_familiarity = 0.0
+        return func
+    return model
+
+
+@pytest.mark.parametrize("channel", [2, 1])
+def test_ssd_plugin_pairs_against_the_reference_ssds(channel):
+    """ssd_familiarity(channel)(scenes) -> func(scene, fambuf): the reference's two-stage plug-in shape (util.pyx:10-25) with the
+    north star's literal metric; every pair is the exact integer oracle.ssds returns."""
+    rng = np.random.default_rng(12)
+    scenes = rng.integers(0, 256, (300, 12, 20, 3), dtype=np.uint8)
+    func = navsim_amd.ssd_familiarity(channel)(scenes)
+    assert func.max_familiarity == 0.0 and func.metric == "ssd_u8" and func.channel == channel
+    scene = rng.integers(0, 256, (12, 20, 3), dtype=np.uint8)
+    scene[3:9] = scenes[77, 3:9]
+    fam = np.full(300, np.nan)
+    func(scene, fam)
+    for f in (0, 77, 150, 299):
+        assert fam[f] == -oracle.ssds(scene[..., channel].astype(np.float64), scenes[f, ..., channel].astype(np.float64))
+    want = np.empty(300)
+    _host_ssd_model(channel)(scenes)(scene, want)
+    assert np.array_equal(fam, want)
+    with pytest.raises(ValueError):
+        func(scene, np.empty(300, dtype=np.float32))                 # "Buffer dtype mismatch", like the reference's kernel
+    with pytest.raises(ValueError):
+        navsim_amd.ssd_familiarity(channel)(scenes.astype(np.int16))
+    func.engine.close()
+    # float32 scenes take the ssd_f32 metric: within 1e-6 relative of ssds on the upcast data
+    fs = rng.random((200, 12, 20), dtype=np.float32)
+    func = navsim_amd.ssd_familiarity(channel)(fs)
+    assert func.metric == "ssd_f32"
+    q = (fs[40] + 0.01 * rng.random((12, 20), dtype=np.float32)).astype(np.float32)
+    fam = np.empty(200)
+    func(q, fam)
+    want = np.array([-oracle.ssds(q.astype(np.float64), v.astype(np.float64)) for v in fs])
+    np.testing.assert_allclose(fam, want, rtol=1e-6)
+    assert int(np.argmax(fam)) == 40
+    func.engine.close()
+
+
+def test_agent_with_the_ssd_plugin_walks_the_host_loops_trajectory():
+    """step_forward with ssd_familiarity: sense -> score (int8 matrix cores) -> decide on the device (dv_sense_step_u8),
+    against the same agent running the reference's loop -- one `func(scene, fambuf)` call per heading, host sensor model,
+    host SSD -- over 250 steps: heading index, pose and every per-heading familiarity equal (the SSDs are exact integers)."""
+    land = synth.synth_landscape(5, 500, 4)
+    path = synth.sin_training_path(0.5, 60, 380, arclen=1.0)[:330]
+    kw = dict(n_test_angles=12, n_sensor_levels=256, saccade_degrees=120.)
+    dev = navsim_amd.NavBySceneFamiliarity(land, (32, 32), 1.0, familiarity_model=navsim_amd.ssd_familiarity(2), **kw)
+    ref = navsim_amd.NavBySceneFamiliarity(land, (32, 32), 1.0, familiarity_model=_host_ssd_model(2), use_gpu_sensor=False, **kw)
+    for nsf in (dev, ref):
+        nsf.train_from_path(path)
+        nsf.position, nsf.angle = (path[3][0] + 0.7, path[3][1] - 0.4), 0.9
+    assert dev._familiarity_func.metric == "ssd_u8" and dev._familiarity_func.engine is dev._engine
+    assert np.array_equal(dev.familiar_scenes, ref.familiar_scenes)
+    for t in range(250):
+        dev.step_forward(fake=(t % 2 == 0))
+        ref.step_forward(fake=(t % 2 == 0))
+        assert dev.last_best_idex == ref.last_best_idex, t
+        assert dev.position == ref.position and dev.angle == ref.angle, t
+        assert np.array_equal(dev.angle_familiarity, ref.angle_familiarity), t
+        assert np.array_equal(dev.scene_familiarity, ref.scene_familiarity), t
+    assert dev.navigation_error == ref.navigation_error
+    assert dev.percent_recapitulated == ref.percent_recapitulated
+    # off the landscape: the reference's stop exception, raised before anything is sensed
+    dev.position = (3.0, 3.0)
+    with pytest.raises(navsim_amd.OutOfLandscapeBoundsException):
+        dev.step_forward()
+    # a second training path: the SSD library is ingested again with the new views
+    more = synth.sin_training_path(0.3, 80, 200, arclen=1.0)[:90]
+    dev.train_additional_path(more)
+    ref.train_additional_path(more)
+    dev.position = ref.position = (more[5][0] + 0.3, more[5][1])
+    dev.angle = ref.angle = 0.7
+    dev.step_forward(fake=True)
+    ref.step_forward(fake=True)
+    assert dev.last_best_idex == ref.last_best_idex and np.array_equal(dev.angle_familiarity, ref.angle_familiarity)
+    dev.clear_training()
+
+
+def test_ssd_plugin_with_the_host_sensor_model():
+    """The same plug-in under an agent that senses on the host (use_gpu_sensor=False): patches are uploaded, the step is
+    step_u8 -- still one device step per step_forward."""
+    land = synth.synth_landscape(6, 300, 4)
+    path = synth.sin_training_path(0.5, 60, 180, arclen=1.0)[:120]
+    kw = dict(n_test_angles=9, n_sensor_levels=5, use_gpu_sensor=False)
+    dev = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, familiarity_model=navsim_amd.ssd_familiarity(2), **kw)
+    ref = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, familiarity_model=_host_ssd_model(2), **kw)
+    for nsf in (dev, ref):
+        nsf.train_from_path(path)
+        nsf.position, nsf.angle = (path[3][0] + 0.7, path[3][1] - 0.4), 0.9
+    for t in range(30):
+        dev.step_forward(fake=True)
+        ref.step_forward(fake=True)
+        assert dev.last_best_idex == ref.last_best_idex and dev.position == ref.position, t
+        assert np.array_equal(dev.angle_familiarity, ref.angle_familiarity)
+    dev.clear_training()
+
+
+# ------------------------------------------------------------------ clean-up paths and small fixes of the round-3 review
+@pytest.mark.parametrize("metric,n_allocs", [("u8", 6), ("f32", 5)])
+def test_allocation_failure_leaves_no_library(metric, n_allocs):
+    """A failed allocation inside an SSD ingest must not leave a half-built library behind (the step calls would launch kernels
+    on null pointers): every allocation of the ingest is failed in turn (DEJAVU_TEST_FAIL_ALLOC), the call reports
+    DV_ERR_OOM, the step answers DV_ERR_STATE, and the same context takes the library afterwards."""
+    rng = np.random.default_rng(2)
+    if metric == "u8":
+        views = rng.integers(0, 256, (200, 10, 12), dtype=np.uint8)
+        pats = rng.integers(0, 256, (4, 10, 12), dtype=np.uint8)
+    else:
+        views = rng.random((200, 10, 12), dtype=np.float32)
+        pats = rng.random((4, 10, 12), dtype=np.float32)
+    for k in range(1, n_allocs + 1):
+        e = _engine({"DEJAVU_TEST_FAIL_ALLOC": str(k)})
+        try:
+            with pytest.raises(navsim_amd.EngineError, match="DV_ERR_OOM"):
+                (e.set_library_u8 if metric == "u8" else e.set_library_f32)(views)
+            res = N.StepResult()                                     # (the C calls themselves: the Python face has no shape to check against)
+            if metric == "u8":
+                rc = e._lib.dv_step_u8(e._ctx, N.u8ptr(pats), 4, 0, ctypes.byref(res), None)
+            else:
+                rc = e._lib.dv_step_f32(e._ctx, pats.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 4, 0, ctypes.byref(res), None)
+            assert rc == -3, rc                                      # DV_ERR_STATE: no library
+            assert e._lib.dv_get_library_info(e._ctx, ctypes.byref(N.LibInfo())) == -3
+        finally:
+            e.close()
+    e = _engine({"DEJAVU_TEST_FAIL_ALLOC": str(n_allocs + 1)})      # past the ingest's allocations: nothing fails
+    try:
+        (e.set_library_u8 if metric == "u8" else e.set_library_f32)(views)
+        r = (e.step_u8 if metric == "u8" else e.step_f32)(pats)
+        assert 0 <= r["best_idex"] < 4
+    finally:
+        e.close()
+
+
+def test_resolve_after_an_ssd_u8_step_is_a_no_op():
+    """dv_resolve on an ssd_u8 step (every score exact already) must not reach the sads_hsv resolver, whose tiles do not exist."""
+    rng = np.random.default_rng(4)
+    views = rng.integers(0, 256, (300, 20, 24), dtype=np.uint8)
+    views[200] = views[10]
+    pats = rng.integers(0, 256, (5, 20, 24), dtype=np.uint8)
+    pats[3] = views[10]
+    e = navsim_amd.FamiliarityEngine(0)
+    try:
+        e.set_library_u8(views)
+        r = e.step_u8(pats)
+        assert (r["best_idex"], r["best_view"], r["step_ssd"]) == (3, 10, 0.0)
+        r2 = e.resolve()
+        assert (r2["best_idex"], r2["best_view"]) == (3, 10)
+        r3 = e.step_u8(pats)                                         # and the engine is fine afterwards
+        assert (r3["best_idex"], r3["best_view"]) == (3, 10)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("env", [{"DEJAVU_LC": "0"}, {"DEJAVU_LC": "2"}, {"DEJAVU_HT": "1"}, {"DEJAVU_MIXED": "0"},
+                                 {"DEJAVU_LC": "0", "DEJAVU_RING": "1"}, {"DEJAVU_LC": "0", "DEJAVU_RING": "2"}, {"DEJAVU_TUNE_ALL": "1"}])
+def test_body_knobs_are_read_per_context(env):
+    """DEJAVU_LC / DEJAVU_HT / DEJAVU_RING / DEJAVU_MIXED select kernel bodies; they are fields of the context read at
+    dv_create (they used to be process-wide statics: a second engine silently ignored a changed value).  Each body on a small
+    library with 33..64 resident headings (two heading tiles) and with 13, against the oracle and against the default body."""
+    F, h, w, cw = 7000 + 19, 16, 12, 0.25
+    full = env.get("DEJAVU_MIXED") is not None
+    lib = synth.synth_views(71, F, h, w, full_range_s=full)
+    base = {"DEJAVU_SHAPE": "6", "DEJAVU_BITS": "2", "DEJAVU_MFMA_CHUNK": "1"}     # one K chunk: the loader / consumer body even at this size
+    e_def = _engine(base)
+    e_knob = _engine(dict(base, **env))
+    try:
+        for e in (e_def, e_knob):
+            e.set_library(lib, cw)
+        if full:
+            assert e_def.library_info()["mixed_layout"] and not e_knob.library_info()["mixed_layout"]
+        for A in (13, 40, 64):
+            pats = synth.synth_patches(200 + A, A, h, w, full_range_s=full)
+            pats[A // 2] = synth.near_match_patch(lib[(A * 131) % F], A, fraction=0.03)
+            want = oracle.step(lib, pats, cw)
+            for e in (e_def, e_knob):
+                for it in range(3):
+                    got = e.step(pats, want_scene=(it == 1))
+                    assert (got["best_idex"], got["best_view"]) == (want["best_idex"], want["best_view"]), (env, A)
+                    np.testing.assert_allclose(got["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+                    if it == 1:
+                        np.testing.assert_allclose(got["scene_familiarity"], want["scene_familiarity"], rtol=RTOL)
+    finally:
+        e_def.close()
+        e_knob.close()
+
+
+def test_fenced_ticket_is_the_default_on_long_passes():
+    """The release / acquire pair around k_finish's arrival ticket is the default wherever the scoring pass is long (>= 200 us
+    estimated): the byte path and the mixed layout at large sizes.  Checked through the decisions of both forms on a library
+    large enough to take the fenced default (duplicated best views in far-apart blocks), and DEJAVU_FENCED still overrides."""
+    F, h, w, A, cw = 120000, 32, 32, 16, 0.25                        # byte tiles 246 MB -> fenced by default; bit tiles 92 MB
+    seen = {}
+    for name, env in (("default bytes", {"DEJAVU_BITS": "0", "DEJAVU_FINISH": "2"}),
+                      ("unfenced bytes", {"DEJAVU_BITS": "0", "DEJAVU_FINISH": "2", "DEJAVU_FENCED": "0"})):
+        e = _engine(env)
+        try:
+            e.generate_library(31, F, h, w, cw)
+            pats = synth.synth_patches(31, A, h, w)
+            pats[9] = synth.near_match_patch(synth.synth_views(31, 1, h, w, first_view=119999)[0], 4, fraction=0.02)
+            for _ in range(5):
+                r = e.step(pats, want_scene=True)
+                assert (r["best_idex"], r["best_view"]) == (9, 119999), name
+            seen[name] = (np.array(r["angle_familiarity"]), np.array(r["scene_familiarity"]))
+        finally:
+            e.close()
+    assert np.array_equal(seen["default bytes"][0], seen["unfenced bytes"][0])
+    assert np.array_equal(seen["default bytes"][1], seen["unfenced bytes"][1])
+
+
+# ------------------------------------------------------------------ ssd_f32: device generator, configs[2] in its literal form
+def test_generated_f32_library_equals_uploaded():
+    F, h, w, A = 3000, 24, 20, 16
+    lib = synth.synth_views_f32(9, F, h, w, first_view=50)
+    rng = np.random.default_rng(1)
+    pats = rng.random((A, h, w), dtype=np.float32)
+    pats[6] = lib[1234] + np.float32(0.001) * rng.random((h, w), dtype=np.float32)
+    a, b = navsim_amd.FamiliarityEngine(0), navsim_amd.FamiliarityEngine(0)
+    try:
+        a.set_library_f32(lib, first_view=50)
+        b.generate_library_f32(9, F, h, w, first_view=50)
+        ra, rb = a.step_f32(pats, want_scene=True), b.step_f32(pats, want_scene=True)
+        assert (ra["best_idex"], ra["best_view"]) == (rb["best_idex"], rb["best_view"]) == (6, 50 + 1234)
+        assert np.array_equal(ra["angle_ssd"], rb["angle_ssd"]) and np.array_equal(ra["scene_ssd"], rb["scene_ssd"])
+    finally:
+        a.close()
+        b.close()
+
+
+def test_ssd_f32_at_config_two_literal_size():
+    """BASELINE configs[2] as BASELINE.json words it: 128x128 sensor, 500 000 stored views, 32 headings, fp32 -- 32.8 GB of
+    float32 views generated on the device -- through size-independent properties: planted near-copies in the first, a middle
+    and the last view group win at their headings, the closest wins the step; every reported minimum is the SSD of the
+    reported view to 1e-6 relative of oracle.ssds (util.pyx:171-184) on that view regenerated on the host; no view of a fixed
+    spread beats the reported minima; two half libraries reproduce the full library's minima and views."""
+    F, h, w, A, seed = 500000, 128, 128, 32, 4242
+    eng = navsim_amd.FamiliarityEngine(0)
+    try:
+        eng.generate_library_f32(seed, F, h, w)
+        rng = np.random.default_rng(7)
+        pats = rng.random((A, h, w), dtype=np.float32)
+        targets = {4: (499999, 0.02), 19: (250001, 0.01), 27: (3, 0.03)}
+        for a, (f, eps) in targets.items():
+            v = synth.synth_views_f32(seed, 1, h, w, first_view=f)[0]
+            pats[a] = v + np.float32(eps) * rng.random((h, w), dtype=np.float32)
+        r = eng.step_f32(pats)
+        for a, (f, _) in targets.items():
+            assert r["angle_view"][a] == f, (a, r["angle_view"][a])
+        assert r["best_idex"] == 19 and r["best_view"] == 250001
+        spread = np.unique(np.concatenate([np.arange(0, F, F // 61), np.asarray(r["angle_view"], dtype=np.int64)]))
+        views = {int(f): synth.synth_views_f32(seed, 1, h, w, first_view=int(f))[0].astype(np.float64) for f in spread}
+        for a in range(A):
+            pa = pats[a].astype(np.float64)
+            want = oracle.ssds(pa, views[int(r["angle_view"][a])])
+            np.testing.assert_allclose(r["angle_ssd"][a], want, rtol=1e-6)
+            if a % 8 == 3:
+                assert min(oracle.ssds(pa, v) for v in views.values()) >= want * (1 - 1e-6), a
+        full_min, full_view = np.array(r["angle_ssd"]), np.array(r["angle_view"])
+        halves = []
+        for lo, hi in ((0, F // 2), (F // 2, F)):
+            eng.generate_library_f32(seed, hi - lo, h, w, first_view=lo)
+            halves.append(eng.step_f32(pats))
+        merged = np.minimum(halves[0]["angle_ssd"], halves[1]["angle_ssd"])
+        assert np.array_equal(merged, full_min)
+        pick = np.where(halves[0]["angle_ssd"] <= halves[1]["angle_ssd"], halves[0]["angle_view"], halves[1]["angle_view"])
+        assert np.array_equal(pick, full_view)
+    finally:
+        eng.close()

@@ -9,6 +9,7 @@ reference's golden trajectories without a GPU.  The product default (HIP engine)
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -164,6 +165,46 @@ def test_c_abi_exports_every_declared_symbol():
     assert ctypes.sizeof(_native.StepResult) == 56 + 4 * 8 * 64
     # dv_last_error(NULL) is safe without a context
     assert isinstance(lib.dv_last_error(None), bytes)
+
+
+def test_shipped_scoring_kernels_use_no_scratch():
+    """No kernel of the built library keeps registers in scratch memory (read from the code object inside libdejavu_hip.so:
+    tools/kernel_resources.py) -- the matrix-core loop's hand-counted waits (inline-asm ds_read_b128 / LDS-DMA) are only right
+    while the compiler neither copies nor spills the registers involved.  Two instantiations are known to spill a few
+    item-level values and are never launched by default: the round-2 body with two view groups per wave in its fused form
+    (launch_mfma asks hipFuncGetAttributes and takes one view group per wave while it spills) and the two-heading-tile body on
+    3-bit code rows (DEJAVU_VCODE=1, an experiment's knob)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    rows = kernel_resources.kernel_table()
+    assert len(rows) > 100 and any(r["name"].startswith("k_sad_mfma_dual<") for r in rows)
+    guarded = {"k_sad_mfma_dual<1, 3, 2, 3, 2, true, 0, 3, false, 1>", "k_sad_mfma_dual<4, 2, 2, 4, 1, true, 4, 3, true, 2>"}
+    spilling = {r["name"]: r["scratch"] for r in rows if r.get("vgpr_spills", 0) > 0}
+    assert set(spilling) <= guarded, "kernels with spilled registers: %r" % (spilling,)
+    # scratch that is not a spill: the two exact fp64 kernels index a small private array of plane bytes (96 bytes per lane)
+    private = {r["name"] for r in rows if r["scratch"] > 0 and r.get("vgpr_spills", 0) == 0}
+    assert private <= {"k_exact_all", "k_resolve"}, private
+    for r in rows:                                                    # every step's fold, whatever its thread count
+        if r["name"].startswith("k_fold<"):
+            assert r["scratch"] == 0, r
+    # the loader / consumer body that ships (fused and unfused, one and two heading tiles) and the SSD matrix-core kernels
+    for name in ("k_sad_mfma_dual<4, 2, 2, 4, 1, true, 4, 3, false, 1>", "k_sad_mfma_dual<4, 2, 2, 4, 1, false, 4, 3, false, 1>",
+                 "k_sad_mfma_dual<4, 2, 2, 4, 1, true, 4, 3, false, 2>", "k_sad_mfma_dual<4, 2, 2, 4, 1, false, 4, 3, false, 2>",
+                 "k_ssd_u8_mfma<1>", "k_ssd_u8_mfma<2>"):
+        row = [r for r in rows if r["name"] == name]
+        assert row and row[0]["scratch"] == 0 and row[0]["vgpr"] <= 256, name
+
+
+def test_ssd_plugin_factory_arguments():
+    """ssd_familiarity(channel) checks its argument like the reference's factory checks chem_weight (util.pyx:12); the two
+    later stages need the GPU (tests/test_gpu_parity.py)."""
+    with pytest.raises(ValueError):
+        navsim_amd.ssd_familiarity(channel=3)
+    model = navsim_amd.ssd_familiarity(channel=1)
+    assert model.metric == "ssd" and model.channel == 1 and callable(model.make_engine) and callable(model.from_engine)
 
 
 def test_no_cpu_fallback_in_product(monkeypatch):

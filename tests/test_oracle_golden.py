@@ -62,3 +62,21 @@ def test_known_answers():
     # dtype errors surface as ValueError like the reference's buffer mismatch
     with pytest.raises(ValueError):
         oracle.sads_hsv(base.astype(np.float32), scene0, 0.0)
+
+
+def test_dense_synthetic_oracle_is_pinned_to_the_integer_sums():
+    """oracle_synth_int_sums (the full-size dense check of tests/test_gpu_parity.py regenerates every view inside its C loop)
+    gives exactly oracle_int_sums on the views navsim_amd.synth.synth_views makes -- both saturation flavours, a first_view
+    that is not zero, a sensor whose pixel count is not a multiple of anything."""
+    if not oracle.have_omp():
+        pytest.skip("oracle/liboracle_omp.so is not built")
+    from navsim_amd import synth
+    for full in (False, True):
+        for seed, first, F, h, w in ((5, 1000, 300, 9, 13), (777, 499990, 10, 128, 128)):
+            lib = synth.synth_views(seed, F, h, w, first_view=first, full_range_s=full)
+            scene = synth.synth_patches(seed, 1, h, w, full_range_s=full)[0]
+            want = oracle.int_sums(lib, scene)
+            got = oracle.synth_int_sums(seed, first, F, h, w, scene, full_range_s=full, threads=3)
+            assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+            fam = oracle.fam_from_sums(got[0], got[1], h * w, 0.25)
+            np.testing.assert_allclose(fam, oracle.sads_hsv(lib, scene, 0.25), rtol=1e-12)

@@ -1,29 +1,54 @@
 #!/usr/bin/env python3
-"""Register / scratch / occupancy table of every kernel in csrc/dejavu_hip.hip (hipcc -Rpass-analysis), to catch a
-change that costs a scoring kernel its occupancy or sends it to scratch.  usage: python tools/kernel_resources.py [filter]"""
-import os, re, subprocess, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "navigation-by-deja-vu_amd", "csrc")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c",
-                      "-Rpass-analysis=kernel-resource-usage", "dejavu_hip.hip", "-o", "/dev/null"], cwd=src,
-                     capture_output=True, text=True).stderr
-flt = sys.argv[1] if len(sys.argv) > 1 else ""
-cur = None
-rows = []
-for line in out.splitlines():
-    m = re.search(r"remark: (.*?) \[-Rpass", line)
-    if not m:
-        continue
-    t = m.group(1).strip()
-    if t.startswith("Function Name:"):
-        name = subprocess.run(["c++filt", t.split(": ", 1)[1]], capture_output=True, text=True).stdout.strip()
-        cur = {"name": re.sub(r"\(.*", "", name).replace("void dv::", "").replace("dv::", "")}
-        rows.append(cur)
-    elif cur is not None and ":" in t:
-        k, v = t.split(":", 1)
-        cur[k.strip()] = v.strip()
-print("%-44s %5s %5s %7s %5s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS"))
-for r in rows:
-    if flt in r["name"]:
-        print("%-44s %5s %5s %7s %5s %6s" % (r["name"][:44], r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"),
-                                             r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
+"""Register / scratch table of every kernel in the BUILT libdejavu_hip.so (what ships), read from the code object's
+metadata -- to catch a change that sends a scoring kernel to scratch or costs it its occupancy.
+
+    python tools/kernel_resources.py [filter]
+
+`kernel_table()` is what tests/test_host_logic.py:test_shipped_scoring_kernels_use_no_scratch checks (no compile: the
+gfx950 code object is unbundled from the library's .hip_fatbin section and its notes are parsed)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "navigation-by-deja-vu_amd", "csrc", "libdejavu_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_table(lib=LIB):
+    """[{name, vgpr, sgpr, scratch (bytes per lane), vgpr_spills, lds}] of the gfx950 kernels in `lib`."""
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co], check=True)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
+                               text=True).stdout
+    # amdhsa.kernels: one entry per kernel, opened by "  - .agpr_count:"; the fields wanted sit at the entry's own indent
+    rows, cur = [], None
+    keys = {".private_segment_fixed_size": "scratch", ".vgpr_count": "vgpr", ".sgpr_count": "sgpr",
+            ".vgpr_spill_count": "vgpr_spills", ".group_segment_fixed_size": "lds", ".name": "mangled"}
+    for line in notes.splitlines():
+        if re.match(r"\s{2}- \.agpr_count:", line):
+            cur = {}
+            rows.append(cur)
+            continue
+        m = re.match(r"\s{4}(\.[a-z_]+):\s*(\S+)\s*$", line)
+        if m and cur is not None and m.group(1) in keys:
+            k, v = keys[m.group(1)], m.group(2)
+            cur[k] = v if k == "mangled" else int(v)
+    rows = [r for r in rows if "mangled" in r and "scratch" in r]
+    names = subprocess.run(["c++filt"] + [r["mangled"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+    for r, n in zip(rows, names):
+        r["name"] = re.sub(r"\(.*", "", n).replace("void dv::", "").replace("dv::", "")
+    return rows
+
+
+if __name__ == "__main__":
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    print("%-60s %5s %5s %7s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "LDS"))
+    for r in kernel_table():
+        if flt in r["name"]:
+            print("%-60s %5s %5s %7s %6s" % (r["name"][:60], r.get("vgpr"), r.get("sgpr"), r.get("scratch"), r.get("lds")))
