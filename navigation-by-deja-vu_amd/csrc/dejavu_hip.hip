@@ -97,6 +97,12 @@ struct dv_ctx {
     float* d_fraw = nullptr;                  // [64][P] raw float patches
     float* d_fprep = nullptr;                 // [Q][4][64]
     double* d_fpart = nullptr;                // [nchunk][64][Fpad]
+    float4* d_fprep4 = nullptr;               // ssd_f32 on the matrix cores: [Q][APAD] float4 patch rows (k_prep_f32x)
+    double* d_fvnorm = nullptr;               // [Fpad] sum of squares of each view (k_norm_f32, at ingest)
+    double* d_fpnorm = nullptr;               // [64] ... of each heading's patch
+    int ssd_mfma_env = 1;                     // DEJAVU_SSD_MFMA=0: ssd_f32 steps keep the direct form (k_ssd_tiles) throughout
+    bool f32x_request = false;                // enqueue_step: this ssd_f32 pass may take the cross-term form (no per-view output wanted)
+    bool f32x_used = false;                   // ... and did: the step ends in k_cand_f32x + k_resolve_f32 + k_decide
     uint4* d_u8tiles = nullptr;               // ssd_u8 library: [Fpad/32][K][64] (k_retile_u8), K = ceil(P / 32) K-steps
     unsigned char* d_u8raw = nullptr;         // [64][P] raw uint8 patches
     uint4* d_u8prep = nullptr;                // [2][K][64] operand rows of the two passes of 32 headings
@@ -252,7 +258,7 @@ static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_acc); F(c->d_one); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
-    F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart);
+    F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart); F(c->d_fprep4); F(c->d_fvnorm); F(c->d_fpnorm);
     F(c->d_u8tiles); F(c->d_u8raw); F(c->d_u8prep); F(c->d_u8part); F(c->d_vnorm); F(c->d_pnorm);
     F(c->d_btiles); F(c->d_coef); F(c->d_coef4); F(c->d_ctiles); c->ctile_bytes = 0;
     c->pbits = PrepBits{};
@@ -314,6 +320,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_RING", c->ring_env, 0, 2);
     env_int("DEJAVU_MIXED", c->mixed_env, 0, 1);
     env_int("DEJAVU_TUNE_ALL", c->tune_all_env, 0, 1);
+    env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 1);
     env_int("DEJAVU_TEST_FAIL_ALLOC", c->fail_alloc_env, 0, 64);
     *out = c;
     return DV_OK;
@@ -893,6 +900,9 @@ static int alloc_f32_buffers(dv_ctx* c) {
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fraw, (size_t)kMaxHeadings * g.P * sizeof(float));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fprep, (size_t)g.Q * 4 * kMaxHeadings * sizeof(float));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fpart, (size_t)c->nchunk_cap * kMaxHeadings * g.Fpad * sizeof(double));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_fprep4, (size_t)g.Q * kMaxHeadings * sizeof(float4));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_fvnorm, (size_t)g.Fpad * sizeof(double));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_fpnorm, (size_t)kMaxHeadings * sizeof(double));
     if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 buffers");
     return DV_OK;
 }
@@ -944,6 +954,7 @@ extern "C" int dv_set_library_f32(dv_ctx* c, const float* views, int64_t F, int 
     if (e == hipSuccess) {
         const long long total = (g.Fpad / 64) * (long long)g.Q * 64;
         hipLaunchKernelGGL(k_retile_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_raw, c->d_ftiles, c->cfg);
+        hipLaunchKernelGGL(k_norm_f32, dim3((unsigned)(g.Fpad / 64)), dim3(64), 0, c->stream, c->d_ftiles, c->d_fvnorm, c->cfg);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -962,6 +973,7 @@ extern "C" int dv_generate_library_f32(dv_ctx* c, uint64_t seed, int64_t F, int 
     const long long total = (c->cfg.Fpad / 64) * (long long)c->cfg.Q * 64;
     hipLaunchKernelGGL(k_generate_tiles_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_ftiles, c->cfg,
                        (unsigned long long)seed);
+    hipLaunchKernelGGL(k_norm_f32, dim3((unsigned)(c->cfg.Fpad / 64)), dim3(64), 0, c->stream, c->d_ftiles, c->d_fvnorm, c->cfg);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 generator");
@@ -979,6 +991,11 @@ static int upload_patches_f32(dv_ctx* c, const float* patches, int A) {
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
     const long long total = (long long)c->cfg.Q * 4 * c->APAD;
     hipLaunchKernelGGL(k_prep_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep, c->cfg, A, c->APAD);
+    if (c->ssd_mfma_env) {                                            // the matrix-core form's operand rows and patch norms
+        const long long t4 = (long long)c->cfg.Q * c->APAD;
+        hipLaunchKernelGGL(k_prep_f32x, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep4, c->cfg, A, c->APAD);
+        hipLaunchKernelGGL(k_pnorm_f32, dim3((unsigned)A), dim3(256), 0, c->stream, c->d_fraw, c->d_fpnorm, c->cfg);
+    }
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
@@ -2007,6 +2024,24 @@ static int launch_scoring(dv_ctx* c, bool with_combine = true) {
                                c->d_ftiles, c->d_fraw, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->A, c->n_agents);
             HIP_TRY(c, hipGetLastError());
             n_partial = (int)(g.Fpad / 64);
+        } else if (c->f32x_request && c->ssd_mfma_env) {
+            // The cross-term form on the matrix cores (k_ssd_f32_mfma): 32 headings per pass over the library (16 when no more are
+            // resident), items = (pixel chunk, view group) on single-wave workgroups as many as are resident at once.
+            auto launch = [&](auto kern, int hb, int a_off) {
+                dim3 block;
+                const dim3 grid = scoring_grid(c, resident_waves_per_cu((const void*)kern), block);
+                hipLaunchKernelGGL(kern, grid, block, 0, c->stream, c->d_ftiles, c->d_fprep4, c->d_fpart, c->cfg, c->nchunk, c->APAD, a_off);
+                (void)hb;
+            };
+            if (c->APAD <= 16) launch(k_ssd_f32_mfma<16>, 16, 0);
+            else for (int a_off = 0; a_off < c->APAD; a_off += 32) launch(k_ssd_f32_mfma<32>, 32, a_off);
+            HIP_TRY(c, hipGetLastError());
+            if (prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
+            n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
+            hipLaunchKernelGGL(k_combine_f32x, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_fpart, c->d_fvnorm,
+                               c->d_fpnorm, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, c->n_agents);
+            HIP_TRY(c, hipGetLastError());
+            c->f32x_used = true;
         } else {
             // 16 headings per pass (8 when no more are resident).  DEJAVU_SHAPE: 1 single-wave workgroups, 2 four waves
             // + LDS fold, 3 / 4 the same with the next block's tiles prefetched.  Measured on 50 000 views x 64x64 x 16
@@ -2143,11 +2178,23 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     // runs across the lanes there.
     c->fuse_request = c->metric == 0 && !c->exact && !want_scene;
     c->epilogue_fused = false;
+    // ssd_f32 without per-view output: the cross-term form on the matrix cores selects, the exact resolver scores (k_ssd_f32_mfma)
+    c->f32x_request = c->metric == 1 && !c->exact && !want_scene && c->n_agents == 1;
+    c->f32x_used = false;
     int rc = launch_scoring(c, !fused);
     c->fuse_request = false;
+    c->f32x_request = false;
     if (rc) return rc;
     Range range("dv:finish");
-    if (c->epilogue_fused) {
+    if (c->f32x_used) {
+        // candidates per heading -> exact re-scoring -> minima and decision from the exact values; the record is k_decide's
+        hipLaunchKernelGGL(k_cand_f32x, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_pmax, c->n_partial,
+                           c->d_fvnorm, c->d_fpnorm, c->d_state, c->d_cand, c->cfg, c->A_agent);
+        hipLaunchKernelGGL(k_resolve_f32, dim3(256), dim3(64), 0, c->stream, c->d_ftiles, c->d_fraw, c->d_state, c->d_cand, c->d_cand_exact, c->cfg);
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result + c->result_slot,
+                           c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta, sense_err_ptr(c), 0,
+                           ++c->seq);
+    } else if (c->epilogue_fused) {
         launch_fold(c, c->fused_nb, c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), force, ++c->seq,
                     sense_err_ptr(c));
     } else if (fused) {
@@ -2183,7 +2230,7 @@ static int enqueue_resolve(dv_ctx* c, int agent = 0) {
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state + agent, c->d_cand + co, c->d_cand_exact + co,
                        c->d_result + agent, c->d_record + (size_t)agent * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta,
-                       sense_err_ptr(c), agent);
+                       sense_err_ptr(c), agent, -1);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }

@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -1542,7 +1543,7 @@ k_resolve(const uint4* __restrict__ tiles, const unsigned char* __restrict__ raw
 __global__ void k_decide(const StepState* __restrict__ st, const unsigned long long* __restrict__ cand,
                          const double* __restrict__ cand_exact, StepResultDev* __restrict__ out,
                          double* __restrict__ rec, LibCfg c, int A, double delta,
-                         const unsigned long long* __restrict__ sense_err, int agent) {
+                         const unsigned long long* __restrict__ sense_err, int agent, int seq) {
     __shared__ unsigned long long ekey[kMaxHeadings];
     __shared__ unsigned long long eview[kMaxHeadings];
     __shared__ StepResultDev s_res;
@@ -1561,12 +1562,17 @@ __global__ void k_decide(const StepState* __restrict__ st, const unsigned long l
     if (lane == 0) {
         decide_core(st->amax, st->aview, n_all, n > 0, ekey, eview, &s_res, c, A, delta, 0);
         if (sense_err && ((*sense_err >> agent) & 1ull)) s_res.flags |= kResSenseError;
+        if (seq >= 0) {                                  // a step that ENDS here (ssd_f32 on the matrix cores): the host polls this record
+            s_res.reserved = seq;
+            s_res.check = record_check(reinterpret_cast<const unsigned long long*>(&s_res), A);
+        }
     }
     __syncthreads();
     emit_record(&s_res, rec, A, lane, blockDim.x);
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_res);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
     if (lane < 7) dst[lane] = src[lane];
+    if (lane == 7 && seq >= 0) out->check = s_res.check;
     for (int i = lane; i < 4 * A; i += blockDim.x) {
         const int o = 7 + (i / A) * kMaxHeadings + (i % A);
         dst[o] = src[o];
@@ -1745,6 +1751,201 @@ k_combine_f32(const double* __restrict__ part, double* __restrict__ fam, unsigne
         unsigned long long m = wmax[0];
         for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
         blockmax[(long long)a * gridDim.x + blockIdx.x] = m;
+    }
+}
+
+// ------------------------------------------------------------------ ssd_f32 on the matrix cores (round 4)
+// k_ssd_tiles computes (l - p)^2 directly: two vector operations per pixel and heading, which bound it by its instruction
+// stream at 0.50-0.59 of the HBM peak.  The expansion  sum (l - p)^2 = N_l + N_p - 2 sum l p  turns the library stream into
+// the B operand of an fp32 matrix product -- v_mfma_f32_32x32x1_2b_f32 (32 headings x 64 views per instruction and pixel) or
+// v_mfma_f32_16x16x1_4b_f32 (16 headings x 64 views): with K = 1 and 2 / 4 blocks the 64 lanes of the B operand are 64
+// DIFFERENT views, i.e. exactly the lane <-> view tiles the library already has (ftiles), one VGPR of a loaded float4 per
+// instruction; the A operand is the patch pixel of heading lane & 31 (& 15), the same in every block.  Lane maps measured with
+// tools/exp/mfma_f32_blocks.hip: result register r of lane l holds
+//     32x32x1_2b: heading (r & 3) + 8 ((r & 15) >> 2) + 4 (l >> 5), view 32 (r >> 4) + (l & 31)
+//     16x16x1_4b: heading (r & 3) + 4 (l >> 4),                     view 16 (r >> 2) + (l & 15)
+// and both issue at 32 multiply-adds per cycle and SIMD (64.7 / 33.1 cycles): 500 000 views x 128x128 x 32 headings need 3.3 ms of
+// matrix pipe at 2.4 GHz against 5.2 ms of HBM stream, 50 000 x 64x64 x 16 headings 42 us against 130.
+// The expansion cancels -- a near match's small SSD is the difference of large numbers -- so these sums only SELECT: an fp32
+// chain of 1024 pixels (then folded into a double) is off by at most gamma = 1024 u / (1 - 1024 u), u = 2^-24, times sum |l p| <=
+// (N_l + N_p) / 2, hence every score lies within E = gamma (N_l + N_p) of its approximation; k_cand_f32x lists, per heading,
+// every view whose interval reaches the best lower bound, k_resolve_f32 re-scores the listed pairs in the reference's own
+// sequential double arithmetic (util.pyx:180-182) and k_decide takes minima and the decision from those exact values: every
+// reported per-heading minimum is then the reference's double bit for bit, not merely within 1e-6.
+constexpr int kF32xFold = 256;                         // q-steps (4 pixels each) per fp32 chain
+constexpr double kF32xKappa = 6.2e-5;                  // >= gamma_1024 = 6.1039e-5 with room for the norms' own rounding
+
+// N_f of every view, in double.  One thread per view (lane <-> view: coalesced), grid = Fpad / 64 blocks of 64.
+__global__ void __launch_bounds__(64)
+k_norm_f32(const float4* __restrict__ ftiles, double* __restrict__ vnorm, LibCfg c) {
+    const long long g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float4* base = ftiles + g * c.gstride + lane;
+    double n = 0.0;
+    for (int q = 0; q < c.Q; ++q) {
+        const float4 L = base[(long long)q * 64];
+        n += (double)L.x * (double)L.x; n += (double)L.y * (double)L.y; n += (double)L.z * (double)L.z; n += (double)L.w * (double)L.w;
+    }
+    vnorm[g * 64 + lane] = n;
+}
+
+// The A operand rows: pprep[q][a] = float4 of patch a's pixels 4q .. 4q+3 (zero past the last heading / pixel), a < APAD.
+__global__ void k_prep_f32x(const float* __restrict__ raw, float4* __restrict__ pprep, LibCfg c, int A, int APAD) {
+    const long long total = (long long)c.Q * APAD;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int a = (int)(t % APAD);
+    const int q = (int)(t / APAD);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a < A)
+        for (int i = 0; i < 4; ++i) { const int px = 4 * q + i; if (px < c.P) v[i] = raw[(long long)a * c.P + px]; }
+    pprep[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+// N_a of every heading's patch: one block per heading, a fixed-order sum (the same value every run).
+__global__ void __launch_bounds__(256)
+k_pnorm_f32(const float* __restrict__ raw, double* __restrict__ pnorm, LibCfg c) {
+    __shared__ double red[256];
+    const float* pa = raw + (long long)blockIdx.x * c.P;
+    double n = 0.0;
+    for (int px = threadIdx.x; px < c.P; px += 256) n += (double)pa[px] * (double)pa[px];
+    red[threadIdx.x] = n;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pnorm[blockIdx.x] = red[0];
+}
+
+typedef float v32f_t __attribute__((ext_vector_type(32)));
+typedef float v16f32_t __attribute__((ext_vector_type(16)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+// The cross terms sum l p of HB headings (at a_off) against one view group of 64 per item = (pixel chunk, view group); one wave
+// per item, D q-steps of library AND patch rows in flight (the patch rows come out of L1 / L2: every wave of the chip reads the
+// same ones), four MFMAs per q-step.  part[chunk][heading][view] (double) takes the item's sums.
+template <int HB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HB == 32 ? 2 : 3)))
+k_ssd_f32_mfma(const float4* __restrict__ ftiles, const float4* __restrict__ pprep, double* __restrict__ part, LibCfg c, int nchunk,
+               int apad_total, int a_off) {
+    constexpr int R = HB == 32 ? 32 : 16;              // result registers per lane
+    constexpr int D = 8;                               // q-steps in flight
+    using acc_t = typename std::conditional<HB == 32, v32f_t, v16f32_t>::type;
+    const int lane = threadIdx.x;
+    const long long G = c.Fpad / 64;
+    const long long n_items = G * nchunk;
+    const int Q = c.Q;
+    const int rows = (apad_total - a_off) < HB ? (apad_total - a_off) : HB;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ch = (int)(item / G);
+        const long long g = item - (long long)ch * G;
+        const int q0 = (int)(((long long)ch * Q) / nchunk), q1 = (int)(((long long)(ch + 1) * Q) / nchunk);
+        const v4f_t* lb = reinterpret_cast<const v4f_t*>(ftiles + g * c.gstride + lane);
+        const v4f_t* pb = reinterpret_cast<const v4f_t*>(pprep + a_off + (lane & (HB - 1)));
+        acc_t acc;
+        double accd[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc[r] = 0.f; accd[r] = 0.0; }
+        v4f_t L[D], Pt[D];
+        auto fetch = [&](int d, int q) {
+            const int qq = q < q1 ? q : q1 - 1;                     // (past the chunk: its last rows again, not multiplied)
+            L[d] = __builtin_nontemporal_load(lb + (long long)qq * 64);
+            Pt[d] = pb[(long long)qq * apad_total];
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) fetch(d, q0 + d);
+        int chain = 0;
+        for (int q = q0; q < q1; q += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const v4f_t l = L[d], p = Pt[d];
+                fetch(d, q + d + D);
+                if (q + d < q1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (HB == 32) acc = __builtin_amdgcn_mfma_f32_32x32x1f32(p[j], l[j], acc, 0, 0, 0);
+                        else acc = __builtin_amdgcn_mfma_f32_16x16x1f32(p[j], l[j], acc, 0, 0, 0);
+                    }
+                }
+            }
+            chain += D;
+            if (chain >= kF32xFold) {                               // the fp32 chains end here: into the doubles
+#pragma unroll
+                for (int r = 0; r < R; ++r) { accd[r] += (double)acc[r]; acc[r] = 0.f; }
+                chain = 0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) accd[r] += (double)acc[r];
+        double* dst = part + ((long long)ch * apad_total + a_off) * c.Fpad + g * 64;
+        int ln = lane;                                              // opaque: the row addresses are not hoisted out of the item loop
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int hd = HB == 32 ? (r & 3) + 8 * ((r & 15) >> 2) + 4 * (ln >> 5) : (r & 3) + 4 * (ln >> 4);
+            const int view = HB == 32 ? 32 * (r >> 4) + (ln & 31) : 16 * (r >> 2) + (ln & 15);
+            if (hd < rows) dst[(long long)hd * c.Fpad + view] = accd[r];
+        }
+    }
+}
+
+// fam[a][f] = -(N_f + N_a - 2 sum over chunks of part): the approximate SSD, negated like every score here; per block the
+// largest LOWER bound fam - E (E = kappa (N_f + N_a)) as an ordered key.  grid = (ceil(Fpad / 256), A).
+__global__ void __launch_bounds__(256)
+k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm, const double* __restrict__ pnorm, double* __restrict__ fam,
+               unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD, int n_agents) {
+    __shared__ unsigned long long wmax[4];
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0) reset_step_state(st, threadIdx.x, n_agents);
+    unsigned long long key = 0;
+    if (f < c.F) {
+        double dot = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) dot += part[((long long)ch * APAD + a) * c.Fpad + f];
+        const double n2 = vnorm[f] + pnorm[a];
+        const double val = -(n2 - 2.0 * dot);
+        fam[(long long)a * c.Fpad + f] = val;
+        key = ordered_key(val - kF32xKappa * n2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmax[0];
+        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+        blockmax[(long long)a * gridDim.x + blockIdx.x] = m;
+    }
+}
+
+// Per heading: every view whose interval [fam - E, fam + E] reaches the heading's best lower bound goes to the candidate list
+// (cand[i] = heading << 40 | view; st->ncand counts, possibly past kCandCap: the step is then redone exactly).  Block 0 leaves the
+// lower bounds as the step's approximate per-heading maxima.  grid = ceil(F / 256).
+__global__ void __launch_bounds__(256)
+k_cand_f32x(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial, const double* __restrict__ vnorm,
+            const double* __restrict__ pnorm, StepState* __restrict__ st, unsigned long long* __restrict__ cand, LibCfg c, int A) {
+    __shared__ unsigned long long s_lb[kMaxHeadings];
+    if (threadIdx.x < kMaxHeadings) s_lb[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * n_partial; i += blockDim.x) atomicMax(&s_lb[i / n_partial], pmax[i]);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < A) {
+        __hip_atomic_store(&st->amax[threadIdx.x], s_lb[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->aview[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= c.F) return;
+    const double nf = vnorm[f];
+    for (int a = 0; a < A; ++a) {
+        const double v = fam[(long long)a * c.Fpad + f];
+        const double e = kF32xKappa * (nf + pnorm[a]);
+        if (v + e >= key_to_double(s_lb[a])) {
+            const unsigned long long pos = atomicAdd(&st->ncand, 1ull);
+            if (pos < (unsigned long long)kCandCap) cand[pos] = ((unsigned long long)a << 40) | (unsigned long long)f;
+        }
     }
 }
 

@@ -489,3 +489,53 @@ def test_ssd_f32_at_config_two_literal_size():
         assert np.array_equal(pick, full_view)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("F,h,w,A", [(1, 1, 1, 1), (130, 5, 7, 3), (300, 16, 16, 16), (64, 9, 31, 8), (257, 32, 32, 10), (200, 12, 12, 32),
+                                     (150, 10, 14, 64), (90, 7, 9, 37), (4100, 64, 64, 17), (9000, 24, 24, 33), (700, 128, 128, 12)])
+def test_ssd_f32_on_the_matrix_cores_reports_the_references_doubles(F, h, w, A):
+    """step_f32 without per-view output takes the cross-term form on the fp32 matrix cores (k_ssd_f32_mfma: it only SELECTS, the
+    listed pairs are re-scored in the reference's sequential double arithmetic): every per-heading minimum must be the double
+    `ssds` (util.pyx:171-184, via the pinned oracle) returns for the reported view -- bit for bit -- and the view the true first
+    minimiser; ragged shapes (pixels not a multiple of 4, 1..64 headings = the 16-wide and the 32-wide instruction, one and two
+    passes, several pixel chunks per view group), near matches whose SSD is 1e-6 of the norms, exact duplicates.  The direct
+    form (DEJAVU_SSD_MFMA=0: k_ssd_tiles) must agree to its 1e-6."""
+    rng = np.random.default_rng(F * 13 + A)
+    lib = rng.uniform(-3, 3, (F, h, w)).astype(np.float32)
+    patches = rng.uniform(-3, 3, (A, h, w)).astype(np.float32)
+    if F > 100:
+        patches[A // 2] = lib[F // 3] + rng.normal(0, 0.001, (h, w)).astype(np.float32)    # a near match: SSD ~1e-6 of the norms
+        lib[F - 1] = lib[F // 7]                                                             # an exact duplicate of a view ...
+        patches[0] = lib[F // 7]                                                             # ... that a heading looks at: SSD 0 twice
+    want = np.empty((A, F))
+    l64 = lib.astype(np.float64)
+    for a in range(A):
+        d = l64 - patches[a].astype(np.float64)
+        want[a] = (d * d).reshape(F, -1).sum(axis=1)                  # near the oracle's value: used to find the few pairs it scores
+    e_new, e_old = _engine({}), _engine({"DEJAVU_SSD_MFMA": "0"})
+    try:
+        for e in (e_new, e_old):
+            e.set_library_f32(lib)
+        r = e_new.step_f32(patches)
+        assert r["flags"] & 1                                         # decided on exact values
+        for a in range(A):
+            f = int(r["angle_view"][a])
+            exact = oracle.ssds(patches[a].astype(np.float64), l64[f])
+            assert r["angle_ssd"][a] == exact, (a, f)
+            # the first true minimiser: no view scores lower, and none of a lower index ties with it
+            near = np.flatnonzero(want[a] <= exact * (1 + 1e-9) + 1e-300)
+            ex = np.array([oracle.ssds(patches[a].astype(np.float64), l64[k]) for k in near])
+            assert ex.min() == exact and int(near[int(np.argmin(ex))]) == f, (a, f, near[:5])
+        best = int(np.argmin(r["angle_ssd"]))
+        assert r["best_idex"] == best and r["best_view"] == int(r["angle_view"][best]) and r["step_ssd"] == r["angle_ssd"][best]
+        if F > 100:
+            assert r["best_idex"] == 0 and r["best_view"] == F // 7 and r["step_ssd"] == 0.0
+        r0 = e_old.step_f32(patches)
+        assert (r0["best_idex"], r0["best_view"]) == (r["best_idex"], r["best_view"])
+        np.testing.assert_allclose(r0["angle_ssd"], r["angle_ssd"], rtol=1e-6, atol=1e-12)
+        for _ in range(3):                                            # repeatable
+            again = e_new.step_f32(patches)
+            assert np.array_equal(again["angle_ssd"], r["angle_ssd"]) and np.array_equal(again["angle_view"], r["angle_view"])
+    finally:
+        e_new.close()
+        e_old.close()
