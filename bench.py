@@ -37,8 +37,10 @@ I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 matrix-core peak: 2x the ~2.5 PF dense 
 CLOCK_PEAK_GHZ = 2.4
 
 
-def kernel_of_shape(shape):
-    return {5: "k_sad_packed", 6: "k_sad_mfma"}.get(shape, "k_sad_tiles")
+def kernel_of_shape(shape, generic=False):
+    if generic:
+        return "k_sad_generic"
+    return {5: "k_sad_packed", 6: "k_sad_mfma_dual"}.get(shape, "k_sad_tiles")
 
 
 def launch_ranks(n):
@@ -76,7 +78,8 @@ def committed_traffic(workload_key, kernel="k_sad_tiles"):
         try:
             d = json.load(open(f))
             if d["bench_under_trace"]["config"]["workload"] == workload_key:
-                best = (float(d[kernel]["hbm_traffic_bytes_per_launch"]), os.path.basename(f))
+                k = kernel if kernel in d else {"k_sad_mfma_dual": "k_sad_mfma"}.get(kernel, kernel)   # (summaries key the dual kernel as k_sad_mfma)
+                best = (float(d[k]["hbm_traffic_bytes_per_launch"]), os.path.basename(f))
         except Exception:   # noqa: BLE001
             continue
     return best
@@ -171,22 +174,29 @@ def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
         for _ in range(3):
             e2.sense_step_batch(xs, ys, angs)
         resolved = sum(1 for r in e2.sense_step_batch(xs, ys, angs) if r["flags"] & 1)
+        form = e2.scoring_form()
         t0 = time.perf_counter()
         for _ in range(2 * n_steps):
             e2.sense_step_batch(xs, ys, angs)
         dt = (time.perf_counter() - t0) / (2 * n_steps)
         out["sensed"] = dict(view_comparisons_per_s=n_agents * A * n_views / dt, ms_per_ensemble_step=dt * 1e3, library_views=n_views,
-                             agents_resolved_exactly=resolved,
+                             agents_resolved_exactly=resolved, kernel_form=form,
                              what="dv_sense_step_batch: patches sensed on the device, poses only go up")
     finally:
         e2.close()
     best = out["sensed"]
     k_elems = float(planes) * h * w                                # K-elements per (view, heading): bit planes x pixels of the sensed library
+    # the sensed patches are 5-level sensor output scored against a synthetic library: on its levels they take the fp4 form, off them
+    # the int8 form at half the peak -- the fraction is priced against the form that ran
+    fp4 = bool(out["sensed"]["kernel_form"].get("fp4"))
+    peak = FP4_MFMA_PEAK_TOPS if fp4 else I8_MFMA_PEAK_TOPS
     return dict(view_comparisons_per_s=best["view_comparisons_per_s"], agent_steps_per_s=n_agents / (best["ms_per_ensemble_step"] * 1e-3),
                 ms_per_ensemble_step=best["ms_per_ensemble_step"], sensed=out["sensed"], uploaded=out["uploaded"],
-                mfma_frac_of_fp4_peak=2.0 * best["view_comparisons_per_s"] * k_elems / 1e12 / FP4_MFMA_PEAK_TOPS,
+                kernel="k_sad_mfma_dual", mfma_form="fp4" if fp4 else "int8", mfma_peak_tops=peak,
+                mfma_frac_of_peak=2.0 * best["view_comparisons_per_s"] * k_elems / 1e12 / peak,
                 what="%d agents x %d headings against %d views (%dx%d): one GPU's share of BASELINE.json configs[4]; headline = "
-                     "the sensed form; mfma_frac = 2 x comparisons x bit planes (%d) x pixels / s over the dense fp4 peak" % (n_agents, A, n_views, w, h, planes))
+                     "the sensed form; mfma_frac = 2 x comparisons x bit planes (%d) x pixels / s over the dense peak of the form that ran "
+                     "(fp4 10 POP/s, int8 5)" % (n_agents, A, n_views, w, h, planes))
 
 
 def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
@@ -250,42 +260,61 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     return rates, n_lib, ens_rate, outliers
 
 
-def ssd_f32_block(device_index, F, h, w, A, steps):
-    """The north star's literal "fp32 SSD" on the configs[1] shape: float32 single-channel views (819 MB), the metric the
-    reference defines as `ssds` (util.pyx:171-184).  Patches are uploaded every step (262 KB): the PCIe-inclusive step."""
+def ssd_f32_block(device_index, F, h, w, A, steps, seed=4242):
+    """The north star's literal "fp32 SSD": float32 single-channel views, the metric the reference defines as `ssds`
+    (util.pyx:171-184) -- on configs[1]'s shape (819 MB) and on configs[2] as BASELINE.json words it (500 000 x 128x128 float32 =
+    32.8 GB, 32 headings).  The library is generated on the device (dv_generate_library_f32); patches are uploaded every step
+    (PCIe-inclusive step).  Steps without per-view output take the cross-term form on the fp32 matrix cores (k_ssd_f32_mfma), the
+    listed candidates re-scored exactly; `direct` repeats the timing with DEJAVU_SSD_MFMA=0 (k_ssd_tiles, 16 headings per pass)."""
     import navsim_amd
+    from navsim_amd import synth
     rng = np.random.default_rng(1)
-    lib = rng.random((F, h, w), dtype=np.float32)
     patches = rng.random((A, h, w), dtype=np.float32)
-    patches[A // 2] = lib[31337 % F] + np.float32(0.01)
-    eng = navsim_amd.FamiliarityEngine(device_index)
-    try:
-        eng.set_library_f32(lib)
-        for _ in range(5):
-            r = eng.step_f32(patches)
-        if (r["best_idex"], r["best_view"]) != (A // 2, 31337 % F):
-            raise RuntimeError("ssd_f32: planted view not found")
-        eng.profile_kernel(True)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            eng.step_f32(patches)
-        dt = (time.perf_counter() - t0) / steps
-        kms, kn = eng.profile_read()
-        eng.profile_kernel(False)
-    finally:
-        eng.close()
-    passes = (A + 15) // 16
-    kern_ms = kms / max(kn, 1)
-    streamed = float(F) * h * w * 4 * passes
+    plant = 31337 % F
+    patches[A // 2] = synth.synth_views_f32(seed, 1, h, w, first_view=plant)[0] + np.float32(0.01)
+    out = {}
+    for name, env in (("mfma", None), ("direct", "0")):
+        if env is not None:
+            os.environ["DEJAVU_SSD_MFMA"] = env
+        try:
+            eng = navsim_amd.FamiliarityEngine(device_index)
+        finally:
+            os.environ.pop("DEJAVU_SSD_MFMA", None)
+        try:
+            eng.generate_library_f32(seed, F, h, w)
+            n = steps if name == "mfma" else max(steps // 4, 5)
+            for _ in range(3):
+                r = eng.step_f32(patches)
+            if (r["best_idex"], r["best_view"]) != (A // 2, plant):
+                raise RuntimeError("ssd_f32: planted view not found")
+            eng.profile_kernel(True)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                eng.step_f32(patches)
+            dt = (time.perf_counter() - t0) / n
+            kms, kn = eng.profile_read()
+            eng.profile_kernel(False)
+            out[name] = (dt, kms / max(kn, 1), kn, int(r["n_candidates"]))
+        finally:
+            eng.close()
+    dt, kern_ms, kn, ncand = out["mfma"]
+    passes = (A + 31) // 32 if A > 16 else 1
     algo = float(F) * h * w * 4
+    streamed = algo * passes
     return {"workload": "%dx%d sensor, %d stored float32 views, %d headings, ssd_f32" % (w, h, F, A), "dtype": "f32",
             "value": F * A / dt, "unit": "view-comparisons/s", "ms_per_step": dt * 1e3, "steps": steps,
-            "roofline": {"bound": "hbm", "kernel": "k_ssd_tiles", "kernel_ms": kern_ms, "launches_timed": kn,
+            "candidates_rescored_exactly": ncand,
+            "direct_form": {"ms_per_step": out["direct"][0] * 1e3, "kernel_ms": out["direct"][1], "kernel": "k_ssd_tiles",
+                            "library_passes": (A + 15) // 16},
+            "roofline": {"bound": "hbm", "kernel": "k_ssd_f32_mfma", "kernel_ms": kern_ms, "launches_timed": kn,
                          "library_passes": passes, "achieved": streamed / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": streamed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "bytes_basis": "streamed library bytes (4 B/px x passes of 16 headings)",
+                         "bytes_basis": "streamed library bytes (4 B/px x passes of 32 headings) = the algorithmic bytes of SURVEY 8(d), s = 4",
                          "algorithmic_bytes_per_launch": algo,
-                         "frac_algorithmic": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+                         "frac_algorithmic": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "mfma": {"dtype": "f32 (v_mfma_f32_32x32x1_2b / 16x16x1_4b)", "ops_per_launch": 2.0 * F * h * w * max(A, 16 if A <= 16 else 32 * passes),
+                                  "peak": 157.3, "unit": "TFLOP/s",
+                                  "frac": 2.0 * F * h * w * max(A, 16 if A <= 16 else 32 * passes) / (kern_ms * 1e-3) / 1e12 / 157.3}}}
 
 
 def ssd_u8_block(device_index, F, h, w, A, steps):
@@ -341,7 +370,7 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
     committed PMC passes when they are of this workload, else the bytes it streams by construction (stored library
     bytes + the partial sums it writes).  The SURVEY section 8(d) figure (F*P*s reference bytes) is kept as
     `algorithmic_*`: it counts 3 B/px where the bit-plane layout stores 0.75."""
-    kernel = kernel_of_shape(shape)
+    kernel = kernel_of_shape(shape, bool(info.get("generic_hue")))
     s_ref = 3 if cw > 0 else 1
     algo_bytes = float(F) * h * w * s_ref
     streamed = float(info["bit_tile_bytes"] if shape == 6 else info["tile_bytes"])
@@ -402,17 +431,67 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
     if with_ceiling:
         try:
             out["measured_read_ceiling"] = float(eng.stream_read_gbps(1 << 30, 10))
+            # the same bytes against what an LDS-DMA stream probe inside this library reads on THIS box (not the spec peak)
+            out["frac_of_measured_ceiling"] = out["achieved"] / out["measured_read_ceiling"]
         except Exception:                                        # measurement aid only
             out["measured_read_ceiling"] = None
+            out["frac_of_measured_ceiling"] = None
     return out
 
 
-def secondary_scoring(device_index, seed, F, h, w, A, cw, steps, warmup, full_range_s=False):
+def generic_block(device_index, seed, F, h, w, A, cw, steps):
+    """A library the one-hot layout cannot hold -- more than four hues, full-range S and V (uploaded: random bytes) -- scored by
+    k_sad_generic on H, S, V byte planes; resident patches, scoring + reductions per step."""
+    import navsim_amd
+    from navsim_amd import synth
+    lib = synth.random_hsv(seed, (F, h, w, 3))
+    patches = synth.random_hsv(seed + 1, (A, h, w, 3))
+    patches[A // 2] = lib[F // 3]
+    eng = navsim_amd.FamiliarityEngine(device=device_index)
+    try:
+        eng.set_library(lib, cw)
+        del lib
+        info = eng.library_info()
+        eng.upload_patches(patches)
+        for _ in range(5):
+            eng.step_enqueue(want_scene=False)
+            r = eng.step_wait(want_scene=False)
+        if (r["best_idex"], r["best_view"]) != (A // 2, F // 3):
+            raise RuntimeError("generic block: planted view not found")
+        eng.profile_kernel(True, every=2)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step_enqueue(want_scene=False)
+            eng.step_wait(want_scene=False)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        kms, kn = eng.profile_read()
+        eng.profile_kernel(False)
+        shape = eng.workgroup_shape(A)
+        workload = "%dx%d sensor, %d stored views, %d headings, sads_hsv chem_weight=%g, uniformly random H, S, V bytes (generic hue planes)" % (w, h, F, A, cw)
+        return {"workload": workload, "value": F * A * steps / dt, "unit": "view-comparisons/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                "generic_hue": bool(info["generic_hue"]), "patches": "resident (uploaded once)",
+                "roofline": roofline_block(eng, info, shape, kms / max(kn, 1), kn, F, h, w, A, cw, workload, with_ceiling=False)}
+    finally:
+        eng.close()
+
+
+def secondary_scoring(device_index, seed, F, h, w, A, cw, steps, warmup, full_range_s=False, env=None):
     """One more workload on a fresh engine (N=1 only): value, step and kernel time, roofline.  full_range_s: the library's
     saturation takes every value 0..127 (a swept concentration range) -- too many levels for thermometer planes, so the layout
     is the mixed one: value bit planes on the matrix cores, then the saturation byte planes with v_sad_u8, k_finish on both."""
     import navsim_amd
-    eng = navsim_amd.FamiliarityEngine(device=device_index)
+    before = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        eng = navsim_amd.FamiliarityEngine(device=device_index)     # (the context reads its knobs when it is created)
+    finally:
+        for k, v in before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     try:
         eng.generate_library(seed, F, h, w, cw, full_range_s=full_range_s)
         eng.generate_patches(seed, A)
@@ -441,7 +520,7 @@ def secondary_scoring(device_index, seed, F, h, w, A, cw, steps, warmup, full_ra
         shape = eng.workgroup_shape(A)
         workload = workload_name(w, h, F, A, cw, 1) + (", saturation 0..127 (mixed layout)" if full_range_s else "")
         return {"workload": workload, "value": F * A * steps / dt, "unit": "view-comparisons/s", "ms_per_step": dt / steps * 1e3,
-                "steps": steps, "workgroup_shape": shape,
+                "steps": steps, "workgroup_shape": shape, "env": env,
                 "scoring_only": {"value": F * A * steps / dt_res, "ms_per_step": dt_res / steps * 1e3,
                                  "what": "the same resident patches every step: no preparation kernels"},
                 "roofline": roofline_block(eng, info, shape, kms / max(kn, 1), kn, F, h, w, A, cw, workload, with_ceiling=False)}
@@ -586,6 +665,13 @@ def main():
         raise SystemExit("rank %d: known-answer step failed: got heading %d view %d familiarity %r, expected %d %d %r"
                          % (rank, chk["best_idex"], chk["best_view"], chk["step_familiarity"], a_star, f_star, float(h * w)))
 
+    rccl_ranks, exchange_us = None, None
+    if exchange is not None and hasattr(exchange, "rccl_ranks"):
+        try:
+            rccl_ranks = exchange.rccl_ranks()                      # ncclCommCount of the communicator the per-step collective uses
+            exchange_us = exchange.exchange_only_us(50)             # every rank takes part: a collective
+        except Exception as e:                                      # noqa: BLE001
+            sys.stderr.write("rank %d: exchange facts unavailable: %r\n" % (rank, e))
     if use_dist:
         t = torch.tensor([dt, dt_resident], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -624,6 +710,8 @@ def main():
                 "bytes_per_pixel_streamed": ((info["code_tile_bytes"] or info["bit_tile_bytes"]) / float(((F + 63) // 64) * 64 * h * w)
                                              if shape == 6 else info["n_planes"]),
                 "parallelism": "library sharded x%d" % world,
+                "rccl_ranks": rccl_ranks, "exchange_us_per_step": exchange_us,
+                "exchange_words": (A + 4 * world) if use_dist else 0,
                 "exchange": "none" if not use_dist else "1 exchange of per-heading records per step (%s)" % (
                     "mailbox in host-shared memory, no collective" if args.exchange == "mailbox" else
                     (("RCCL on the step's stream, device-resident"
@@ -679,6 +767,18 @@ def main():
                 out["ssd_f32"] = ssd_f32_block(device_index, 50000, 64, 64, 16, 50)
             except Exception as e:                               # noqa: BLE001
                 out["ssd_f32"] = {"error": repr(e)}
+            try:                                                 # configs[2] as BASELINE.json words it: fp32, 32.8 GB
+                out["ssd_f32_configs2"] = ssd_f32_block(device_index, F, h, w, A, 12)
+            except Exception as e:                               # noqa: BLE001
+                out["ssd_f32_configs2"] = {"error": repr(e)}
+            try:                                                 # the headline library on the byte path (what a library the planes cannot describe pays)
+                out["byte_path"] = secondary_scoring(device_index, args.seed, F, h, w, A, cw, max(args.steps // 5, 5), 3, env={"DEJAVU_BITS": "0"})
+            except Exception as e:                               # noqa: BLE001
+                out["byte_path"] = {"error": repr(e)}
+            try:
+                out["generic_hue"] = generic_block(device_index, args.seed, 50000, 64, 64, 16, cw, 50)
+            except Exception as e:                               # noqa: BLE001
+                out["generic_hue"] = {"error": repr(e)}
         if extras and args.secondary:
             try:
                 out["ssd_u8"] = ssd_u8_block(device_index, 50000, 64, 64, 16, 50)
@@ -693,6 +793,41 @@ def main():
             out["cpu_baseline"] = cpu_baseline(h, w, A, cw, args.seed, min(args.cpu_views, F))
         else:
             out["cpu_baseline"] = None
+        # The figures of the secondary blocks as scalars INSIDE `roofline` (the driver's record keeps config / roofline /
+        # cpu_baseline whole and only lists other keys): every number DESIGN.md section 4 quotes can be read from here.
+        def g(block, *path):
+            v = out.get(block)
+            for k in path:
+                v = v.get(k) if isinstance(v, dict) else None
+            return v
+        def us(x):
+            return None if x is None else x * 1e3
+        out["roofline"]["secondary"] = {
+            "c2_step_ms": out["ms_per_step"], "c2_kernel_ms": g("roofline", "kernel_ms"), "c2_scoring_only_ms": g("scoring_only", "ms_per_step"),
+            "c1_step_us": us(g("configs1", "ms_per_step")), "c1_scoring_only_step_us": us(g("configs1", "scoring_only", "ms_per_step")),
+            "c1_kernel_us": us(g("configs1", "roofline", "kernel_ms")), "c1_frac": g("configs1", "roofline", "frac"),
+            "c1_view_comparisons_per_s": g("configs1", "value"),
+            "full_s_ms": g("full_range_s", "ms_per_step"), "full_s_kernel_ms": g("full_range_s", "roofline", "kernel_ms"),
+            "full_s_frac": g("full_range_s", "roofline", "frac"), "full_s_valu_frac": g("full_range_s", "roofline", "valu", "frac"),
+            "byte_path_ms": g("byte_path", "ms_per_step"), "byte_path_kernel_ms": g("byte_path", "roofline", "kernel_ms"),
+            "byte_path_frac": g("byte_path", "roofline", "frac"), "byte_path_valu_frac": g("byte_path", "roofline", "valu", "frac"),
+            "generic_hue_step_us": us(g("generic_hue", "ms_per_step")), "generic_hue_kernel_us": us(g("generic_hue", "roofline", "kernel_ms")),
+            "generic_hue_frac": g("generic_hue", "roofline", "frac"), "generic_hue_valu_frac": g("generic_hue", "roofline", "valu", "frac"),
+            "ssd_f32_kernel_us": us(g("ssd_f32", "roofline", "kernel_ms")), "ssd_f32_frac": g("ssd_f32", "roofline", "frac"),
+            "ssd_f32_step_us": us(g("ssd_f32", "ms_per_step")), "ssd_f32_direct_kernel_us": us(g("ssd_f32", "direct_form", "kernel_ms")),
+            "ssd_f32_c2_kernel_ms": g("ssd_f32_configs2", "roofline", "kernel_ms"), "ssd_f32_c2_frac": g("ssd_f32_configs2", "roofline", "frac"),
+            "ssd_f32_c2_step_ms": g("ssd_f32_configs2", "ms_per_step"), "ssd_f32_c2_direct_kernel_ms": g("ssd_f32_configs2", "direct_form", "kernel_ms"),
+            "ssd_f32_c2_mfma_frac": g("ssd_f32_configs2", "roofline", "mfma", "frac"),
+            "ssd_u8_kernel_us": us(g("ssd_u8", "roofline", "kernel_ms")), "ssd_u8_frac": g("ssd_u8", "roofline", "frac"),
+            "ssd_u8_step_us": us(g("ssd_u8", "ms_per_step")),
+            "ens_ms": g("ensemble", "ms_per_ensemble_step"), "ens_uploaded_ms": g("ensemble", "uploaded", "ms_per_ensemble_step"),
+            "ens_mfma_frac": g("ensemble", "mfma_frac_of_peak"), "ens_mfma_form": g("ensemble", "mfma_form"),
+            "ens_view_comparisons_per_s": g("ensemble", "view_comparisons_per_s"),
+            "agent_steps_per_s": g("agent", "nav_steps_per_s"), "agent_steps_per_s_fake": g("agent", "nav_steps_per_s_fake"),
+            "agent_median_step_us": g("agent", "median_step_us_and_steps_over_4x_median", "not_fake", "median_step_us"),
+            "agent_ensemble_of_32_steps_per_s": g("agent", "ensemble_of_32_nav_steps_per_s"),
+            "cpu_one_core_cmp_per_s": g("cpu_baseline", "value"), "cpu_16_threads_cmp_per_s": g("cpu_baseline", "multicore", "value"),
+        }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if exchange is not None:
         exchange.close()

@@ -100,6 +100,8 @@ struct dv_ctx {
     float4* d_fprep4 = nullptr;               // ssd_f32 on the matrix cores: [Q][APAD] float4 patch rows (k_prep_f32x)
     double* d_fvnorm = nullptr;               // [Fpad] sum of squares of each view (k_norm_f32, at ingest)
     double* d_fpnorm = nullptr;               // [64] ... of each heading's patch
+    unsigned long long* d_flower = nullptr;   // [64] per heading the best lower bound of the step (ordered key; k_combine_f32x)
+    bool fprep_direct_ready = false;          // d_fprep (the direct form's operand layout) describes the resident patches
     int ssd_mfma_env = 1;                     // DEJAVU_SSD_MFMA=0: ssd_f32 steps keep the direct form (k_ssd_tiles) throughout
     bool f32x_request = false;                // enqueue_step: this ssd_f32 pass may take the cross-term form (no per-view output wanted)
     bool f32x_used = false;                   // ... and did: the step ends in k_cand_f32x + k_resolve_f32 + k_decide
@@ -258,7 +260,7 @@ static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_acc); F(c->d_one); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
-    F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart); F(c->d_fprep4); F(c->d_fvnorm); F(c->d_fpnorm);
+    F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart); F(c->d_fprep4); F(c->d_fvnorm); F(c->d_fpnorm); F(c->d_flower);
     F(c->d_u8tiles); F(c->d_u8raw); F(c->d_u8prep); F(c->d_u8part); F(c->d_vnorm); F(c->d_pnorm);
     F(c->d_btiles); F(c->d_coef); F(c->d_coef4); F(c->d_ctiles); c->ctile_bytes = 0;
     c->pbits = PrepBits{};
@@ -903,6 +905,7 @@ static int alloc_f32_buffers(dv_ctx* c) {
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fprep4, (size_t)g.Q * kMaxHeadings * sizeof(float4));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fvnorm, (size_t)g.Fpad * sizeof(double));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fpnorm, (size_t)kMaxHeadings * sizeof(double));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_flower, (size_t)kMaxHeadings * sizeof(unsigned long long));
     if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 buffers");
     return DV_OK;
 }
@@ -989,14 +992,25 @@ static int upload_patches_f32(dv_ctx* c, const float* patches, int A) {
     HIP_TRY(c, hipMemcpyAsync(c->d_fraw, patches, (size_t)A * c->cfg.P * sizeof(float), hipMemcpyHostToDevice, c->stream));
     c->A = A; c->n_agents = 1; c->A_agent = A; c->patches_sensed = false;
     c->APAD = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
-    const long long total = (long long)c->cfg.Q * 4 * c->APAD;
-    hipLaunchKernelGGL(k_prep_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep, c->cfg, A, c->APAD);
-    if (c->ssd_mfma_env) {                                            // the matrix-core form's operand rows and patch norms
+    // the matrix-core form's operand rows, patch norms and cleared lower bounds in one launch; the direct form's operand layout
+    // only when a direct pass is about to run (ensure_direct_prep_f32: dv_score_f32, scene_ssd, DEJAVU_SSD_MFMA=0)
+    c->fprep_direct_ready = false;
+    if (c->ssd_mfma_env) {
         const long long t4 = (long long)c->cfg.Q * c->APAD;
-        hipLaunchKernelGGL(k_prep_f32x, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep4, c->cfg, A, c->APAD);
-        hipLaunchKernelGGL(k_pnorm_f32, dim3((unsigned)A), dim3(256), 0, c->stream, c->d_fraw, c->d_fpnorm, c->cfg);
+        const int nrow = (int)((t4 + 255) / 256);
+        hipLaunchKernelGGL(k_prep_f32x, dim3((unsigned)(nrow + A)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep4, c->d_fpnorm, c->d_flower,
+                           c->cfg, A, c->APAD, nrow);
+        HIP_TRY(c, hipGetLastError());
     }
+    return DV_OK;
+}
+
+static int ensure_direct_prep_f32(dv_ctx* c) {
+    if (c->fprep_direct_ready) return DV_OK;
+    const long long total = (long long)c->cfg.Q * 4 * c->APAD;
+    hipLaunchKernelGGL(k_prep_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep, c->cfg, c->A, c->APAD);
     HIP_TRY(c, hipGetLastError());
+    c->fprep_direct_ready = true;
     return DV_OK;
 }
 
@@ -2033,19 +2047,20 @@ static int launch_scoring(dv_ctx* c, bool with_combine = true) {
                 hipLaunchKernelGGL(kern, grid, block, 0, c->stream, c->d_ftiles, c->d_fprep4, c->d_fpart, c->cfg, c->nchunk, c->APAD, a_off);
                 (void)hb;
             };
-            if (c->APAD <= 16) launch(k_ssd_f32_mfma<16>, 16, 0);
-            else for (int a_off = 0; a_off < c->APAD; a_off += 32) launch(k_ssd_f32_mfma<32>, 32, a_off);
+            if (c->APAD <= 16) launch(k_ssd_f32_mfma<16, 8>, 16, 0);
+            else for (int a_off = 0; a_off < c->APAD; a_off += 32) launch(k_ssd_f32_mfma<32, 16>, 32, a_off);
             HIP_TRY(c, hipGetLastError());
             if (prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
             n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
             hipLaunchKernelGGL(k_combine_f32x, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_fpart, c->d_fvnorm,
-                               c->d_fpnorm, c->d_fam, c->d_pmax, c->d_state, c->cfg, c->nchunk, c->APAD, c->n_agents);
+                               c->d_fpnorm, c->d_fam, c->d_flower, c->d_state, c->cfg, c->nchunk, c->APAD, c->n_agents);
             HIP_TRY(c, hipGetLastError());
             c->f32x_used = true;
         } else {
             // 16 headings per pass (8 when no more are resident).  DEJAVU_SHAPE: 1 single-wave workgroups, 2 four waves
             // + LDS fold, 3 / 4 the same with the next block's tiles prefetched.  Measured on 50 000 views x 64x64 x 16
             // headings (819 MB): 191 / 308 / 181 / 207 us -> default 3.
+            { const int rc2 = ensure_direct_prep_f32(c); if (rc2) return rc2; }
             const int var = (c->shape_env >= 1 && c->shape_env <= 4) ? c->shape_env : 3;
             auto launch = [&](auto kern, int nw, int apad, int a_off) {
                 static_assert(true, "");
@@ -2188,7 +2203,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     Range range("dv:finish");
     if (c->f32x_used) {
         // candidates per heading -> exact re-scoring -> minima and decision from the exact values; the record is k_decide's
-        hipLaunchKernelGGL(k_cand_f32x, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_pmax, c->n_partial,
+        hipLaunchKernelGGL(k_cand_f32x, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_flower,
                            c->d_fvnorm, c->d_fpnorm, c->d_state, c->d_cand, c->cfg, c->A_agent);
         hipLaunchKernelGGL(k_resolve_f32, dim3(256), dim3(64), 0, c->stream, c->d_ftiles, c->d_fraw, c->d_state, c->d_cand, c->d_cand_exact, c->cfg);
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result + c->result_slot,

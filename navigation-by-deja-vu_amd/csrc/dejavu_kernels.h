@@ -1789,8 +1789,27 @@ k_norm_f32(const float4* __restrict__ ftiles, double* __restrict__ vnorm, LibCfg
     vnorm[g * 64 + lane] = n;
 }
 
-// The A operand rows: pprep[q][a] = float4 of patch a's pixels 4q .. 4q+3 (zero past the last heading / pixel), a < APAD.
-__global__ void k_prep_f32x(const float* __restrict__ raw, float4* __restrict__ pprep, LibCfg c, int A, int APAD) {
+// Everything the matrix-core form needs of the A resident patches, one launch: blocks [0, nrow) write the A operand rows
+// pprep[q][a] = float4 of patch a's pixels 4q .. 4q+3 (zero past the last heading / pixel), a < APAD; block nrow + a sums N_a of
+// heading a's patch in double (a fixed-order sum: the same value every run) and zeroes the heading's lower bound for k_combine_f32x.
+__global__ void __launch_bounds__(256)
+k_prep_f32x(const float* __restrict__ raw, float4* __restrict__ pprep, double* __restrict__ pnorm, unsigned long long* __restrict__ lower,
+            LibCfg c, int A, int APAD, int nrow) {
+    if ((int)blockIdx.x >= nrow) {
+        __shared__ double red[256];
+        const int a = blockIdx.x - nrow;
+        const float* pa = raw + (long long)a * c.P;
+        double n = 0.0;
+        for (int px = threadIdx.x; px < c.P; px += 256) n += (double)pa[px] * (double)pa[px];
+        red[threadIdx.x] = n;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { pnorm[a] = red[0]; lower[a] = 0ull; }
+        return;
+    }
     const long long total = (long long)c.Q * APAD;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -1801,21 +1820,6 @@ __global__ void k_prep_f32x(const float* __restrict__ raw, float4* __restrict__ 
         for (int i = 0; i < 4; ++i) { const int px = 4 * q + i; if (px < c.P) v[i] = raw[(long long)a * c.P + px]; }
     pprep[t] = make_float4(v[0], v[1], v[2], v[3]);
 }
-// N_a of every heading's patch: one block per heading, a fixed-order sum (the same value every run).
-__global__ void __launch_bounds__(256)
-k_pnorm_f32(const float* __restrict__ raw, double* __restrict__ pnorm, LibCfg c) {
-    __shared__ double red[256];
-    const float* pa = raw + (long long)blockIdx.x * c.P;
-    double n = 0.0;
-    for (int px = threadIdx.x; px < c.P; px += 256) n += (double)pa[px] * (double)pa[px];
-    red[threadIdx.x] = n;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) pnorm[blockIdx.x] = red[0];
-}
 
 typedef float v32f_t __attribute__((ext_vector_type(32)));
 typedef float v16f32_t __attribute__((ext_vector_type(16)));
@@ -1824,12 +1828,18 @@ typedef float v4f_t __attribute__((ext_vector_type(4)));
 // The cross terms sum l p of HB headings (at a_off) against one view group of 64 per item = (pixel chunk, view group); one wave
 // per item, D q-steps of library AND patch rows in flight (the patch rows come out of L1 / L2: every wave of the chip reads the
 // same ones), four MFMAs per q-step.  part[chunk][heading][view] (double) takes the item's sums.
-template <int HB>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HB == 32 ? 2 : 3)))
+// Measured (round 4, one MI355X): 50 000 views x 64x64 x 16 headings (16-wide instruction, D = 8, three waves per SIMD) 138-148 us =
+// 5.5-5.9 TB/s, where k_ssd_tiles takes 186-205; 500 000 views x 128x128 x 32 headings (32-wide, D = 16, two waves per SIMD) 6.6 ms =
+// 5.0 TB/s against 14.5 ms in two direct passes.  At 32 headings the pass is no longer bound by the stream: the matrix pipe is busy
+// 67 % of the kernel at the 1.79 GHz the chip holds under it (PMC: SQ_VALU_MFMA_BUSY_CYCLES 8.0e6 of 1.2e7 cycles per SIMD, waves
+// 77 % in issue stalls, 10 % in memory waits); D = 8 6.8 ms, three waves per SIMD with fp32 second-level sums 7.2-7.7 ms.
+template <int HB, int D>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HB == 32 || D > 8) ? 2 : 3)))
 k_ssd_f32_mfma(const float4* __restrict__ ftiles, const float4* __restrict__ pprep, double* __restrict__ part, LibCfg c, int nchunk,
                int apad_total, int a_off) {
     constexpr int R = HB == 32 ? 32 : 16;              // result registers per lane
-    constexpr int D = 8;                               // q-steps in flight
+    // D: q-steps (1 KB of library + 0.5 KB of patch rows each) in flight per wave
+    static_assert(kF32xFold % D == 0, "the chains are folded on a step boundary");
     using acc_t = typename std::conditional<HB == 32, v32f_t, v16f32_t>::type;
     const int lane = threadIdx.x;
     const long long G = c.Fpad / 64;
@@ -1893,7 +1903,7 @@ k_ssd_f32_mfma(const float4* __restrict__ ftiles, const float4* __restrict__ ppr
 // largest LOWER bound fam - E (E = kappa (N_f + N_a)) as an ordered key.  grid = (ceil(Fpad / 256), A).
 __global__ void __launch_bounds__(256)
 k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm, const double* __restrict__ pnorm, double* __restrict__ fam,
-               unsigned long long* __restrict__ blockmax, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD, int n_agents) {
+               unsigned long long* __restrict__ lower, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD, int n_agents) {
     __shared__ unsigned long long wmax[4];
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int a = blockIdx.y;
@@ -1917,7 +1927,7 @@ k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm
     if (threadIdx.x == 0) {
         unsigned long long m = wmax[0];
         for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
-        blockmax[(long long)a * gridDim.x + blockIdx.x] = m;
+        atomicMax(&lower[a], m);                                       // (zeroed by k_prep_f32x with the patches this step scores)
     }
 }
 
@@ -1925,12 +1935,10 @@ k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm
 // (cand[i] = heading << 40 | view; st->ncand counts, possibly past kCandCap: the step is then redone exactly).  Block 0 leaves the
 // lower bounds as the step's approximate per-heading maxima.  grid = ceil(F / 256).
 __global__ void __launch_bounds__(256)
-k_cand_f32x(const double* __restrict__ fam, const unsigned long long* __restrict__ pmax, int n_partial, const double* __restrict__ vnorm,
+k_cand_f32x(const double* __restrict__ fam, const unsigned long long* __restrict__ lower, const double* __restrict__ vnorm,
             const double* __restrict__ pnorm, StepState* __restrict__ st, unsigned long long* __restrict__ cand, LibCfg c, int A) {
     __shared__ unsigned long long s_lb[kMaxHeadings];
-    if (threadIdx.x < kMaxHeadings) s_lb[threadIdx.x] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < A * n_partial; i += blockDim.x) atomicMax(&s_lb[i / n_partial], pmax[i]);
+    if (threadIdx.x < kMaxHeadings) s_lb[threadIdx.x] = threadIdx.x < A ? lower[threadIdx.x] : 0ull;
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < A) {
         __hip_atomic_store(&st->amax[threadIdx.x], s_lb[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2200,7 +2208,16 @@ k_resolve_f32(const float4* __restrict__ ftiles, const float* __restrict__ raw_p
             __syncthreads();
             int npx = c.P - qb * 4;
             npx = npx > 256 ? 256 : npx;
-            for (int i = 0; i < npx; ++i) diff += terms[i];
+            // the reference's sequential order; the LDS reads are batched so that only the adds are serial (as k_resolve does)
+            int i = 0;
+            for (; i + 16 <= npx; i += 16) {
+                double t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] = terms[i + k];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) diff += t[k];
+            }
+            for (; i < npx; ++i) diff += terms[i];
             __syncthreads();
         }
         if (lane == 0) cand_exact[ci] = -diff;

@@ -421,6 +421,12 @@ class DirectRccl(object):
         self._ok(self.lib.ncclAllReduce(ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr), count, self.NCCL_UINT64,
                                         self.NCCL_MAX, self.comm, ctypes.c_void_p(stream)), "ncclAllReduce")
 
+    def comm_count(self):
+        """ncclCommCount of the communicator the per-step collective runs on: the number of ranks RCCL itself sees."""
+        n = ctypes.c_int(-1)
+        self._ok(self.lib.ncclCommCount(self.comm, ctypes.byref(n)), "ncclCommCount")
+        return int(n.value)
+
     def close(self):
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)
@@ -539,6 +545,25 @@ class DeviceExchange(object):
         self.engine.publish_wait(self.keys_host)
         self.exchanges += 1
         return merge_keys_native(self.keys_host, self.world, self.A, self.delta, signed_order=not direct)
+
+    def rccl_ranks(self):
+        """Ranks of the RCCL communicator the exchange runs on (ncclCommCount), or torch.distributed's world size when the
+        collective goes through torch."""
+        if self.direct is not None:
+            return self.direct.comm_count()
+        return int(self._dist.get_world_size())
+
+    def exchange_only_us(self, n=50):
+        """Microseconds per exchange with nothing else on the stream: the last step's keys reduced again n times (one
+        all-reduce(max) + hand-over to the host each).  What a step pays for being sharded, beside its scoring."""
+        import time
+        if not self.use_keys:
+            return None
+        self._reduce_keys()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self._reduce_keys()
+        return (time.perf_counter() - t0) / n * 1e6
 
     def step(self):
         self.engine.step_enqueue(want_scene=False)
