@@ -187,6 +187,20 @@ int dv_sense_step(dv_ctx *ctx, double x, double y, const double *angles, int n_h
  */
 int dv_sense_step_batch(dv_ctx *ctx, const double *x, const double *y, const double *angles, int n_agents, int n_headings,
                         uint32_t flags, dv_step_result *results);
+/*
+ * The device work AND the device-side book-keeping of one agent step in ONE call (the fast path of
+ * navsim_amd.NavBySceneFamiliarity.step_forward; a 60 us step does not want three trips through a binding):
+ *   1. when an error-metric answer is outstanding (dv_path_error_enqueue of an earlier step), it is collected:
+ *      *have_nearest = 1, *nearest = the distance (update_error, NavBySceneFamiliarity.py:252-276); else *have_nearest = 0;
+ *   2. when do_error != 0, the metrics of position (ex, ey) -- where the PREVIOUS step ended -- are asked for
+ *      (dv_path_error_enqueue: on the context's second stream, beside this step's kernels);
+ *   3. the headings (angle + offsets[a]) mod 2 pi (numpy's mod: the result takes the divisor's sign, :291) are sensed at
+ *      (x, y) and scored as dv_sense_step does; angle_fam[n_headings] receives the per-heading maxima, *best_heading the
+ *      decision (:313-315).  DV_ERR_INDEX like the reference's IndexError.
+ */
+int dv_agent_step(dv_ctx *ctx, double x, double y, double angle, const double *offsets, int n_headings,
+                  int do_error, double ex, double ey, double reach,
+                  double *angle_fam, int32_t *best_heading, double *nearest, int32_t *have_nearest);
 /* train_from_path (:118-140) on the device: sense n poses and ingest them as the library; out_views
  * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */
 int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,

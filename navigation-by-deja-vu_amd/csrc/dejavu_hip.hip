@@ -229,6 +229,7 @@ struct dv_ctx {
     PathErrOut* h_errout = nullptr;           // mapped ring of kErrRing answers
     PathErrOut* d_errout = nullptr;
     unsigned long long err_enq = 0, err_deq = 0;   // answers requested / collected
+    bool err_on_main = false;                 // the last metric computation rode on the step's own stream (dv_agent_step)
 
     // measurement
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1288,7 +1289,7 @@ static int ensure_prep_dwords(dv_ctx* c) {
     static const PoseSet no_poses{};
     hipLaunchKernelGGL(k_patch_prep<0>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, c->A, SensorCfg{}, (const unsigned char*)nullptr,
                        c->d_raw_patches, c->d_prep, c->cfg, c->APAD, c->d_acc + c->acc_parity, c->d_acc + (c->acc_parity ^ 1), c->A_agent, PrepBits{},
-                       0ull, (uint4*)nullptr, (uint4*)nullptr, 1);
+                       0ull, (uint4*)nullptr, (uint4*)nullptr, 1, PathErrArgs{});
     HIP_TRY(c, hipGetLastError());
     c->prep_dwords_ready = true;
     return DV_OK;
@@ -1296,7 +1297,8 @@ static int ensure_prep_dwords(dv_ctx* c) {
 
 // Senses the patches of A_total headings (poses by value) straight into the scoring kernel's operand layout: ONE
 // kernel, no copy and no memset on the way (see k_sense_prep).  n_agents agents of A_agent headings each.
-static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_agents, int A_agent, unsigned long long seed) {
+static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_agents, int A_agent, unsigned long long seed,
+                             const PathErrArgs* path_err = nullptr) {
     Range range(mode == 1 ? "dv:sense" : "dv:prep");
     const int A = n_agents * A_agent;
     c->A = A; c->n_agents = n_agents; c->A_agent = A_agent;
@@ -1305,7 +1307,8 @@ static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_ag
     PrepAcc* cur = c->d_acc + c->acc_parity;
     PrepAcc* nxt = c->d_acc + (c->acc_parity ^ 1);
     // (prep entries and image columns of the padded headings A..APAD-1 are left as they are: their sums are never read)
-    const dim3 grid((unsigned)(A * ((c->cfg.P + 255) / 256))), block(256);      // one block per (heading, 256 pixels)
+    const PathErrArgs pe = path_err ? *path_err : PathErrArgs{};
+    const dim3 grid((unsigned)(A * ((c->cfg.P + 255) / 256) + pe.nblk)), block(256);      // one block per (heading, 256 pixels) [+ the metric blocks]
     static const PoseSet no_poses{};
     const PrepBits pb = c->bits_ok ? c->pbits : PrepBits{};
     uint4* i8 = c->bits_ok ? c->d_coef : nullptr;
@@ -1316,19 +1319,19 @@ static int launch_patch_prep(dv_ctx* c, int mode, const PoseSet* poses, int n_ag
     c->prep_dwords_ready = dwords;
     if (mode == 1)
         hipLaunchKernelGGL(k_patch_prep<1>, grid, block, 0, c->stream, c->d_land, *poses, A, c->sensor, c->d_lut, c->d_raw_patches, c->d_prep,
-                           c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4, what);
+                           c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4, what, pe);
     else if (mode == 2)
         hipLaunchKernelGGL(k_patch_prep<2>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
-                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, seed, i8, i4, what);
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, seed, i8, i4, what, pe);
     else
         hipLaunchKernelGGL(k_patch_prep<0>, grid, block, 0, c->stream, (const unsigned char*)nullptr, no_poses, A, SensorCfg{}, (const unsigned char*)nullptr,
-                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4, what);
+                           c->d_raw_patches, c->d_prep, c->cfg, c->APAD, cur, nxt, A_agent, pb, 0ull, i8, i4, what, pe);
     HIP_TRY(c, hipGetLastError());
     c->patches_sensed = mode == 1;     // no host synchronisation here: the step's result record carries the sensor's error flag
     return enqueue_bit_prep(c);
 }
-static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int A_agent) {
-    return launch_patch_prep(c, 1, &poses, n_agents, A_agent, 0ull);
+static int sense_prep_launch(dv_ctx* c, const PoseSet& poses, int n_agents, int A_agent, const PathErrArgs* path_err = nullptr) {
+    return launch_patch_prep(c, 1, &poses, n_agents, A_agent, 0ull, path_err);
 }
 
 static int check_sense_args(dv_ctx* c, int A) {
@@ -1436,6 +1439,61 @@ extern "C" int dv_sense_step(dv_ctx* c, double x, double y, const double* angles
     rc = enqueue_step(c, flags, scene_fam != nullptr);
     if (rc) return rc;
     return wait_step(c, result, scene_fam);
+}
+
+constexpr int kErrRing = 8;             // answers of the error metrics that may be outstanding
+// Arguments of one error-metric computation; takes the next sequence number of the answer ring.
+static PathErrArgs path_err_args(dv_ctx* c, double x, double y, double reach) {
+    PathErrArgs pe{};
+    const unsigned long long seq = ++c->err_enq;
+    long long nb = (c->n_path + 255) / 256;
+    if (nb > 512) nb = 512;
+    pe.xy = c->d_path; pe.n = (long long)c->n_path; pe.x = x; pe.y = y; pe.reach = reach; pe.cover = c->d_cover; pe.st = c->d_errstate;
+    pe.out = c->d_errout + (seq % kErrRing); pe.seq = seq; pe.nblk = (int)nb;
+    return pe;
+}
+
+// One agent step's device work and device-side book-keeping in one call (include/dejavu.h: dv_agent_step).
+extern "C" int dv_agent_step(dv_ctx* c, double x, double y, double angle, const double* offsets, int A, int do_error, double ex,
+                             double ey, double reach, double* angle_fam, int32_t* best_heading, double* nearest, int32_t* have_nearest) {
+    int rc = check_sense_args(c, A);
+    if (rc) return rc;
+    if (!offsets || !angle_fam || !best_heading || !nearest || !have_nearest) return fail(c, DV_ERR_INVALID, "dv_agent_step: NULL argument");
+    *have_nearest = 0;
+    if (do_error && c->n_path < 1) return fail(c, DV_ERR_STATE, "no training path set (dv_set_training_path)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->err_enq > c->err_deq) {                                     // asked for a step ago: there by now
+        rc = dv_path_error_wait(c, nearest);
+        if (rc) return rc;
+        *have_nearest = 1;
+    }
+    const double two_pi = 2.0 * M_PI;
+    PoseSet poses;
+    for (int a = 0; a < A; ++a) {
+        double m = std::fmod(angle + offsets[a], two_pi);            // np.mod: a remainder of the divisor's sign
+        if (m != 0.0) { if (m < 0.0) m += two_pi; } else m = 0.0;
+        poses.p[a] = make_pose(x, y, m);
+    }
+    for (int a = A; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
+    // the metrics of (ex, ey) ride in the preparation launch: blocks behind its own (no launch, no second stream)
+    PathErrArgs pe{};
+    if (do_error) {
+        if (c->err_enq - c->err_deq >= (unsigned long long)kErrRing)
+            return fail(c, DV_ERR_STATE, "%d path-error answers outstanding: collect them with dv_path_error_wait", kErrRing);
+        if (!c->err_on_main) { HIP_TRY(c, hipStreamSynchronize(c->aux_stream)); c->err_on_main = true; }   // (shared d_errstate)
+        pe = path_err_args(c, ex, ey, reach);
+    }
+    rc = sense_prep_launch(c, poses, 1, A, do_error ? &pe : nullptr);
+    if (rc) return rc;
+    rc = enqueue_step(c, 0, false);
+    if (rc) return rc;
+    rc = finish_pass(c);
+    if (rc) return rc;
+    if (c->h_result[0].flags & kResSenseError)
+        return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)");
+    memcpy(angle_fam, c->h_result[0].angle_fam, (size_t)A * sizeof(double));
+    *best_heading = c->h_result[0].best_heading;
+    return DV_OK;
 }
 
 extern "C" int dv_set_library_from_poses(dv_ctx* c, const double* x, const double* y, const double* angle, int64_t n,
@@ -2598,7 +2656,6 @@ extern "C" int dv_score(dv_ctx* c, const uint8_t* patch, double* fambuf) {
 }
 
 // ------------------------------------------------------------------ error / coverage metrics
-constexpr int kErrRing = 8;
 
 extern "C" int dv_set_training_path(dv_ctx* c, const double* xy, int64_t n) {
     if (!c) return DV_ERR_INVALID;
@@ -2633,12 +2690,11 @@ extern "C" int dv_path_error_enqueue(dv_ctx* c, double x, double y, double reach
     if (c->err_enq - c->err_deq >= (unsigned long long)kErrRing)
         return fail(c, DV_ERR_STATE, "%d path-error answers outstanding: collect them with dv_path_error_wait", kErrRing);
     HIP_TRY(c, hipSetDevice(c->device));
-    const unsigned long long seq = ++c->err_enq;
-    long long nb = (c->n_path + 255) / 256;
-    if (nb > 512) nb = 512;
     // on its own stream: the answer is collected a step later (dv_path_error_wait), so it runs beside the next step's kernels
-    hipLaunchKernelGGL(k_path_error, dim3((unsigned)nb), dim3(256), 0, c->aux_stream, c->d_path, (long long)c->n_path, x, y, reach,
-                       c->d_cover, c->d_errstate, c->d_errout + (seq % kErrRing), seq);
+    // (the two forms are never in flight together -- they share d_errstate: a context's steps are either dv_agent_step's or not)
+    if (c->err_on_main) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->err_on_main = false; }
+    const PathErrArgs pe = path_err_args(c, x, y, reach);
+    hipLaunchKernelGGL(k_path_error, dim3((unsigned)pe.nblk), dim3(256), 0, c->aux_stream, pe);
     HIP_TRY(c, hipGetLastError());
     return DV_OK;
 }
@@ -2659,6 +2715,7 @@ extern "C" int dv_path_error_wait(dv_ctx* c, double* nearest) {
     if (!seen) {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (*word != seq) return fail(c, DV_ERR_STATE, "the path-error answer never arrived");
     }
     std::atomic_thread_fence(std::memory_order_acquire);

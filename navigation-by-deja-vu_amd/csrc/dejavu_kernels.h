@@ -2382,6 +2382,74 @@ struct PrepBits {
     unsigned ok[kMaxHues + 1][8];             // bit v of plane pl: patch byte v has fp4 coefficients (on a level, or outside the range)
 };
 // The headings' poses travel as a kernel argument (64 x 32 bytes): no host-to-device copy on the step's path.
+// ------------------------------------------------------------------ error / coverage metrics of the agent
+// update_error of the reference (navsim/NavBySceneFamiliarity.py:252-276) for one position: the distance to every
+// training point in the reference's double arithmetic (delta*delta summed, sqrt; no contraction), its minimum, and
+// the coverage marks `dist <= reach` (the reference ORs them in only when the minimum is within reach, which is the
+// same set: no distance is within reach unless the smallest is).  The last block to arrive hands {nearest, seq} to the
+// host through mapped memory.  Off the step's critical path: the host collects the answer one step later.
+struct PathErrState { unsigned long long minkey; unsigned ticket; unsigned pad; };
+struct alignas(16) PathErrOut { double nearest; unsigned long long seq; };
+
+// Block `blk` of `nblk` (256 threads each) of the computation: its own kernel (k_path_error), or the blocks behind the preparation
+// blocks of k_patch_prep when an agent step asks for both in one launch (dv_agent_step).
+struct PathErrArgs {
+    const double* xy; long long n; double x, y, reach; unsigned char* cover; PathErrState* st; PathErrOut* out; unsigned long long seq;
+    int nblk;                         // 0: nothing asked for
+};
+__device__ __forceinline__ void path_error_block(const PathErrArgs& pe, int blk) {
+    const double* __restrict__ xy = pe.xy;
+    const long long n = pe.n;
+    const double x = pe.x, y = pe.y, reach = pe.reach;
+    unsigned char* __restrict__ cover = pe.cover;
+    PathErrState* __restrict__ st = pe.st;
+    PathErrOut* __restrict__ out = pe.out;
+    const unsigned long long seq = pe.seq;
+    __shared__ unsigned long long wmin[4];
+    unsigned long long key = ~0ull;
+    for (long long i = (long long)blk * blockDim.x + threadIdx.x; i < n; i += (long long)pe.nblk * blockDim.x) {
+        double dx = xy[2 * i] - x, dy = xy[2 * i + 1] - y;
+        dx *= dx;
+        dy *= dy;
+        const double dist = sqrt(dx + dy);
+        if (dist <= reach) cover[i] = 1;
+        const unsigned long long k = (unsigned long long)__double_as_longlong(dist);     // dist >= 0: bit order = value order
+        key = k < key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmin[0];
+        for (int i = 1; i < 4; ++i) m = wmin[i] < m ? wmin[i] : m;
+        // The block's minimum and its arrival are agent-scope atomics, the minimum a RETURNING one waited for before the ticket is
+        // drawn (performed at the device's coherence point by then); the last block reads the minimum with an agent-scope atomic load.
+        // "8-byte agent atomics both sides" of MI355X_MICROARCH.md's valid hand-off forms -- the two __threadfence() that stood here
+        // (an L2 write-back and an L1 invalidate each, in every block) cost the agent's step 3-4 us once these blocks ride in the
+        // preparation launch (dv_agent_step); nothing else is handed over (the coverage marks are read after a stream wait).
+        const unsigned long long before = __hip_atomic_fetch_min(&st->minkey, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");
+        if (__hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)pe.nblk - 1u) {
+            const unsigned long long all = __hip_atomic_load(&st->minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->minkey, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // answer and sequence number leave in ONE 16-byte store to the mapped host record (one PCIe write: the host,
+            // which polls the sequence word and then reads the answer, can never pair a new number with an old answer),
+            // so no system-scope fence sits between them
+            v4u_t rec;
+            rec.x = (unsigned)all; rec.y = (unsigned)(all >> 32); rec.z = (unsigned)seq; rec.w = (unsigned)(seq >> 32);
+            *reinterpret_cast<v4u_t*>(out) = rec;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_path_error(PathErrArgs pe) { path_error_block(pe, (int)blockIdx.x); }
+
 struct PoseSet { Pose p[kMaxHeadings]; };
 
 template <int MODE>
@@ -2389,7 +2457,10 @@ __global__ void __launch_bounds__(256)
 k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A, SensorCfg g, const unsigned char* __restrict__ lut,
              unsigned char* __restrict__ raw, unsigned* __restrict__ prep, LibCfg c, int APAD, PrepAcc* __restrict__ acc,
              PrepAcc* __restrict__ next, int A_agent, PrepBits pb, unsigned long long seed, uint4* __restrict__ coef,
-             uint4* __restrict__ coef4, int what) {
+             uint4* __restrict__ coef4, int what, PathErrArgs pe) {
+    // blocks behind the preparation's own: the agent's error / coverage metrics of the position the last step ended at (dv_agent_step:
+    // one launch for both -- a launch of its own cost the step ~4 us of host time, on a second stream more)
+    if (pe.nblk > 0 && (int)blockIdx.x >= (int)gridDim.x - pe.nblk) { path_error_block(pe, (int)blockIdx.x - ((int)gridDim.x - pe.nblk)); return; }
     // what: bit 0 = the byte path's operand dwords (prep) -- 393 000 four-byte stores into lines shared by 32 headings at 128x128 x 32
     // headings, which a step on the matrix cores never reads: launch_patch_prep leaves them out there, and launch_int_scoring has
     // them written from the raw bytes (MODE 0, what = 1) should a byte kernel run on these patches after all;
@@ -3946,55 +4017,6 @@ k_sad_mfma_dual(const uint4* __restrict__ btiles, const uint4* __restrict__ ftil
     }
 }
 
-// ------------------------------------------------------------------ error / coverage metrics of the agent
-// update_error of the reference (navsim/NavBySceneFamiliarity.py:252-276) for one position: the distance to every
-// training point in the reference's double arithmetic (delta*delta summed, sqrt; no contraction), its minimum, and
-// the coverage marks `dist <= reach` (the reference ORs them in only when the minimum is within reach, which is the
-// same set: no distance is within reach unless the smallest is).  The last block to arrive hands {nearest, seq} to the
-// host through mapped memory.  Off the step's critical path: the host collects the answer one step later.
-struct PathErrState { unsigned long long minkey; unsigned ticket; unsigned pad; };
-struct alignas(16) PathErrOut { double nearest; unsigned long long seq; };
-
-__global__ void __launch_bounds__(256)
-k_path_error(const double* __restrict__ xy, long long n, double x, double y, double reach, unsigned char* __restrict__ cover,
-             PathErrState* __restrict__ st, PathErrOut* __restrict__ out, unsigned long long seq) {
-    __shared__ unsigned long long wmin[4];
-    unsigned long long key = ~0ull;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        double dx = xy[2 * i] - x, dy = xy[2 * i + 1] - y;
-        dx *= dx;
-        dy *= dy;
-        const double dist = sqrt(dx + dy);
-        if (dist <= reach) cover[i] = 1;
-        const unsigned long long k = (unsigned long long)__double_as_longlong(dist);     // dist >= 0: bit order = value order
-        key = k < key ? k : key;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o);
-        key = other < key ? other : key;
-    }
-    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long m = wmin[0];
-        for (int i = 1; i < 4; ++i) m = wmin[i] < m ? wmin[i] : m;
-        atomicMin(&st->minkey, m);
-        __threadfence();
-        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
-            __threadfence();
-            const unsigned long long all = __hip_atomic_load(&st->minkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&st->minkey, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // answer and sequence number leave in ONE 16-byte store to the mapped host record (one PCIe write: the host,
-            // which polls the sequence word and then reads the answer, can never pair a new number with an old answer),
-            // so no system-scope fence sits between them
-            v4u_t rec;
-            rec.x = (unsigned)all; rec.y = (unsigned)(all >> 32); rec.z = (unsigned)seq; rec.w = (unsigned)(seq >> 32);
-            *reinterpret_cast<v4u_t*>(out) = rec;
-        }
-    }
-}
 
 // Streaming-read microbenchmark: the scoring kernels' access pattern without their arithmetic -- every wave pulls 1-KB
 // rows straight into LDS by non-temporal LDS-DMA, sixteen rows in flight per wave, eight waves per workgroup, one workgroup

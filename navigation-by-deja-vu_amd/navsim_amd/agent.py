@@ -159,7 +159,9 @@ class NavBySceneFamiliarity(object):
         extent = self.sensor_dimensions * self.sensor_pixel_dimensions      # landscape px, (w, h)
         assert np.all(extent % 2 == 0)
         self._sensor_r = np.max(extent / 2)
+        self._bounds = None
         self._roundbuf = np.empty((self.sensor_dimensions[1], self.sensor_dimensions[0]), dtype=np.float32)
+        self._end_buf = np.empty(2, dtype=np.float64)
         self._landscape_glimpse_buf = np.empty((extent[1], extent[0], 3), dtype=np.uint8)
         self.n_sensor_pixels = np.prod(self.sensor_dimensions)
 
@@ -203,10 +205,12 @@ class NavBySceneFamiliarity(object):
         return lut
 
     def _check_bounds(self, position):
-        r = self._sensor_r
-        ldims = self.landscape.shape
-        if (position[0] <= r) or (position[1] <= r) or \
-           (position[0] >= ldims[1] - r) or (position[1] >= ldims[0] - r):
+        b = self._bounds
+        if b is None:                          # the four limits of :153-158 as Python floats (same comparisons, no NumPy scalars per step)
+            r = self._sensor_r
+            ldims = self.landscape.shape
+            b = self._bounds = (float(r), float(ldims[1] - r), float(ldims[0] - r))
+        if (position[0] <= b[0]) or (position[1] <= b[0]) or (position[0] >= b[1]) or (position[1] >= b[2]):
             raise OutOfLandscapeBoundsException()
 
     # ---- training (:118-148) -------------------------------------------------------------------
@@ -343,6 +347,7 @@ class NavBySceneFamiliarity(object):
         self._navigation_error = 0.0
         self._n_navigation_error = 0
         self._pending_errors = 0
+        self._error_pos = None                 # a position whose metrics are still to be asked for (the lean step defers them by one call)
         self._host_coverage = None
         if self.training_path is not None:
             self._host_coverage = np.zeros(len(self.training_path), dtype=bool)
@@ -353,14 +358,24 @@ class NavBySceneFamiliarity(object):
     # (dv_path_error_enqueue) and collects the answer one step later, or when a metric is read -- except with a finite
     # max_distance_to_training_path, where the reference may stop the run inside update_error and the answer is
     # awaited at once.  Every number is the reference's double arithmetic; only the moment it reaches the host moves.
+    def _flush_error_pos(self):
+        if self._error_pos is not None:
+            self._engine.path_error_enqueue(self._error_pos[0], self._error_pos[1], self.coverage_threshold_factor * self.step_size)
+            self._error_pos = None
+            self._pending_errors += 1
+
+    def _take_error(self, nearest):
+        if nearest > self.max_distance_to_training_path:
+            raise TooFarFromTrainingPathException()
+        self._navigation_error += nearest * nearest
+        self._n_navigation_error += 1
+
     def _collect_errors(self, keep=0):
+        self._flush_error_pos()
         while self._pending_errors > keep:
             nearest = self._engine.path_error_wait()
             self._pending_errors -= 1
-            if nearest > self.max_distance_to_training_path:
-                raise TooFarFromTrainingPathException()
-            self._navigation_error += nearest * nearest
-            self._n_navigation_error += 1
+            self._take_error(nearest)
 
     @property
     def _coverage_array(self):
@@ -406,7 +421,7 @@ class NavBySceneFamiliarity(object):
     def update_error(self):
         self.navigated_for_frames += 1
         if getattr(self, "_metrics_on_device", False):
-            self._collect_errors()                               # the previous step's answer: ready by now
+            self._collect_errors()                               # the previous step's answer: ready by now (and a deferred position first)
             self._engine.path_error_enqueue(self.position[0], self.position[1],
                                             self.coverage_threshold_factor * self.step_size)
             self._pending_errors += 1
@@ -433,6 +448,7 @@ class NavBySceneFamiliarity(object):
 
         func = self._familiarity_func
         engine = getattr(func, "engine", None)
+        defer_error = False
         if engine is not None and str(getattr(func, "metric", "")).startswith("ssd"):
             self._step_ssd(func, engine, position)
             best_idex = self.last_scored_idex
@@ -442,7 +458,23 @@ class NavBySceneFamiliarity(object):
                 if engine is self._engine:
                     # patches are sensed on the GPU, straight into the scoring kernel's operand layout
                     self._check_bounds(position)
-                    if not self.track_scene_familiarity and hasattr(engine, "sense_step_into"):
+                    if not self.track_scene_familiarity and hasattr(engine, "agent_step") and self.n_test_angles <= 64:
+                        # the lean form of the same device step (dv_agent_step): ONE call does the sensing, the scoring and the
+                        # device side of the error metrics -- the answer asked for at the last step is collected, the position
+                        # the last step ended at is handed in -- and writes the per-heading maxima straight into angle_familiarity
+                        epos = self._error_pos
+                        best_idex, nearest = engine.agent_step(position[0], position[1], self.angle, self.angle_offsets,
+                                                               self.angle_familiarity, epos,
+                                                               self.coverage_threshold_factor * self.step_size)
+                        if epos is not None:
+                            self._error_pos = None
+                            self._pending_errors += 1
+                        if nearest is not None:
+                            self._pending_errors -= 1
+                            self._take_error(nearest)
+                        res = None
+                        defer_error = self._metrics_on_device and not math.isfinite(self.max_distance_to_training_path)
+                    elif not self.track_scene_familiarity and hasattr(engine, "sense_step_into"):
                         # (the same device step through the engine's lean binding: no per-step record, views or dictionary)
                         best_idex = engine.sense_step_into(position[0], position[1], self.angle, self.angle_offsets,
                                                            self.angle_familiarity)
@@ -483,7 +515,7 @@ class NavBySceneFamiliarity(object):
                 self.angle_familiarity[a_idex] = np.max(temp_fam)
             best_idex = np.argmax(self.angle_familiarity)
 
-        self._move(best_idex, fake)
+        self._move(best_idex, fake, defer_error)
 
     def _step_ssd(self, func, engine, position):
         """The heading loop (:289-315) with the SSD plug-in (util.ssd_familiarity): ONE device step -- sense, score on the matrix
@@ -514,7 +546,7 @@ class NavBySceneFamiliarity(object):
             self._scene_is_inf = True
         self.last_scored_idex = res["best_idex"]
 
-    def _move(self, best_idex, fake=False):
+    def _move(self, best_idex, fake=False, defer_error=False):
         """The part of a step after the heading is chosen (:316-329): turn, advance, book-keeping, stop conditions."""
         position = self.position
         self.step_familiarity = self.angle_familiarity[best_idex]
@@ -525,9 +557,18 @@ class NavBySceneFamiliarity(object):
         self.last_best_idex = int(best_idex)
 
         if not fake:
-            self.update_error()
-            # np.linalg.norm of the 2-vector (:325-326) without its wrapper: the same dot product, the same square root
-            d = self.training_path[-1] - self.position
+            if defer_error:
+                # the lean step: this position's metrics are asked for by the NEXT step's device call (or when a metric is read)
+                self.navigated_for_frames += 1
+                self._flush_error_pos()
+                self._error_pos = self.position
+            else:
+                self.update_error()
+            # np.linalg.norm of the 2-vector (:325-326) without its wrapper: the same subtraction, dot product and square root,
+            # in one small buffer kept for the agent's lifetime
+            d, end = self._end_buf, self.training_path[-1]
+            d[0] = end[0] - self.position[0]
+            d[1] = end[1] - self.position[1]
             if math.sqrt(d.dot(d)) <= self.threshold_factor * self.step_size:
                 raise ReachedEndOfTrainingPathException()
 

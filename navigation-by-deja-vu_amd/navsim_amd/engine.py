@@ -25,6 +25,7 @@ class FamiliarityEngine(object):
         self.n_views = 0
         self.shape = None
         self._step_state = None                  # sense_step_into's result record and angle buffer
+        self._agent_state = None                 # agent_step's argument buffers
         self._err_out = ctypes.c_double()        # path_error_wait's answer
         self._err_out_ref = ctypes.byref(self._err_out)
         if exact:
@@ -203,6 +204,28 @@ class FamiliarityEngine(object):
             self._check_sense(rc, "dv_sense_step")
         out_fam[:] = fam
         return res.best_heading
+
+    def agent_step(self, x, y, angle, offsets, out_fam, error_pos, reach):
+        """dv_agent_step: one agent step's device work and device-side book-keeping in one call.  The headings (angle + offsets)
+        mod 2 pi are sensed at (x, y) and scored, out_fam (float64[A], C-contiguous: the agent's angle_familiarity) is written in
+        place; error_pos = (ex, ey) asks for the error metrics of that position (or None), and an outstanding answer comes back.
+        Returns (best heading, nearest distance or None)."""
+        st = self._agent_state
+        if st is None or st[0] is not offsets or st[1] is not out_fam:
+            if not (out_fam.flags.c_contiguous and out_fam.dtype == np.float64 and out_fam.shape == (len(offsets),)):
+                raise ValueError("out_fam must be a C-contiguous float64[%d]" % len(offsets))
+            off = np.ascontiguousarray(offsets, dtype=np.float64)
+            best, nearest, have = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_int32(0)
+            st = self._agent_state = (offsets, out_fam, off, N.f64ptr(off), len(off), N.f64ptr(out_fam), best, ctypes.byref(best),
+                                      nearest, ctypes.byref(nearest), have, ctypes.byref(have))
+        _, _, _, offp, A, famp, best, bestp, nearest, nearestp, have, havep = st
+        if error_pos is None:
+            rc = self._lib.dv_agent_step(self._ctx, x, y, angle, offp, A, 0, 0.0, 0.0, 0.0, famp, bestp, nearestp, havep)
+        else:
+            rc = self._lib.dv_agent_step(self._ctx, x, y, angle, offp, A, 1, error_pos[0], error_pos[1], reach, famp, bestp, nearestp, havep)
+        if rc:
+            self._check_sense(rc, "dv_agent_step")
+        return best.value, (nearest.value if have.value else None)
 
     def sense_step_batch(self, x, y, angles, force_resolve=False):
         """Ensemble step on the device: agent i at (x[i], y[i]) looking along angles[i][0..A) -> list of result dicts."""
