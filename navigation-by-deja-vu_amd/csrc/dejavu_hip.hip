@@ -188,6 +188,26 @@ struct dv_ctx {
     unsigned long long* d_cand = nullptr;     // [kCandCap]
     double* d_cand_exact = nullptr;           // [kCandCap]
     int result_slot = 0;                      // first result record of the pass being enqueued (pipelined ensemble passes)
+    // Ensemble passes packed over the whole chip (run_batch): every pass of a group gets its OWN set of the per-step buffers, so that
+    // all preparations run first, the scoring kernels of consecutive passes then sit in two hardware queues and fill each other's last,
+    // partly empty round of work items (782 items on 256 workgroups: 14 run a fourth), and the folds come at the end.
+    // `extra[j - 1]` holds set j while it is not in the fields above; set 0 is the context's own.
+    struct PassSet {
+        unsigned char* raw = nullptr; uint4* coef = nullptr; uint4* coef4 = nullptr; PrepAcc* acc = nullptr; int parity = 0;
+        unsigned long long* bsum = nullptr; unsigned long long* ctmp = nullptr; StepState* state = nullptr;
+        unsigned long long* cand = nullptr; double* cand_exact = nullptr;
+        bool coef_ready = false, prep_dwords_ready = false, patches_sensed = false;
+        int A = 0, APAD = 0, n_agents = 1, A_agent = 0, fused_nb = 0;
+    };
+    static constexpr int kExtraSets = 8;
+    PassSet extra[kExtraSets];
+    int n_extra = 0;                          // extra sets allocated (at the first ensemble call on this library that wants them)
+    int cur_set = 0;                          // which set is in the fields
+    hipStream_t batch_stream = nullptr;       // the second hardware queue of the scoring kernels
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bool defer_fold = false;                  // enqueue_step: a fused pass leaves its fold to the caller (run_batch launches them last)
+    int deferred_force = 0, deferred_seq = 0; // ... with these arguments
+    int chains_env = 2;                       // DEJAVU_CHAINS=1: ensemble passes one after the other on one stream, as in round 3 (A/B)
     StepResultDev* h_result = nullptr;        // pinned, mapped: the kernels write the result record into it
     StepResultDev* d_result = nullptr;        // device-side address of h_result
     double* d_record = nullptr;               // [3 + 4*64] packed record of the last step, for device-side exchange
@@ -257,8 +277,16 @@ static int fail(dv_ctx* c, int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                             \
     } while (0)
 
+static void use_set(dv_ctx* c, int which);
 static void free_library(dv_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    use_set(c, 0);
+    for (int j = 0; j < dv_ctx::kExtraSets; ++j) {
+        dv_ctx::PassSet& a = c->extra[j];
+        F(a.raw); F(a.coef); F(a.coef4); F(a.acc); F(a.bsum); F(a.ctmp); F(a.state); F(a.cand); F(a.cand_exact);
+        a = dv_ctx::PassSet{};
+    }
+    c->n_extra = 0;
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_acc); F(c->d_one); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
     F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart); F(c->d_fprep4); F(c->d_fvnorm); F(c->d_fpnorm); F(c->d_flower);
@@ -324,6 +352,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_MIXED", c->mixed_env, 0, 1);
     env_int("DEJAVU_TUNE_ALL", c->tune_all_env, 0, 1);
     env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 1);
+    env_int("DEJAVU_CHAINS", c->chains_env, 1, 2);
     env_int("DEJAVU_TEST_FAIL_ALLOC", c->fail_alloc_env, 0, 64);
     *out = c;
     return DV_OK;
@@ -349,6 +378,9 @@ extern "C" void dv_destroy(dv_ctx* c) {
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->batch_stream) { (void)hipStreamSynchronize(c->batch_stream); (void)hipStreamDestroy(c->batch_stream); }
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1016,6 +1048,9 @@ static int ensure_direct_prep_f32(dv_ctx* c) {
 }
 
 static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene);
+static void launch_fold(dv_ctx* c, int nb, StepResultDev* outp, double* recp, int force, int seq, const unsigned long long* serr);
+static const unsigned long long* sense_err_ptr(const dv_ctx* c);
+static bool batch_pass_fuses(dv_ctx* c, int apad);
 static int wait_step(dv_ctx* c, dv_step_result* result, double* scene_fam);
 static int finish_pass(dv_ctx* c);
 static void copy_result(const dv_ctx* c, int agent, dv_step_result* result);
@@ -1359,33 +1394,153 @@ extern "C" int dv_sense_patches(dv_ctx* c, double x, double y, const double* ang
     return sense_prep_launch(c, poses, 1, A);
 }
 
-// Ensemble passes, pipelined: the passes of up to 64 agents are enqueued back to back (their scratch buffers are
-// reused in stream order; only the result records are distinct, `result_slot`), then the host collects the records.
-// A pass whose agents need the exact resolver, overflowed their candidate list or sensed past the landscape is
-// simply run again on its own through the synchronous path, which handles all of that.  `stage(first, n)` makes
-// agents [first, first + n) the resident patches.
+// The per-step buffers (and the few scalars that describe the resident patches) a pass writes, as sets that can be swapped into the
+// context's fields: set 0 is the context's own, set j > 0 lives in c->extra[j - 1] while it is not in use.
+static void swap_set(dv_ctx* c, dv_ctx::PassSet& a) {
+    std::swap(c->d_raw_patches, a.raw); std::swap(c->d_coef, a.coef); std::swap(c->d_coef4, a.coef4);
+    std::swap(c->d_acc, a.acc); std::swap(c->acc_parity, a.parity); std::swap(c->d_bsum, a.bsum);
+    std::swap(c->d_ctmp, a.ctmp); std::swap(c->d_state, a.state); std::swap(c->d_cand, a.cand); std::swap(c->d_cand_exact, a.cand_exact);
+    std::swap(c->coef_ready, a.coef_ready); std::swap(c->prep_dwords_ready, a.prep_dwords_ready); std::swap(c->patches_sensed, a.patches_sensed);
+    std::swap(c->A, a.A); std::swap(c->APAD, a.APAD); std::swap(c->n_agents, a.n_agents); std::swap(c->A_agent, a.A_agent);
+    std::swap(c->fused_nb, a.fused_nb);
+}
+static void use_set(dv_ctx* c, int which) {
+    if (which == c->cur_set) return;
+    if (c->cur_set != 0) swap_set(c, c->extra[c->cur_set - 1]);       // home first
+    if (which != 0) swap_set(c, c->extra[which - 1]);
+    c->cur_set = which;
+}
+
+// At least `want` extra sets (<= kExtraSets), the second stream and the two events; returns how many sets there are (0: the passes run
+// one after the other as before).  Allocates at the first ensemble call on a library that wants them, never inside a single step.
+static int ensure_extra_sets(dv_ctx* c, int want) {
+    if (c->chains_env < 2 || c->metric != 0 || !c->bits_ok || c->mixed || c->stream != c->own_stream || c->cur_set != 0) return 0;
+    if (want > dv_ctx::kExtraSets) want = dv_ctx::kExtraSets;
+    if (!c->batch_stream) {
+        // a stream of ANOTHER priority: the runtime maps streams of one priority onto a few hardware queues round-robin, and two
+        // streams that share a queue run their kernels one after the other (rocprofv3 showed both on queue 4); queues of different
+        // priority classes are distinct
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&c->batch_stream, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); c->batch_stream = nullptr; return 0; }
+    }
+    if (!c->ev_a && hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->ev_a = nullptr; return 0; }
+    if (!c->ev_b && hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->ev_b = nullptr; return 0; }
+    const LibCfg& g = c->cfg;
+    const size_t nkt = (size_t)(c->bcfg.NK[0] + c->bcfg.NK[1]);
+    while (c->n_extra < want) {
+        dv_ctx::PassSet& a = c->extra[c->n_extra];
+        bool ok = hipMalloc(&a.raw, (size_t)kMaxHeadings * g.P * 3) == hipSuccess &&
+                  hipMalloc(&a.coef, (size_t)2 * nkt * 8192) == hipSuccess &&
+                  (!c->fp4_ok || hipMalloc(&a.coef4, (size_t)2 * nkt * 4096) == hipSuccess) &&
+                  hipMalloc(&a.acc, 2 * sizeof(PrepAcc)) == hipSuccess &&
+                  hipMalloc(&a.bsum, (size_t)std::max<long long>((g.F + 255) / 256, 256) * 2 * kMaxHeadings * sizeof(unsigned long long)) == hipSuccess &&
+                  hipMalloc(&a.ctmp, (size_t)kMaxHeadings * kTmpCap * 2 * sizeof(unsigned long long)) == hipSuccess &&
+                  hipMalloc(&a.state, kMaxHeadings * sizeof(StepState)) == hipSuccess &&
+                  hipMalloc(&a.cand, (size_t)kMaxHeadings * kCandCap * sizeof(unsigned long long)) == hipSuccess &&
+                  hipMalloc(&a.cand_exact, (size_t)kMaxHeadings * kCandCap * sizeof(double)) == hipSuccess;
+        if (ok)          // as the first set is initialised (alloc_library, build_bit_planes): cleared constants and state, zeroed images
+            ok = hipMemsetAsync(a.acc, 0, 2 * sizeof(PrepAcc), c->stream) == hipSuccess &&
+                 hipMemsetAsync(a.state, 0, kMaxHeadings * sizeof(StepState), c->stream) == hipSuccess &&
+                 hipMemsetAsync(a.coef, 0, (size_t)2 * nkt * 8192, c->stream) == hipSuccess &&
+                 (!c->fp4_ok || hipMemsetAsync(a.coef4, 0, (size_t)2 * nkt * 4096, c->stream) == hipSuccess) &&
+                 hipStreamSynchronize(c->stream) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+            F(a.raw); F(a.coef); F(a.coef4); F(a.acc); F(a.bsum); F(a.ctmp); F(a.state); F(a.cand); F(a.cand_exact);
+            a = dv_ctx::PassSet{};
+            break;
+        }
+        ++c->n_extra;
+    }
+    return c->n_extra;
+}
+
+// Ensemble passes: the passes of up to 64 agents each take a result record of their own (`result_slot`) and the host collects the
+// records afterwards.  The first pass runs on its own (it shows whether this library's passes finish their scores themselves: a fused
+// pass writes nothing shared).  If so, the others go in groups of up to kExtraSets passes, each with its own set of per-step buffers:
+//   1. every preparation of the group, on the context's stream;
+//   2. the scoring kernels, alternating between the context's stream and a second one of another priority (= two hardware queues):
+//      a kernel is 256 persistent workgroups with one CU each, so the next pass's workgroups move in as the last pass's finish their
+//      third round -- the fourth, which only 14 of 256 run, no longer holds the chip (and no small kernel sits between two passes);
+//   3. the folds (one small workgroup per agent and pass), last.
+// A pass whose agents need the exact resolver, overflowed their candidate list or sensed past the landscape is simply run again on
+// its own through the synchronous path, which handles all of that.  `stage(first, n)` makes agents [first, first + n) the resident
+// patches.
 template <class Stage>
 static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_result* results, Stage stage) {
     struct Pass { int first, n, seq, slot; };
     const int per_pass = kMaxHeadings / A;
     int rc = DV_OK;
+    const int full_total = per_pass * A;                                // resident headings of a full pass
+    const int full_apad = full_total <= 8 ? 8 : (full_total <= 16 ? 16 : (full_total <= 32 ? 32 : 64));
+    bool first_pass_seen = false;
+    auto sync_both = [&]() { (void)hipStreamSynchronize(c->stream); if (c->batch_stream) (void)hipStreamSynchronize(c->batch_stream); };
     for (int sb = 0; sb < n_agents && rc == DV_OK; sb += kMaxHeadings) {
         const int cnt = (n_agents - sb < kMaxHeadings) ? n_agents - sb : kMaxHeadings;
         std::vector<Pass> passes;
-        for (int first = 0; first < cnt && rc == DV_OK; first += per_pass) {
-            const int n = (cnt - first < per_pass) ? cnt - first : per_pass;
-            rc = stage(sb + first, n);
-            if (rc) break;
-            c->result_slot = first;
-            rc = enqueue_step(c, flags, false);
-            passes.push_back(Pass{sb + first, n, c->seq, first});
+        std::vector<std::pair<int, int>> todo;                           // (first agent of the 64, agents) of every pass of this 64
+        for (int first = 0; first < cnt; first += per_pass) todo.push_back({first, (cnt - first < per_pass) ? cnt - first : per_pass});
+        size_t k = 0;
+        auto classic = [&](const std::pair<int, int>& p) -> int {        // preparation, scoring, fold on the context's stream
+            int r2 = stage(sb + p.first, p.second);
+            if (r2) return r2;
+            c->result_slot = p.first;
+            r2 = enqueue_step(c, flags, false);
+            passes.push_back(Pass{sb + p.first, p.second, c->seq, p.first});
+            return r2;
+        };
+        if (!first_pass_seen && !batch_pass_fuses(c, full_apad) && k < todo.size()) {
+            rc = classic(todo[k++]);               // (an untimed heading class: this pass times the kernel forms; the rest may then group)
+            first_pass_seen = true;
         }
+        while (rc == DV_OK && k < todo.size()) {
+            // passes of the full size only (a shorter last pass may take another kernel form: on its own, afterwards)
+            int left = 0;
+            while (k + (size_t)left < todo.size() && todo[k + (size_t)left].second == per_pass) ++left;
+            const int nset = (left > 1 && batch_pass_fuses(c, full_apad)) ? ensure_extra_sets(c, left) : 0;
+            if (nset < 2) { rc = classic(todo[k++]); continue; }
+            const int ng = left < nset ? left : nset;
+            const int force = (flags & DV_STEP_FORCE_RESOLVE) ? 1 : 0;
+            std::vector<int> seqs((size_t)ng, 0);
+            // Pass j of the group lives on stream j & 1 from its preparation to its fold: two chains that share nothing but the
+            // library, each [its preparations][its scoring kernels][its folds] -- no event between the streams
+            auto on = [&](int j) { use_set(c, j + 1); c->stream = (j & 1) ? c->batch_stream : c->own_stream; };
+            for (int j = 0; j < ng && rc == DV_OK; ++j) { on(j); rc = stage(sb + todo[k + j].first, todo[k + j].second); }
+            c->defer_fold = true;
+            for (int j = 0; j < ng && rc == DV_OK; ++j) {
+                on(j);
+                c->result_slot = todo[k + j].first;
+                rc = enqueue_step(c, flags, false);
+                if (rc == DV_OK && !c->epilogue_fused) rc = fail(c, DV_ERR_STATE, "internal: an ensemble pass of a fused library did not fuse");
+                seqs[(size_t)j] = c->deferred_seq;
+            }
+            c->defer_fold = false;
+            for (int j = 0; j < ng && rc == DV_OK; ++j) {
+                on(j);
+                const int slot = todo[k + j].first;
+                launch_fold(c, c->fused_nb, c->d_result + slot, c->d_record + (size_t)slot * (3 + 4 * kMaxHeadings), force, seqs[(size_t)j],
+                            sense_err_ptr(c));
+                if (hipGetLastError() != hipSuccess) rc = fail(c, DV_ERR_HIP, "k_fold launch failed");
+                passes.push_back(Pass{sb + slot, todo[k + j].second, seqs[(size_t)j], slot});
+            }
+            c->stream = c->own_stream;
+            use_set(c, 0);
+            k += (size_t)ng;
+        }
+        c->stream = c->own_stream;
+        use_set(c, 0);
+        c->defer_fold = false;
         c->result_slot = 0;
-        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+        if (rc) { sync_both(); return rc; }
         bool polled = c->spin_wait != 0;
         for (const Pass& p : passes)
             if (polled && !spin_for_records(c, p.slot, p.n, A, p.seq)) polled = false;
-        if (!polled) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!polled) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->batch_stream) HIP_TRY(c, hipStreamSynchronize(c->batch_stream));
+        }
         std::vector<Pass> again;
         for (const Pass& p : passes) {
             unsigned bad = 0;
@@ -1857,26 +2012,29 @@ static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
 // Work items of k_sad_mfma_dual = (chunk of K-steps, range of at most 8*TILES view groups of 32).  Two view groups per wave
 // halve the coefficient traffic (every A operand serves both) once the library is large enough to keep every CU busy that
 // way; very small libraries also cut the K-steps into chunks so that there are about as many items as CUs.
-static void launch_mfma(dv_ctx* c, int has_hs) {
+struct MfmaPlan { bool use_lc, two_tiles; int tiles, nchunk; };
+// How a matrix-core pass over the resident library is cut for `apad` resident headings (what launch_mfma launches; run_batch asks
+// beforehand whether its passes will finish their scores themselves: one chunk).
+static MfmaPlan mfma_plan(dv_ctx* c, int apad, bool fuse_request) {
+    MfmaPlan p{};
     const long long G32 = c->cfg.Fpad / 32;
     // two view groups per wave once there are about 1.25 such items per CU (200 000 views x 128x128 x 32 headings, 391 items:
     // 0.432 ms with two, 0.474 ms with one; 500 000 views: two)
     // DEJAVU_LC (A/B): 0 = every wave loads and multiplies (sad_ring_fp4); 1 = loader and consumer waves, stage of 4 K-steps, ring of 3
     // (sad_lc_fp4; ranges of 8 view groups whatever the library's size); 2 = the same with stages of 2 K-steps, ring of 5
-    const int lc = c->lc_env;
-    const bool use_lc = lc != 0 && c->fp4_ok && !c->mfma_tiles_env;
-    int tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (use_lc ? 1 : (G32 >= 16ll * 320 ? 2 : 1));
+    p.use_lc = c->lc_env != 0 && c->fp4_ok && !c->mfma_tiles_env;
+    p.tiles = c->mfma_tiles_env ? c->mfma_tiles_env : (p.use_lc ? 1 : (G32 >= 16ll * 320 ? 2 : 1));
     // (never by default a variant the compiler could only build with scratch: its fused form keeps a few item-level pointers
     // there in this build -- tests/test_host_logic.py:test_shipped_scoring_kernels_use_no_scratch lists what is guarded)
-    if (tiles == 2 && !c->mfma_tiles_env) {
+    if (p.tiles == 2 && !c->mfma_tiles_env) {
         static const bool spills[2] = {kernel_uses_scratch((const void*)k_sad_mfma_dual<1, 3, 2, 3, 2, false, 0, 3, false, 1>),
                                        kernel_uses_scratch((const void*)k_sad_mfma_dual<1, 3, 2, 3, 2, true, 0, 3, false, 1>)};
-        const bool will_fuse = c->fuse_request && c->fuse_env && !c->mfma_chunk_env && item_groups(G32, 16) >= 160;
-        if (spills[will_fuse ? 1 : 0]) tiles = 1;
+        const bool will_fuse = fuse_request && c->fuse_env && !c->mfma_chunk_env && item_groups(G32, 16) >= 160;
+        if (spills[will_fuse ? 1 : 0]) p.tiles = 1;
     }
     // DEJAVU_HT=1 (A/B): 64 resident headings as two passes over the library instead of two heading tiles per view group in one
-    const bool two_tiles = use_lc && c->APAD == 64 && c->ht_env == 2;
-    const long long GQ = item_groups(G32, two_tiles ? 4 : 8 * tiles);
+    p.two_tiles = p.use_lc && apad == 64 && c->ht_env == 2;
+    const long long GQ = item_groups(G32, p.two_tiles ? 4 : 8 * p.tiles);
     int nchunk = 1;
     if (c->mfma_chunk_env) {
         nchunk = c->mfma_chunk_env;
@@ -1889,6 +2047,24 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     while (nchunk > 1 && nk_min / nchunk < 4) --nchunk;                  // keep a few K-steps per chunk
     if (nchunk > c->nchunk_cap) nchunk = c->nchunk_cap;
     if (nchunk < 1 || c->mixed) nchunk = 1;                              // (mixed layout: the byte pass shares the one-chunk rows of the partial sums)
+    p.nchunk = nchunk;
+    return p;
+}
+
+// An ensemble pass of `apad` resident headings would finish its scores inside the scoring kernel (fused epilogue: nothing shared is
+// written, so passes may run beside each other).  The shape must be known already (timed or forced): an untimed class says no.
+static bool batch_pass_fuses(dv_ctx* c, int apad) {
+    if (c->metric != 0 || c->exact || c->cfg.generic || !c->bits_ok || c->mixed || !c->fuse_env) return false;
+    const int cls = apad_class(apad);
+    const int shape = c->shape_env ? c->shape_env : c->tuned_shape[cls];
+    if (shape != 6) return false;
+    return mfma_plan(c, apad, true).nchunk == 1;
+}
+
+static void launch_mfma(dv_ctx* c, int has_hs) {
+    const MfmaPlan plan = mfma_plan(c, c->APAD, c->fuse_request);
+    const bool use_lc = plan.use_lc, two_tiles = plan.two_tiles;
+    const int tiles = plan.tiles, nchunk = plan.nchunk, lc = c->lc_env;
     c->nchunk = nchunk;
     // <int8 stage, ring | fp4 stage, ring (thermometer rows) | fp4 stage, ring (code rows), view groups per wave>.  Measured in
     // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
@@ -2267,6 +2443,9 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result + c->result_slot,
                            c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta, sense_err_ptr(c), 0,
                            ++c->seq);
+    } else if (c->epilogue_fused && c->defer_fold) {
+        c->deferred_force = force;                           // run_batch launches this pass's fold behind the group's scoring kernels
+        c->deferred_seq = ++c->seq;
     } else if (c->epilogue_fused) {
         launch_fold(c, c->fused_nb, c->d_result + c->result_slot, c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), force, ++c->seq,
                     sense_err_ptr(c));
