@@ -102,6 +102,7 @@ struct dv_ctx {
     double* d_fpnorm = nullptr;               // [64] ... of each heading's patch
     unsigned long long* d_flower = nullptr;   // [64] per heading the best lower bound of the step (ordered key; k_combine_f32x)
     bool fprep_direct_ready = false;          // d_fprep (the direct form's operand layout) describes the resident patches
+    int nt_env = -1;                          // DEJAVU_NT=0/1: default / non-temporal policy for the matrix-core kernel's library rows (default: by size)
     int ssd_mfma_env = 1;                     // DEJAVU_SSD_MFMA=0: ssd_f32 steps keep the direct form (k_ssd_tiles) throughout
     bool f32x_request = false;                // enqueue_step: this ssd_f32 pass may take the cross-term form (no per-view output wanted)
     bool f32x_used = false;                   // ... and did: the step ends in k_cand_f32x + k_resolve_f32 + k_decide
@@ -353,6 +354,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TUNE_ALL", c->tune_all_env, 0, 1);
     env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 1);
     env_int("DEJAVU_CHAINS", c->chains_env, 1, 2);
+    env_int("DEJAVU_NT", c->nt_env, 0, 1);
     env_int("DEJAVU_TEST_FAIL_ALLOC", c->fail_alloc_env, 0, 64);
     *out = c;
     return DV_OK;
@@ -641,6 +643,10 @@ static int build_bit_planes(dv_ctx* c) {
             b.GSC = b.GS;
         }
     }
+    // library rows: non-temporal (used once per step).  DEJAVU_NT=0 streams them with the default policy instead -- measured equal on
+    // 50 000 views x 64x64 (158 MB of bit tiles, which would fit the 256 MiB Infinity Cache between two steps): kernel 38.9-40.5 us
+    // either way (tools/runs/r4_c1.sh), so that kernel is not waiting for its stream
+    b.nt = c->nt_env >= 0 ? c->nt_env : 1;
     c->bcfg = b;
     const long long total_t = G32 * nkt * 64;
     hipLaunchKernelGGL(k_bitpack, dim3((unsigned)((total_t + 255) / 256)), dim3(256), 0, c->stream, c->d_tiles, c->d_btiles, c->cfg, b);
@@ -938,7 +944,7 @@ static int alloc_f32_buffers(dv_ctx* c) {
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fprep4, (size_t)g.Q * kMaxHeadings * sizeof(float4));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fvnorm, (size_t)g.Fpad * sizeof(double));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fpnorm, (size_t)kMaxHeadings * sizeof(double));
-    if (e == hipSuccess) e = lib_malloc(c, &c->d_flower, (size_t)kMaxHeadings * sizeof(unsigned long long));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_flower, (size_t)kMaxHeadings * kF32xShards * sizeof(unsigned long long));
     if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 buffers");
     return DV_OK;
 }

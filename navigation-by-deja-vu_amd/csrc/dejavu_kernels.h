@@ -1774,6 +1774,7 @@ k_combine_f32(const double* __restrict__ part, double* __restrict__ fam, unsigne
 // reported per-heading minimum is then the reference's double bit for bit, not merely within 1e-6.
 constexpr int kF32xFold = 256;                         // q-steps (4 pixels each) per fp32 chain
 constexpr double kF32xKappa = 6.2e-5;                  // >= gamma_1024 = 6.1039e-5 with room for the norms' own rounding
+constexpr int kF32xShards = 32;                        // copies of a heading's lower bound the blocks of k_combine_f32x spread their atomics over
 
 // N_f of every view, in double.  One thread per view (lane <-> view: coalesced), grid = Fpad / 64 blocks of 64.
 __global__ void __launch_bounds__(64)
@@ -1807,7 +1808,8 @@ k_prep_f32x(const float* __restrict__ raw, float4* __restrict__ pprep, double* _
             if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
             __syncthreads();
         }
-        if (threadIdx.x == 0) { pnorm[a] = red[0]; lower[a] = 0ull; }
+        if (threadIdx.x == 0) pnorm[a] = red[0];
+        if (threadIdx.x < kF32xShards) lower[a * kF32xShards + threadIdx.x] = 0ull;
         return;
     }
     const long long total = (long long)c.Q * APAD;
@@ -1927,7 +1929,9 @@ k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm
     if (threadIdx.x == 0) {
         unsigned long long m = wmax[0];
         for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
-        atomicMax(&lower[a], m);                                       // (zeroed by k_prep_f32x with the patches this step scores)
+        // (zeroed by k_prep_f32x with the patches this step scores; 32 shards per heading: a few hundred blocks' atomics on ONE word
+        // serialise at ~100 ns each -- 21 of this kernel's 32 us at 50 000 views x 16 headings)
+        atomicMax(&lower[a * kF32xShards + (blockIdx.x & (kF32xShards - 1))], m);
     }
 }
 
@@ -1938,7 +1942,9 @@ __global__ void __launch_bounds__(256)
 k_cand_f32x(const double* __restrict__ fam, const unsigned long long* __restrict__ lower, const double* __restrict__ vnorm,
             const double* __restrict__ pnorm, StepState* __restrict__ st, unsigned long long* __restrict__ cand, LibCfg c, int A) {
     __shared__ unsigned long long s_lb[kMaxHeadings];
-    if (threadIdx.x < kMaxHeadings) s_lb[threadIdx.x] = threadIdx.x < A ? lower[threadIdx.x] : 0ull;
+    if (threadIdx.x < kMaxHeadings) s_lb[threadIdx.x] = 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * kF32xShards; i += blockDim.x) atomicMax(&s_lb[i / kF32xShards], lower[i]);
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < A) {
         __hip_atomic_store(&st->amax[threadIdx.x], s_lb[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2193,15 +2199,29 @@ k_resolve_f32(const float4* __restrict__ ftiles, const float* __restrict__ raw_p
         const float4* base = ftiles + (f >> 6) * c.gstride + (f & 63);
         const float* pa = raw_patches + (long long)a * c.P;
         double diff = 0.0;
+        // the next round's view and patch pixels are fetched while this round's 256 terms are summed (the sum is the serial part:
+        // fetched in its own round, each of the 16 rounds of a 64x64 view paid a memory round trip on top -- 38 us per step)
+        auto fetch = [&](int qb, float4& L, float (&pv)[4]) {
+            const int q = qb + lane;
+            L = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < c.Q) L = base[(long long)q * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int px = q * 4 + i; pv[i] = (q < c.Q && px < c.P) ? pa[px] : 0.f; }
+        };
+        float4 Ln;
+        float pn[4];
+        fetch(0, Ln, pn);
         for (int qb = 0; qb < c.Q; qb += 64) {
             const int q = qb + lane;
+            const float4 L = Ln;
+            const float pv[4] = {pn[0], pn[1], pn[2], pn[3]};
+            if (qb + 64 < c.Q) fetch(qb + 64, Ln, pn);
             if (q < c.Q) {
-                const float4 L = base[(long long)q * 64];
                 const float lw[4] = {L.x, L.y, L.z, L.w};
                 for (int i = 0; i < 4; ++i) {
                     const int px = q * 4 + i;
                     double t = 0.0;
-                    if (px < c.P) { const double d = (double)pa[px] - (double)lw[i]; t = d * d; }
+                    if (px < c.P) { const double d = (double)pv[i] - (double)lw[i]; t = d * d; }
                     terms[lane * 4 + i] = t;
                 }
             }
@@ -2636,6 +2656,8 @@ struct BitCfg {
     int GS;                 // 1-KB rows between consecutive view groups in btiles (>= NK[0] + NK[1], odd)
     int vcode;              // 1: the fp4 form reads the V segment as 3-bit level codes (ctiles, see k_bitpack_code)
     int GSC;                // 256-byte units between view groups in ctiles (>= 4 NK[0] + 3 NK[1])
+    int nt;                 // 1: the library rows are streamed with the non-temporal policy (used once per step and larger than the
+                            // Infinity Cache); 0: default policy -- a library that fits the 256 MiB cache is re-read from it step after step
     int wacc[2][4];         // fp4 form (sad_ring_fp4): the one gap width of the planes that land on bit b of a nibble, per segment
     int nbp;                // byte planes described below (= LibCfg::npl)
     unsigned char pl[kMaxBitPlanes];   // byte plane of bit plane t (HS planes first, then V)
@@ -3662,6 +3684,7 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
         }
     };
     bool young_code = false;                                            // the stage issued last is one of code rows (PERC instructions, not PER)
+    const bool nt_rows = b.nt != 0;
     auto issue_stage = [&]() {
         const unsigned slot = lds_base + (unsigned)lslot * (unsigned)SLOTB;
         const int kb = lst * SK;
@@ -3687,7 +3710,8 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                 const int cc = i / TL, t = i % TL;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + cc * KLIB + lw + 4 * t) * 1024));
                 if (!llive[t]) lds_dma_16(hot, dst);
-                else lds_dma_16_nt(reinterpret_cast<const uint4*>(lpv[t] + (long long)((kb - NK0) / SK) * 3072 + cc * 1024), dst);
+                else if (nt_rows) lds_dma_16_nt(reinterpret_cast<const uint4*>(lpv[t] + (long long)((kb - NK0) / SK) * 3072 + cc * 1024), dst);
+                else lds_dma_16(reinterpret_cast<const uint4*>(lpv[t] + (long long)((kb - NK0) / SK) * 3072 + cc * 1024), dst);
             }
         } else {
 #pragma unroll
@@ -3700,7 +3724,8 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
                 k = k < NKT ? k : NKT - 1;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + kk * KLIB + lw + 4 * t) * 1024));
                 if (!llive[t]) lds_dma_16(hot, dst);
-                else lds_dma_16_nt(reinterpret_cast<const uint4*>(lp[t] + (long long)k * 1024), dst);
+                else if (nt_rows) lds_dma_16_nt(reinterpret_cast<const uint4*>(lp[t] + (long long)k * 1024), dst);
+                else lds_dma_16(reinterpret_cast<const uint4*>(lp[t] + (long long)k * 1024), dst);
             }
         }
         young_code = code_stage;
