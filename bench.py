@@ -306,15 +306,16 @@ def ssd_f32_block(device_index, F, h, w, A, steps, seed=4242):
             "candidates_rescored_exactly": ncand,
             "direct_form": {"ms_per_step": out["direct"][0] * 1e3, "kernel_ms": out["direct"][1], "kernel": "k_ssd_tiles",
                             "library_passes": (A + 15) // 16},
-            "roofline": {"bound": "hbm", "kernel": "k_ssd_f32_mfma", "kernel_ms": kern_ms, "launches_timed": kn,
+            "roofline": {"bound": "hbm", "kernel": "k_ssd_f32_mfma<16>" if A <= 16 else "k_ssd_f32_bf16x2", "kernel_ms": kern_ms, "launches_timed": kn,
                          "library_passes": passes, "achieved": streamed / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": streamed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "bytes_basis": "streamed library bytes (4 B/px x passes of 32 headings) = the algorithmic bytes of SURVEY 8(d), s = 4",
                          "algorithmic_bytes_per_launch": algo,
                          "frac_algorithmic": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "mfma": {"dtype": "f32 (v_mfma_f32_32x32x1_2b / 16x16x1_4b)", "ops_per_launch": 2.0 * F * h * w * max(A, 16 if A <= 16 else 32 * passes),
-                                  "peak": 157.3, "unit": "TFLOP/s",
-                                  "frac": 2.0 * F * h * w * max(A, 16 if A <= 16 else 32 * passes) / (kern_ms * 1e-3) / 1e12 / 157.3}}}
+                         "mfma": ({"dtype": "f32 (v_mfma_f32_16x16x1_4b_f32)", "ops_per_launch": 2.0 * F * h * w * 16, "peak": 157.3, "unit": "TFLOP/s",
+                                   "frac": 2.0 * F * h * w * 16 / (kern_ms * 1e-3) / 1e12 / 157.3} if A <= 16 else
+                                  {"dtype": "bf16 x 3 terms (v_mfma_f32_32x32x16_bf16: lh ph + lh pl + ll ph)", "ops_per_launch": 6.0 * F * h * w * 32 * passes,
+                                   "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * F * h * w * 32 * passes / (kern_ms * 1e-3) / 1e12 / 2500.0})}}
 
 
 def ssd_u8_block(device_index, F, h, w, A, steps):

@@ -100,7 +100,9 @@ struct dv_ctx {
     float4* d_fprep4 = nullptr;               // ssd_f32 on the matrix cores: [Q][APAD] float4 patch rows (k_prep_f32x)
     double* d_fvnorm = nullptr;               // [Fpad] sum of squares of each view (k_norm_f32, at ingest)
     double* d_fpnorm = nullptr;               // [64] ... of each heading's patch
-    unsigned long long* d_flower = nullptr;   // [64] per heading the best lower bound of the step (ordered key; k_combine_f32x)
+    unsigned long long* d_flower = nullptr;   // [64][32 shards] per heading the best lower bound of the step (ordered key; k_combine_f32x)
+    uint4* d_fprepb = nullptr;                // [2 passes][ceil(P/16)][hi, lo][64] bf16 operand rows of the two-term form (k_prep_f32b)
+    double f32x_kappa = 0.0;                  // error bound of the form the last cross-term pass took (k_cand_f32x)
     bool fprep_direct_ready = false;          // d_fprep (the direct form's operand layout) describes the resident patches
     int nt_env = -1;                          // DEJAVU_NT=0/1: default / non-temporal policy for the matrix-core kernel's library rows (default: by size)
     int ssd_mfma_env = 1;                     // DEJAVU_SSD_MFMA=0: ssd_f32 steps keep the direct form (k_ssd_tiles) throughout
@@ -290,7 +292,7 @@ static void free_library(dv_ctx* c) {
     c->n_extra = 0;
     F(c->d_tiles); F(c->d_raw_patches); F(c->d_prep); F(c->d_acc); F(c->d_one); F(c->d_fam); F(c->d_scene);
     F(c->d_part); F(c->d_pmax); F(c->d_record); F(c->d_keys); F(c->d_bsum); F(c->d_bsum2); F(c->d_ctmp);
-    F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart); F(c->d_fprep4); F(c->d_fvnorm); F(c->d_fpnorm); F(c->d_flower);
+    F(c->d_ftiles); F(c->d_fraw); F(c->d_fprep); F(c->d_fpart); F(c->d_fprep4); F(c->d_fvnorm); F(c->d_fpnorm); F(c->d_flower); F(c->d_fprepb);
     F(c->d_u8tiles); F(c->d_u8raw); F(c->d_u8prep); F(c->d_u8part); F(c->d_vnorm); F(c->d_pnorm);
     F(c->d_btiles); F(c->d_coef); F(c->d_coef4); F(c->d_ctiles); c->ctile_bytes = 0;
     c->pbits = PrepBits{};
@@ -352,7 +354,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_RING", c->ring_env, 0, 2);
     env_int("DEJAVU_MIXED", c->mixed_env, 0, 1);
     env_int("DEJAVU_TUNE_ALL", c->tune_all_env, 0, 1);
-    env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 1);
+    env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 3);
     env_int("DEJAVU_CHAINS", c->chains_env, 1, 2);
     env_int("DEJAVU_NT", c->nt_env, 0, 1);
     env_int("DEJAVU_TEST_FAIL_ALLOC", c->fail_alloc_env, 0, 64);
@@ -945,6 +947,7 @@ static int alloc_f32_buffers(dv_ctx* c) {
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fvnorm, (size_t)g.Fpad * sizeof(double));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_fpnorm, (size_t)kMaxHeadings * sizeof(double));
     if (e == hipSuccess) e = lib_malloc(c, &c->d_flower, (size_t)kMaxHeadings * kF32xShards * sizeof(unsigned long long));
+    if (e == hipSuccess) e = lib_malloc(c, &c->d_fprepb, (size_t)2 * ((g.P + 15) / 16) * 2 * 64 * sizeof(uint4));
     if (e != hipSuccess) return lib_fail(c, e, "ssd_f32 buffers");
     return DV_OK;
 }
@@ -1039,6 +1042,11 @@ static int upload_patches_f32(dv_ctx* c, const float* patches, int A) {
         const int nrow = (int)((t4 + 255) / 256);
         hipLaunchKernelGGL(k_prep_f32x, dim3((unsigned)(nrow + A)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprep4, c->d_fpnorm, c->d_flower,
                            c->cfg, A, c->APAD, nrow);
+        if ((c->APAD > 16 && c->ssd_mfma_env == 1) || c->ssd_mfma_env == 3) {      // the two-term bf16 form's operand rows (passes of 32 headings)
+            const int passes = c->APAD > 32 ? 2 : 1;
+            const long long tb = (long long)passes * ((c->cfg.P + 15) / 16) * 64;
+            hipLaunchKernelGGL(k_prep_f32b, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, c->stream, c->d_fraw, c->d_fprepb, c->cfg, A, passes);
+        }
         HIP_TRY(c, hipGetLastError());
     }
     return DV_OK;
@@ -2287,13 +2295,24 @@ static int launch_scoring(dv_ctx* c, bool with_combine = true) {
                 hipLaunchKernelGGL(kern, grid, block, 0, c->stream, c->d_ftiles, c->d_fprep4, c->d_fpart, c->cfg, c->nchunk, c->APAD, a_off);
                 (void)hb;
             };
-            if (c->APAD <= 16) launch(k_ssd_f32_mfma<16, 8>, 16, 0);
-            else for (int a_off = 0; a_off < c->APAD; a_off += 32) launch(k_ssd_f32_mfma<32, 16>, 32, a_off);
+            // up to 16 resident headings: the 16-wide fp32 instruction (bound by its stream); passes of 32: the two-term bf16 form
+            // (DEJAVU_SSD_MFMA=2: the 32-wide fp32 instruction instead, 67 % matrix-pipe-bound at 1.79 GHz)
+            c->f32x_kappa = kF32xKappa;
+            if (c->APAD <= 16 && c->ssd_mfma_env != 3) launch(k_ssd_f32_mfma<16, 8>, 16, 0);
+            else if (c->ssd_mfma_env == 2) for (int a_off = 0; a_off < c->APAD; a_off += 32) launch(k_ssd_f32_mfma<32, 16>, 32, a_off);
+            else {
+                c->f32x_kappa = kF32xKappaBf16;
+                for (int a_off = 0; a_off < c->APAD; a_off += 32) {                    // (DEJAVU_SSD_MFMA=3: also for <= 16 headings, A/B)
+                    dim3 block;
+                    const dim3 grid = scoring_grid(c, resident_waves_per_cu((const void*)k_ssd_f32_bf16x2<4>), block);
+                    hipLaunchKernelGGL(k_ssd_f32_bf16x2<4>, grid, block, 0, c->stream, c->d_ftiles, c->d_fprepb, c->d_fpart, c->cfg, c->nchunk, c->APAD, a_off);
+                }
+            }
             HIP_TRY(c, hipGetLastError());
             if (prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
             n_partial = (int)(g.Fpad / 256) + ((g.Fpad % 256) ? 1 : 0);
             hipLaunchKernelGGL(k_combine_f32x, dim3((unsigned)n_partial, (unsigned)c->A), dim3(256), 0, c->stream, c->d_fpart, c->d_fvnorm,
-                               c->d_fpnorm, c->d_fam, c->d_flower, c->d_state, c->cfg, c->nchunk, c->APAD, c->n_agents);
+                               c->d_fpnorm, c->d_fam, c->d_flower, c->d_state, c->cfg, c->nchunk, c->APAD, c->n_agents, c->f32x_kappa);
             HIP_TRY(c, hipGetLastError());
             c->f32x_used = true;
         } else {
@@ -2444,7 +2463,7 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     if (c->f32x_used) {
         // candidates per heading -> exact re-scoring -> minima and decision from the exact values; the record is k_decide's
         hipLaunchKernelGGL(k_cand_f32x, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, c->stream, c->d_fam, c->d_flower,
-                           c->d_fvnorm, c->d_fpnorm, c->d_state, c->d_cand, c->cfg, c->A_agent);
+                           c->d_fvnorm, c->d_fpnorm, c->d_state, c->d_cand, c->cfg, c->A_agent, c->f32x_kappa);
         hipLaunchKernelGGL(k_resolve_f32, dim3(256), dim3(64), 0, c->stream, c->d_ftiles, c->d_fraw, c->d_state, c->d_cand, c->d_cand_exact, c->cfg);
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_cand, c->d_cand_exact, c->d_result + c->result_slot,
                            c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg, c->A_agent, c->delta, sense_err_ptr(c), 0,

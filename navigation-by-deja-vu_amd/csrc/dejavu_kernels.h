@@ -1773,7 +1773,11 @@ k_combine_f32(const double* __restrict__ part, double* __restrict__ fam, unsigne
 // sequential double arithmetic (util.pyx:180-182) and k_decide takes minima and the decision from those exact values: every
 // reported per-heading minimum is then the reference's double bit for bit, not merely within 1e-6.
 constexpr int kF32xFold = 256;                         // q-steps (4 pixels each) per fp32 chain
-constexpr double kF32xKappa = 6.2e-5;                  // >= gamma_1024 = 6.1039e-5 with room for the norms' own rounding
+constexpr double kF32xKappa = 6.2e-5;                  // fp32 form: >= gamma_1024 = 6.1039e-5 with room for the norms' own rounding
+// two-term bf16 form (k_ssd_f32_bf16x2): l p is taken as lh ph + lh pl + ll ph with lh = bf16(l), ll = bf16(l - lh) -- what is
+// left out (ll pl and the two residuals below 2^-18) is under 1.2e-5 |l p|; a chain of 256 pixels = 48 instructions of 16 products
+// each, priced at 17 fp32 additions of error 2u apiece whatever the pipe's internal order or rounding: 9.8e-5
+constexpr double kF32xKappaBf16 = 1.2e-4;
 constexpr int kF32xShards = 32;                        // copies of a heading's lower bound the blocks of k_combine_f32x spread their atomics over
 
 // N_f of every view, in double.  One thread per view (lane <-> view: coalesced), grid = Fpad / 64 blocks of 64.
@@ -1793,6 +1797,41 @@ k_norm_f32(const float4* __restrict__ ftiles, double* __restrict__ vnorm, LibCfg
 // Everything the matrix-core form needs of the A resident patches, one launch: blocks [0, nrow) write the A operand rows
 // pprep[q][a] = float4 of patch a's pixels 4q .. 4q+3 (zero past the last heading / pixel), a < APAD; block nrow + a sums N_a of
 // heading a's patch in double (a fixed-order sum: the same value every run) and zeroes the heading's lower bound for k_combine_f32x.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// l as two bf16 terms: hi = bf16(l), lo = bf16(l - hi), each pair of pixels packed low half first
+__device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const bf16x2_t h = {(__bf16)x0, (__bf16)x1};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+    const bf16x2_t l = {(__bf16)(x0 - h0), (__bf16)(x1 - h1)};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// The A operand rows of the two-term bf16 form (k_ssd_f32_bf16x2): pprepb[pass][block of 16 pixels][hi / lo][lane] = the eight bf16
+// of heading 32 pass + (lane & 31) at pixels 16 block + 8 (lane >> 5) + 0..7 -- v_mfma_f32_32x32x16_bf16's A map, lane for lane.
+__global__ void __launch_bounds__(256)
+k_prep_f32b(const float* __restrict__ raw, uint4* __restrict__ pprepb, LibCfg c, int A, int passes) {
+    const int nb16 = (c.P + 15) / 16;
+    const long long total = (long long)passes * nb16 * 64;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const int b = (int)((t >> 6) % nb16);
+    const int pass = (int)((t >> 6) / nb16);
+    const int a = pass * 32 + (lane & 31);
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = 16 * b + 8 * (lane >> 5) + 2 * i;
+        const float x0 = (a < A && px < c.P) ? raw[(long long)a * c.P + px] : 0.f;
+        const float x1 = (a < A && px + 1 < c.P) ? raw[(long long)a * c.P + px + 1] : 0.f;
+        split_bf16(x0, x1, hi[i], lo[i]);
+    }
+    uint4* dst = pprepb + (((long long)pass * nb16 + b) * 2) * 64 + lane;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 __global__ void __launch_bounds__(256)
 k_prep_f32x(const float* __restrict__ raw, float4* __restrict__ pprep, double* __restrict__ pnorm, unsigned long long* __restrict__ lower,
             LibCfg c, int A, int APAD, int nrow) {
@@ -1901,11 +1940,115 @@ k_ssd_f32_mfma(const float4* __restrict__ ftiles, const float4* __restrict__ ppr
     }
 }
 
+// The same cross terms for a pass of 32 headings in the two-term bf16 form: l p = lh ph + lh pl + ll ph on v_mfma_f32_32x32x16_bf16
+// (16x the fp32 instruction's rate).  The library stays fp32 in HBM (the exact resolver needs it); a wave turns each 16 pixels of its
+// 64 views into bf16 pairs in registers (split_bf16) and into the instruction's B operand -- column = view & 31, k = 8 (lane >> 5) +
+// 0..7 -- with four v_permlane32_swap per term: the upper lanes' low-k registers change places with the lower lanes' high-k ones,
+// which leaves one register set holding views 0-31 and the other views 32-63.  Six instructions per 16 pixels and 64 views (192 matrix
+// cycles where the fp32 form takes 1024) beside ~60 vector instructions: the pass is bound by its stream again.
+template <int D>                               // blocks of 16 pixels in flight (4 KB of library + 2 KB of patch rows each)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_ssd_f32_bf16x2(const float4* __restrict__ ftiles, const uint4* __restrict__ pprepb, double* __restrict__ part, LibCfg c, int nchunk,
+                 int apad_total, int a_off) {
+    constexpr int kFoldBlocks = 16;            // 256 pixels per fp32 chain
+    const int lane = threadIdx.x;
+    const long long G = c.Fpad / 64;
+    const long long n_items = G * nchunk;
+    const int Q = c.Q;
+    const int nb16 = (c.P + 15) / 16;
+    const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ch = (int)(item / G);
+        const long long g = item - (long long)ch * G;
+        const int b0 = (int)(((long long)ch * nb16) / nchunk), b1 = (int)(((long long)(ch + 1) * nb16) / nchunk);
+        const v4f_t* lb = reinterpret_cast<const v4f_t*>(ftiles + g * c.gstride + lane);
+        const v4u_t* pb = reinterpret_cast<const v4u_t*>(pprepb + ((long long)(a_off / 32) * nb16) * 128 + lane);
+        v16f32_t acc0, acc1;
+        double accd[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 32; ++r) accd[r] = 0.0;
+        v4f_t L[D][4];
+        v4u_t Ph[D], Pl[D];
+        auto fetch_lib = [&](int d, int b) {
+            const int bb = b < b1 ? b : b1 - 1;                     // (past the chunk: its last block again, not multiplied)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int q = 4 * bb + s2;
+                L[d][s2] = __builtin_nontemporal_load(lb + (long long)(q < Q ? q : Q - 1) * 64);
+            }
+        };
+        auto fetch_rows = [&](int d, int b) {
+            const int bb = b < b1 ? b : b1 - 1;
+            Ph[d] = pb[(long long)bb * 128];
+            Pl[d] = pb[(long long)bb * 128 + 64];
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) { fetch_lib(d, b0 + d); fetch_rows(d, b0 + d); }
+        int chain = 0;
+        for (int b = b0; b < b1; b += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                // the block's 16 pixels as bf16 pairs first: the float registers are then free for the fetch of block b + d + D
+                unsigned H[8], Lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool real = 4 * (b + d) + (j >> 1) < Q;    // (q-steps past the last pixel: the clamped load is not theirs)
+                    const float x0 = real ? L[d][j >> 1][(j & 1) * 2] : 0.f, x1 = real ? L[d][j >> 1][(j & 1) * 2 + 1] : 0.f;
+                    split_bf16(x0, x1, H[j], Lo[j]);
+                }
+                fetch_lib(d, b + d + D);
+                if (b + d < b1) {
+                    // registers j (pixels 2j, 2j+1) and 4 + j (pixels 8 + 2j ..): upper lanes of the first <-> lower lanes of the second
+                    unsigned hx[4], hy[4], lx[4], ly[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const auto sh = __builtin_amdgcn_permlane32_swap(H[j], H[4 + j], false, false);
+                        hx[j] = sh[0]; hy[j] = sh[1];
+                        const auto sl = __builtin_amdgcn_permlane32_swap(Lo[j], Lo[4 + j], false, false);
+                        lx[j] = sl[0]; ly[j] = sl[1];
+                    }
+                    const bf16x8_t Ahi = __builtin_bit_cast(bf16x8_t, Ph[d]), Alo = __builtin_bit_cast(bf16x8_t, Pl[d]);
+                    const bf16x8_t Bhx = __builtin_bit_cast(bf16x8_t, v4u_t{hx[0], hx[1], hx[2], hx[3]});
+                    const bf16x8_t Bhy = __builtin_bit_cast(bf16x8_t, v4u_t{hy[0], hy[1], hy[2], hy[3]});
+                    const bf16x8_t Blx = __builtin_bit_cast(bf16x8_t, v4u_t{lx[0], lx[1], lx[2], lx[3]});
+                    const bf16x8_t Bly = __builtin_bit_cast(bf16x8_t, v4u_t{ly[0], ly[1], ly[2], ly[3]});
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Bhx, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Bhy, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhx, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhy, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Blx, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Bly, acc1, 0, 0, 0);
+                }
+                fetch_rows(d, b + d + D);
+            }
+            chain += D;
+            if (chain >= kFoldBlocks) {                             // the fp32 chains end here: into the doubles
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accd[r] += (double)acc0[r]; acc0[r] = 0.f; accd[16 + r] += (double)acc1[r]; acc1[r] = 0.f; }
+                chain = 0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accd[r] += (double)acc0[r]; accd[16 + r] += (double)acc1[r]; }
+        double* dst = part + ((long long)ch * apad_total + a_off) * c.Fpad + g * 64;
+        int ln = lane;                                              // opaque: the row addresses are not hoisted out of the item loop
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {                              // the 32-wide fp32 form's map: register r of set r >> 4
+            const int hd = (r & 3) + 8 * ((r & 15) >> 2) + 4 * (ln >> 5);
+            const int view = 32 * (r >> 4) + (ln & 31);
+            if (hd < rows) dst[(long long)hd * c.Fpad + view] = accd[r];
+        }
+    }
+}
+
 // fam[a][f] = -(N_f + N_a - 2 sum over chunks of part): the approximate SSD, negated like every score here; per block the
 // largest LOWER bound fam - E (E = kappa (N_f + N_a)) as an ordered key.  grid = (ceil(Fpad / 256), A).
 __global__ void __launch_bounds__(256)
 k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm, const double* __restrict__ pnorm, double* __restrict__ fam,
-               unsigned long long* __restrict__ lower, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD, int n_agents) {
+               unsigned long long* __restrict__ lower, StepState* __restrict__ st, LibCfg c, int nchunk, int APAD, int n_agents, double kappa) {
     __shared__ unsigned long long wmax[4];
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int a = blockIdx.y;
@@ -1917,7 +2060,7 @@ k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm
         const double n2 = vnorm[f] + pnorm[a];
         const double val = -(n2 - 2.0 * dot);
         fam[(long long)a * c.Fpad + f] = val;
-        key = ordered_key(val - kF32xKappa * n2);
+        key = ordered_key(val - kappa * n2);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1940,7 +2083,7 @@ k_combine_f32x(const double* __restrict__ part, const double* __restrict__ vnorm
 // lower bounds as the step's approximate per-heading maxima.  grid = ceil(F / 256).
 __global__ void __launch_bounds__(256)
 k_cand_f32x(const double* __restrict__ fam, const unsigned long long* __restrict__ lower, const double* __restrict__ vnorm,
-            const double* __restrict__ pnorm, StepState* __restrict__ st, unsigned long long* __restrict__ cand, LibCfg c, int A) {
+            const double* __restrict__ pnorm, StepState* __restrict__ st, unsigned long long* __restrict__ cand, LibCfg c, int A, double kappa) {
     __shared__ unsigned long long s_lb[kMaxHeadings];
     if (threadIdx.x < kMaxHeadings) s_lb[threadIdx.x] = 0ull;
     __syncthreads();
@@ -1955,7 +2098,7 @@ k_cand_f32x(const double* __restrict__ fam, const unsigned long long* __restrict
     const double nf = vnorm[f];
     for (int a = 0; a < A; ++a) {
         const double v = fam[(long long)a * c.Fpad + f];
-        const double e = kF32xKappa * (nf + pnorm[a]);
+        const double e = kappa * (nf + pnorm[a]);
         if (v + e >= key_to_double(s_lb[a])) {
             const unsigned long long pos = atomicAdd(&st->ncand, 1ull);
             if (pos < (unsigned long long)kCandCap) cand[pos] = ((unsigned long long)a << 40) | (unsigned long long)f;

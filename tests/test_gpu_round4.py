@@ -320,7 +320,7 @@ def test_ssd_plugin_with_the_host_sensor_model():
 
 
 # ------------------------------------------------------------------ clean-up paths and small fixes of the round-3 review
-@pytest.mark.parametrize("metric,n_allocs", [("u8", 6), ("f32", 9)])
+@pytest.mark.parametrize("metric,n_allocs", [("u8", 6), ("f32", 10)])
 def test_allocation_failure_leaves_no_library(metric, n_allocs):
     """A failed allocation inside an SSD ingest must not leave a half-built library behind (the step calls would launch kernels
     on null pointers): every allocation of the ingest is failed in turn (DEJAVU_TEST_FAIL_ALLOC), the call reports
@@ -539,3 +539,39 @@ def test_ssd_f32_on_the_matrix_cores_reports_the_references_doubles(F, h, w, A):
     finally:
         e_new.close()
         e_old.close()
+
+
+@pytest.mark.parametrize("A,scale,noise", [(32, 1.0, 0.6), (40, 300.0, 0.5), (32, 1e-3, 0.8), (64, 5.0, 0.4), (16, 40.0, 0.5),
+                                           (32, 1.0, 1e-3)])
+def test_ssd_f32_selection_bound_under_cancellation(A, scale, noise):
+    """The matrix-core forms only select (two-term bf16 products at 32 headings per pass, fp32 chains at up to 16): their error
+    bound must keep every heading's true minimiser in the candidate list where the expansion cancels -- a library of noisy copies of
+    one view on top of an offset twice its range (the norms are 10-30x the SSDs, and a planted exact copy makes one SSD zero), values
+    far from 1.  With noise 1e-3 every view lies inside every heading's window (96 000 pairs > the 4096 the list holds): the step
+    must then fall back to exact scores everywhere (flag 4) and still be right.  Every reported minimum is compared with the
+    reference's `ssds` over ALL views (float64 NumPy finds the few pairs the oracle scores)."""
+    rng = np.random.default_rng(A * 7 + int(scale))
+    F, h, w = 3000, 24, 20
+    base = (rng.uniform(-1, 1, (h, w)) * scale + 2 * scale).astype(np.float32)
+    lib = (base[None] + (noise * scale) * rng.standard_normal((F, h, w))).astype(np.float32)
+    patches = (base[None] + (noise * scale) * rng.standard_normal((A, h, w))).astype(np.float32)
+    patches[3] = lib[777]                                              # an exact match among the near-duplicates
+    l64 = lib.astype(np.float64)
+    e = _engine({})
+    try:
+        e.set_library_f32(lib)
+        r = e.step_f32(patches)
+        for a in range(A):
+            d = l64 - patches[a].astype(np.float64)
+            approx = (d * d).reshape(F, -1).sum(axis=1)
+            near = np.flatnonzero(approx <= approx.min() * (1 + 1e-9) + 1e-300)
+            ex = np.array([oracle.ssds(patches[a].astype(np.float64), l64[k]) for k in near])
+            assert r["angle_ssd"][a] == ex.min(), (a, r["angle_ssd"][a], ex.min(), r["n_candidates"], r["flags"])
+            assert int(r["angle_view"][a]) == int(near[int(np.argmin(ex))]), a
+        assert r["best_idex"] == 3 and r["best_view"] == 777 and r["step_ssd"] == 0.0
+        # noise 1e-3: every view lies inside every heading's window (96 000 pairs) -> the exact fallback; the others: the bound itself
+        assert bool(r["flags"] & 4) == (noise < 1e-2), (r["flags"], r["n_candidates"])
+        if noise > 1e-2:
+            assert r["n_candidates"] < 40 * A
+    finally:
+        e.close()
