@@ -2197,13 +2197,11 @@ k_ssd_u8_mfma(const uint4* __restrict__ tiles, const uint4* __restrict__ prep, i
     const int rows = (apad_total - a_off) < 32 ? (apad_total - a_off) : 32;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int k0 = ch * KC, kn = (K - k0) < KC ? (K - k0) : KC;
-        __syncthreads();                                       // everybody is done with the chunk before
-        for (int i = tid; i < kn * 64; i += 512) lds_rows[i] = prep[(long long)k0 * 64 + i];
-        __syncthreads();
-        for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-            const uint4* base[TL];
-            long long gidx[TL];
-            bool live[TL];
+        const uint4* base[TL];
+        long long gidx[TL];
+        bool live[TL];
+        v4i_t buf[2][TL][8];
+        auto aim = [&](long long item) {                       // this wave's view groups of an item
             const long long g0 = (item * G32) / n_items, g1 = ((item + 1) * G32) / n_items;
 #pragma unroll
             for (int t = 0; t < TL; ++t) {
@@ -2212,20 +2210,30 @@ k_ssd_u8_mfma(const uint4* __restrict__ tiles, const uint4* __restrict__ prep, i
                 gidx[t] = live[t] ? g : G32 - 1;               // a slot without a view group re-reads the last one (never stored)
                 base[t] = tiles + (gidx[t] * K + k0) * 64 + lane;
             }
+        };
+        auto load = [&](v4i_t (&dst)[TL][8], int kb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kb + j < kn ? kb + j : kn - 1;   // (past the chunk: its last row again, not multiplied)
+#pragma unroll
+                for (int t = 0; t < TL; ++t) dst[t][j] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(base[t] + (long long)k * 64));
+            }
+        };
+        // the first item's first rows are asked for BEFORE the operand rows are copied into LDS: the two round trips overlap (the copy
+        // and its barriers used to stand in front of the stream: ~4 of the kernel's 39 us at 50 000 views x 64x64)
+        bool first = (long long)blockIdx.x < n_items;
+        if (first) { aim(blockIdx.x); load(buf[0], 0); }
+        __syncthreads();                                       // everybody is done with the chunk before
+        for (int i = tid; i < kn * 64; i += 512) lds_rows[i] = prep[(long long)k0 * 64 + i];
+        __syncthreads();
+        for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+            if (!first) { aim(item); load(buf[0], 0); }
+            first = false;
             v16i_t acc[TL];
 #pragma unroll
             for (int t = 0; t < TL; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0;
-            v4i_t buf[2][TL][8];
-            auto load = [&](v4i_t (&dst)[TL][8], int kb) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = kb + j < kn ? kb + j : kn - 1;   // (past the chunk: its last row again, not multiplied)
-#pragma unroll
-                    for (int t = 0; t < TL; ++t) dst[t][j] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(base[t] + (long long)k * 64));
-                }
-            };
             auto multiply = [&](const v4i_t (&src)[TL][8], int kb) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -2236,7 +2244,6 @@ k_ssd_u8_mfma(const uint4* __restrict__ tiles, const uint4* __restrict__ prep, i
                     }
                 }
             };
-            load(buf[0], 0);
             for (int kb = 0; kb < kn; kb += 16) {
                 if (kb + 8 < kn) load(buf[1], kb + 8);
                 multiply(buf[0], kb);
