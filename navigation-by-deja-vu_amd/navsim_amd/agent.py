@@ -596,5 +596,8 @@ class NavBySceneFamiliarity(object):
 
     def apply_step_result(self, res, fake=False):
         """Finish a step whose device work was done elsewhere (an ensemble pass): same state changes as step_forward."""
-        self.angle_familiarity[:] = res["angle_familiarity"]
-        self._move(res["best_idex"], fake)
+        self.apply_step_arrays(res["angle_familiarity"], res["best_idex"], fake)
+
+    def apply_step_arrays(self, angle_familiarity, best_idex, fake=False):
+        self.angle_familiarity[:] = angle_familiarity
+        self._move(best_idex, fake)

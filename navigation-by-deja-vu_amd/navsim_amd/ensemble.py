@@ -57,14 +57,21 @@ class NavEnsemble(object):
             idx.append(i); xs.append(x); ys.append(y); angs.append(a)
         if idx:
             results = self.engine.sense_step_batch(xs, ys, np.stack(angs))
-            for i, res in zip(idx, results):
-                if res["flags"] & 16:                             # DV_RES_SENSE_ERROR: this agent's footprint left the
+            # the records as arrays when the engine offers them (engine.BatchResults): no dictionary per agent and step
+            lean = hasattr(results, "angle_familiarity")
+            flags = results.flags.tolist() if lean else [r["flags"] for r in results]
+            best = results.best_idex.tolist() if lean else None
+            for k, i in enumerate(idx):
+                if flags[k] & 16:                                 # DV_RES_SENSE_ERROR: this agent's footprint left the
                     # landscape (a corner reaches r*sqrt(2) > r past the bounds test); the reference's trial ends in an
                     # IndexError, the other trials go on
                     self._stop(i, IndexError("sensor footprint reaches past the end of the landscape (index out of bounds)"))
                     continue
                 try:
-                    self.agents[i].apply_step_result(res, fake)
+                    if lean:
+                        self.agents[i].apply_step_arrays(results.angle_familiarity[k], best[k], fake)
+                    else:
+                        self.agents[i].apply_step_result(results[k], fake)
                 except StopNavigationException as e:
                     self._stop(i, e)
         return self.active

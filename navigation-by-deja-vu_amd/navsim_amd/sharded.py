@@ -224,15 +224,38 @@ class ShardedFamiliarity(object):
         self.world_size = world_size
         self.exchanges = 0
         self.key_decisions = 0                # steps decided by the all-reduce(max) of packed keys alone
+        self.n_views_total = None
+        self._scene_local = None              # this rank's block of the last step's per-view minimum (want_scene=True)
 
     def set_library(self, scenes, chem_weight=0.0):
         """Every rank passes the FULL library (or only its own block via set_library_block)."""
         lo, hi = shard_bounds(len(scenes), self.world_size, self.rank)
         self.engine.set_library(scenes[lo:hi], chem_weight, first_view=lo)
         self.bounds = (lo, hi)
+        self.n_views_total = len(scenes)
+        self._scene_local = None
+
+    def gather_scene_familiarity(self):
+        """scene_familiarity[F] of the last step (navsim/NavBySceneFamiliarity.py:301-303), gathered from the ranks' blocks.
+
+        The per-view minimum over the headings is per view, so a step leaves it sharded (`scene_familiarity_local`) and pays
+        nothing for it; the reference only reads it for plots (:540,630).  A COLLECTIVE: every rank calls it (one all-gather of
+        ceil(F / world) doubles per rank), after a step taken with want_scene=True."""
+        if self._scene_local is None:
+            raise RuntimeError("no per-view minimum to gather: the last step was not taken with want_scene=True")
+        per = (self.n_views_total + self.world_size - 1) // self.world_size
+        mine = np.full(per, np.nan)
+        mine[:len(self._scene_local)] = self._scene_local
+        allv = np.asarray(self.gather(mine)).reshape(self.world_size, per)
+        out = np.empty(self.n_views_total, dtype=np.float64)
+        for r in range(self.world_size):
+            lo, hi = shard_bounds(self.n_views_total, self.world_size, r)
+            out[lo:hi] = allv[r, :hi - lo]
+        return out
 
     def step(self, patches, want_scene=False):
         res = self.engine.step(patches, want_scene=want_scene)
+        self._scene_local = res.get("scene_familiarity") if want_scene else None
         A = len(res["angle_familiarity"])
         delta = res["delta"]
         if self.reduce_max is not None:
@@ -242,8 +265,8 @@ class ShardedFamiliarity(object):
             out = merge_keys(keys, self.world_size, A, delta)
             if out is not None:
                 self.key_decisions += 1
-                out["scene_familiarity_local"] = res.get("scene_familiarity")
-                out["scene_familiarity"] = None
+                out["scene_familiarity_local"] = self._scene_local
+                out["scene_familiarity"] = None              # sharded: gather_scene_familiarity() when it is read
                 return out
         records = self.gather(pack_record(res))
         self.exchanges += 1
@@ -251,12 +274,11 @@ class ShardedFamiliarity(object):
         if again:
             if self.rank in ranks and not (res["flags"] & 3):
                 res = self.engine.resolve()
-                res["scene_familiarity"] = None
             records = self.gather(pack_record(res))
             self.exchanges += 1
         out = merge_records(records, delta, A)
-        out["scene_familiarity_local"] = res.get("scene_familiarity")
-        out["scene_familiarity"] = None                      # sharded: see scene_familiarity_local
+        out["scene_familiarity_local"] = self._scene_local
+        out["scene_familiarity"] = None                      # sharded: gather_scene_familiarity() when it is read
         return out
 
 

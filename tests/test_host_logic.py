@@ -399,3 +399,27 @@ def test_sanitizer_build_of_the_host_side_runs_clean():
     r = subprocess.run(["make", "-C", d, "check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "asan_driver: ok" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_batch_results_arrays_are_the_records():
+    """engine.BatchResults: the ensemble step's records as arrays and as the per-agent dictionaries -- the same memory."""
+    from navsim_amd import _native as N
+    from navsim_amd.engine import BatchResults
+    n, A = 7, 5
+    raw = (N.StepResult * n)()
+    for i in range(n):
+        raw[i].best_heading, raw[i].flags, raw[i].best_view, raw[i].best_fam = i % A, 16 * (i == 3), 1000 + i, 0.5 * i
+        raw[i].n_headings, raw[i].n_candidates = A, i
+        for a in range(A):
+            raw[i].angle_fam[a], raw[i].angle_view[a] = i + 0.25 * a, 10 * i + a
+    res = BatchResults(raw, n, A)
+    assert len(res) == n and res.angle_familiarity.shape == (n, A) and len(list(res)) == n and len(res[1:4]) == 3
+    assert res.best_idex.tolist() == [i % A for i in range(n)] and res.flags.tolist() == [0, 0, 0, 16, 0, 0, 0]
+    for i in range(n):
+        d = res[i]
+        assert (d["best_idex"], d["best_view"], d["step_familiarity"], d["flags"], d["n_candidates"]) == \
+               (res.best_idex[i], res.best_view[i], res.step_familiarity[i], res.flags[i], res.n_candidates[i])
+        assert np.array_equal(d["angle_familiarity"], res.angle_familiarity[i]) and np.array_equal(d["angle_view"], res.angle_view[i])
+    assert res[-1]["best_view"] == 1000 + n - 1
+    with pytest.raises(IndexError):
+        res[n]

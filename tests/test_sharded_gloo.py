@@ -62,6 +62,13 @@ def worker(rank, world, port, q):
         rk = shk.step(pat)
         results.append((name + "+keys", rk["best_idex"], rk["best_view"], rk["step_familiarity"],
                         rk["angle_familiarity"].tolist(), (shk.exchanges, shk.key_decisions)))
+        # the per-view minimum stays sharded and is gathered when read: every rank ends with the unsharded array
+        with pytest.raises(RuntimeError):
+            shk.gather_scene_familiarity()
+        rs = shk.step(pat, want_scene=True)
+        assert rs["scene_familiarity"] is None and len(rs["scene_familiarity_local"]) == hi - lo
+        results.append((name + "+scene", rs["best_idex"], rs["best_view"], rs["step_familiarity"],
+                        shk.gather_scene_familiarity().tolist(), 0))
     q.put((rank, results))
     dist.barrier()
     dist.destroy_process_group()
@@ -90,6 +97,7 @@ def test_sharded_matches_unsharded_reference(world):
     expected = {name: oracle.step(lib, pat, cw) for name, lib, pat, cw in cases()}
     for name in list(expected):
         expected[name + "+keys"] = expected[name]
+        expected[name + "+scene"] = dict(expected[name], angle_familiarity=expected[name]["scene_familiarity"])
     exchanged = {}
     for rank in range(world):
         for name, best, view, fam, angle, exchanges in got[rank]:
