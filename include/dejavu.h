@@ -201,6 +201,16 @@ int dv_sense_step_batch(dv_ctx *ctx, const double *x, const double *y, const dou
 int dv_agent_step(dv_ctx *ctx, double x, double y, double angle, const double *offsets, int n_headings,
                   int do_error, double ex, double ey, double reach,
                   double *angle_fam, int32_t *best_heading, double *nearest, int32_t *have_nearest);
+/*
+ * dv_agent_step in two halves: _begin does 1. and 2. and LAUNCHES 3. (returns at once), _end waits for the record and hands out
+ * angle_fam / best_heading (and DV_ERR_INDEX).  The heading update between two steps (NavBySceneFamiliarity.py:317-323) serialises
+ * them, but everything else the host does after a step -- book-keeping, stop tests, the caller's loop -- need not wait: an agent
+ * begins its next step as soon as the new pose is known.  A begun step that is never ended is harmless (its record is not read);
+ * any other step call in between makes _end fail with DV_ERR_STATE.
+ */
+int dv_agent_step_begin(dv_ctx *ctx, double x, double y, double angle, const double *offsets, int n_headings,
+                        int do_error, double ex, double ey, double reach, double *nearest, int32_t *have_nearest);
+int dv_agent_step_end(dv_ctx *ctx, double *angle_fam, int32_t *best_heading);
 /* train_from_path (:118-140) on the device: sense n poses and ingest them as the library; out_views
  * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */
 int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,

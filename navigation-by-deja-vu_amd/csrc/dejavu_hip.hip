@@ -252,6 +252,7 @@ struct dv_ctx {
     PathErrOut* h_errout = nullptr;           // mapped ring of kErrRing answers
     PathErrOut* d_errout = nullptr;
     unsigned long long err_enq = 0, err_deq = 0;   // answers requested / collected
+    int agent_pending = 0;                    // headings of the agent step begun and not yet ended (dv_agent_step_begin / _end)
     bool err_on_main = false;                 // the last metric computation rode on the step's own stream (dv_agent_step)
 
     // measurement
@@ -1622,13 +1623,19 @@ static PathErrArgs path_err_args(dv_ctx* c, double x, double y, double reach) {
     return pe;
 }
 
-// One agent step's device work and device-side book-keeping in one call (include/dejavu.h: dv_agent_step).
-extern "C" int dv_agent_step(dv_ctx* c, double x, double y, double angle, const double* offsets, int A, int do_error, double ex,
-                             double ey, double reach, double* angle_fam, int32_t* best_heading, double* nearest, int32_t* have_nearest) {
+// One agent step's device work and device-side book-keeping (include/dejavu.h: dv_agent_step = dv_agent_step_begin + _end).
+// begin: collect the error answer asked for a step ago, launch sensing / preparation (with the metric blocks of (ex, ey)) / scoring /
+// fold, return; end: wait for the record, resolve near-ties, hand out the per-heading maxima and the decision.  Between the two the
+// host is free: an agent calls begin for the step it will take next as soon as its new pose is known and does its book-keeping
+// while the device works (navsim_amd/agent.py).  A begin that no end follows is harmless: later work queues behind it on the stream
+// and every record carries its step's sequence number.
+extern "C" int dv_agent_step_begin(dv_ctx* c, double x, double y, double angle, const double* offsets, int A, int do_error, double ex,
+                                   double ey, double reach, double* nearest, int32_t* have_nearest) {
     int rc = check_sense_args(c, A);
     if (rc) return rc;
-    if (!offsets || !angle_fam || !best_heading || !nearest || !have_nearest) return fail(c, DV_ERR_INVALID, "dv_agent_step: NULL argument");
+    if (!offsets || !nearest || !have_nearest) return fail(c, DV_ERR_INVALID, "dv_agent_step_begin: NULL argument");
     *have_nearest = 0;
+    c->agent_pending = 0;
     if (do_error && c->n_path < 1) return fail(c, DV_ERR_STATE, "no training path set (dv_set_training_path)");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->err_enq > c->err_deq) {                                     // asked for a step ago: there by now
@@ -1656,13 +1663,32 @@ extern "C" int dv_agent_step(dv_ctx* c, double x, double y, double angle, const 
     if (rc) return rc;
     rc = enqueue_step(c, 0, false);
     if (rc) return rc;
-    rc = finish_pass(c);
+    c->agent_pending = A;
+    return DV_OK;
+}
+
+extern "C" int dv_agent_step_end(dv_ctx* c, double* angle_fam, int32_t* best_heading) {
+    if (!c) return DV_ERR_INVALID;
+    if (!angle_fam || !best_heading) return fail(c, DV_ERR_INVALID, "dv_agent_step_end: NULL argument");
+    if (!c->agent_pending || !c->step_pending) return fail(c, DV_ERR_STATE, "dv_agent_step_end: no agent step was begun (or another step came between)");
+    const int A = c->agent_pending;
+    c->agent_pending = 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = finish_pass(c);
     if (rc) return rc;
     if (c->h_result[0].flags & kResSenseError)
         return fail(c, DV_ERR_INDEX, "sensor footprint reaches past the end of the landscape (index out of bounds)");
     memcpy(angle_fam, c->h_result[0].angle_fam, (size_t)A * sizeof(double));
     *best_heading = c->h_result[0].best_heading;
     return DV_OK;
+}
+
+extern "C" int dv_agent_step(dv_ctx* c, double x, double y, double angle, const double* offsets, int A, int do_error, double ex,
+                             double ey, double reach, double* angle_fam, int32_t* best_heading, double* nearest, int32_t* have_nearest) {
+    if (c && (!angle_fam || !best_heading)) return fail(c, DV_ERR_INVALID, "dv_agent_step: NULL argument");
+    int rc = dv_agent_step_begin(c, x, y, angle, offsets, A, do_error, ex, ey, reach, nearest, have_nearest);
+    if (rc) return rc;
+    return dv_agent_step_end(c, angle_fam, best_heading);
 }
 
 extern "C" int dv_set_library_from_poses(dv_ctx* c, const double* x, const double* y, const double* angle, int64_t n,
@@ -2438,6 +2464,7 @@ static void launch_finish(dv_ctx* c, int want_scene, int force) {
 
 static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
     const LibCfg& g = c->cfg;
+    c->agent_pending = 0;                                               // (dv_agent_step_begin sets it behind its own enqueue)
     const int force = (flags & DV_STEP_FORCE_RESOLVE) ? 1 : 0;
     const int scene_on = (want_scene && c->n_agents == 1) ? 1 : 0;
     // integer path: the scoring kernel's partial sums go straight to k_finish (combine + reductions + decision in one

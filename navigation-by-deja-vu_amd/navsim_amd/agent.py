@@ -10,6 +10,7 @@ scoring kernel when the HIP model is used (landscape resident in HBM, `k_sense`)
 NumPy for other plug-ins; both are pinned byte-for-byte by tests/golden/t5_sensor.npz.
 """
 import math
+import os
 
 import numpy as np
 
@@ -162,6 +163,8 @@ class NavBySceneFamiliarity(object):
         self._bounds = None
         self._roundbuf = np.empty((self.sensor_dimensions[1], self.sensor_dimensions[0]), dtype=np.float32)
         self._end_buf = np.empty(2, dtype=np.float64)
+        self._spec = None                      # the pose and offsets the engine was asked to begin the next step for (_move)
+        self.pipeline_steps = os.environ.get("DEJAVU_AGENT_PIPELINE", "1") != "0"
         self._landscape_glimpse_buf = np.empty((extent[1], extent[0], 3), dtype=np.uint8)
         self.n_sensor_pixels = np.prod(self.sensor_dimensions)
 
@@ -449,6 +452,7 @@ class NavBySceneFamiliarity(object):
         func = self._familiarity_func
         engine = getattr(func, "engine", None)
         defer_error = False
+        begin_next = False
         if engine is not None and str(getattr(func, "metric", "")).startswith("ssd"):
             self._step_ssd(func, engine, position)
             best_idex = self.last_scored_idex
@@ -462,18 +466,27 @@ class NavBySceneFamiliarity(object):
                         # the lean form of the same device step (dv_agent_step): ONE call does the sensing, the scoring and the
                         # device side of the error metrics -- the answer asked for at the last step is collected, the position
                         # the last step ended at is handed in -- and writes the per-heading maxima straight into angle_familiarity
-                        epos = self._error_pos
-                        best_idex, nearest = engine.agent_step(position[0], position[1], self.angle, self.angle_offsets,
-                                                               self.angle_familiarity, epos,
-                                                               self.coverage_threshold_factor * self.step_size)
-                        if epos is not None:
-                            self._error_pos = None
-                            self._pending_errors += 1
-                        if nearest is not None:
-                            self._pending_errors -= 1
-                            self._take_error(nearest)
+                        # The step may already be on the device: the last step began it as soon as this pose was known (_move), so
+                        # that its book-keeping, the caller's loop and this call's preamble ran beside the device's work.  It counts
+                        # only if it was begun for exactly this pose and these offsets and nothing else was asked of the engine since.
+                        best_idex = None
+                        spec, self._spec = self._spec, None
+                        if spec is not None and spec == (position[0], position[1], self.angle, self.angle_offsets.tobytes()):
+                            best_idex = engine.agent_step_end()
+                        if best_idex is None:
+                            epos = self._error_pos
+                            best_idex, nearest = engine.agent_step(position[0], position[1], self.angle, self.angle_offsets,
+                                                                   self.angle_familiarity, epos,
+                                                                   self.coverage_threshold_factor * self.step_size)
+                            if epos is not None:
+                                self._error_pos = None
+                                self._pending_errors += 1
+                            if nearest is not None:
+                                self._pending_errors -= 1
+                                self._take_error(nearest)
                         res = None
                         defer_error = self._metrics_on_device and not math.isfinite(self.max_distance_to_training_path)
+                        begin_next = self.pipeline_steps
                     elif not self.track_scene_familiarity and hasattr(engine, "sense_step_into"):
                         # (the same device step through the engine's lean binding: no per-step record, views or dictionary)
                         best_idex = engine.sense_step_into(position[0], position[1], self.angle, self.angle_offsets,
@@ -515,7 +528,7 @@ class NavBySceneFamiliarity(object):
                 self.angle_familiarity[a_idex] = np.max(temp_fam)
             best_idex = np.argmax(self.angle_familiarity)
 
-        self._move(best_idex, fake, defer_error)
+        self._move(best_idex, fake, defer_error, begin_next)
 
     def _step_ssd(self, func, engine, position):
         """The heading loop (:289-315) with the SSD plug-in (util.ssd_familiarity): ONE device step -- sense, score on the matrix
@@ -546,7 +559,7 @@ class NavBySceneFamiliarity(object):
             self._scene_is_inf = True
         self.last_scored_idex = res["best_idex"]
 
-    def _move(self, best_idex, fake=False, defer_error=False):
+    def _move(self, best_idex, fake=False, defer_error=False, begin_next=False):
         """The part of a step after the heading is chosen (:316-329): turn, advance, book-keeping, stop conditions."""
         position = self.position
         self.step_familiarity = self.angle_familiarity[best_idex]
@@ -556,8 +569,33 @@ class NavBySceneFamiliarity(object):
         self.angle = angle
         self.last_best_idex = int(best_idex)
 
+        begun = False
+        if begin_next and (fake or defer_error):
+            # the lean step on the agent's own engine: the NEXT step's device work starts now, for the pose just computed (the
+            # heading update is all that serialises two steps, :317-323) -- unless that pose is out of bounds, where the next call
+            # stops before it senses (:153-158).  The position's error metrics (update_error, :324) ride in the same launch.
+            b = self._bounds
+            npos = self.position
+            if b is not None and not ((npos[0] <= b[0]) or (npos[1] <= b[0]) or (npos[0] >= b[1]) or (npos[1] >= b[2])):
+                epos = None
+                if not fake:
+                    self.navigated_for_frames += 1
+                    self._flush_error_pos()
+                    epos = npos
+                nearest = self._engine.agent_step_begin(npos[0], npos[1], angle, self.angle_offsets, self.angle_familiarity, epos,
+                                                        self.coverage_threshold_factor * self.step_size)
+                if epos is not None:
+                    self._pending_errors += 1
+                if nearest is not None:
+                    self._pending_errors -= 1
+                    self._take_error(nearest)
+                self._spec = (npos[0], npos[1], angle, self.angle_offsets.tobytes())
+                begun = True
+
         if not fake:
-            if defer_error:
+            if begun:
+                pass                                              # (asked for with the step just begun)
+            elif defer_error:
                 # the lean step: this position's metrics are asked for by the NEXT step's device call (or when a metric is read)
                 self.navigated_for_frames += 1
                 self._flush_error_pos()
@@ -584,6 +622,7 @@ class NavBySceneFamiliarity(object):
         other.angle_familiarity = np.full_like(self.angle_familiarity, np.nan)
         other.scene_familiarity = None if self.track_scene_familiarity is False else np.zeros_like(self.scene_familiarity)
         other.position, other.angle = None, None
+        other._spec = None
         other.step_familiarity = None
         other.reset_error()
         return other

@@ -46,8 +46,9 @@ class FamiliarityEngine(object):
 
     def __init__(self, device=0, exact=False):
         self._lib = N.load()
-        self._ctx = N._ctx_p()
-        rc = self._lib.dv_create(ctypes.byref(self._ctx), int(device))
+        self._begun = False                    # an agent step was begun and not ended (agent_step_begin)
+        self._ctx_raw = N._ctx_p()
+        rc = self._lib.dv_create(ctypes.byref(self._ctx_raw), int(device))
         if rc != 0:
             msg = self._lib.dv_last_error(None)
             raise N.EngineError("dv_create(device=%d) failed: %s (%s)" % (
@@ -63,6 +64,13 @@ class FamiliarityEngine(object):
             self.set_exact(True)
 
     # -- plumbing -------------------------------------------------------------------------------
+    @property
+    def _ctx(self):
+        # Every call into the context goes through here, except agent_step_end: whatever it is, it supersedes an agent step that was
+        # begun and not ended (the begun step's work stays harmlessly queued on the stream; its record is not read)
+        self._begun = False
+        return self._ctx_raw
+
     def _check(self, rc, what):
         if rc != 0:
             msg = self._lib.dv_last_error(self._ctx)
@@ -72,9 +80,9 @@ class FamiliarityEngine(object):
             raise N.EngineError(text)
 
     def close(self):
-        if getattr(self, "_ctx", None):
-            self._lib.dv_destroy(self._ctx)
-            self._ctx = None
+        if getattr(self, "_ctx_raw", None):
+            self._lib.dv_destroy(self._ctx_raw)
+            self._ctx_raw = None
 
     def __del__(self):
         try:
@@ -236,11 +244,7 @@ class FamiliarityEngine(object):
         out_fam[:] = fam
         return res.best_heading
 
-    def agent_step(self, x, y, angle, offsets, out_fam, error_pos, reach):
-        """dv_agent_step: one agent step's device work and device-side book-keeping in one call.  The headings (angle + offsets)
-        mod 2 pi are sensed at (x, y) and scored, out_fam (float64[A], C-contiguous: the agent's angle_familiarity) is written in
-        place; error_pos = (ex, ey) asks for the error metrics of that position (or None), and an outstanding answer comes back.
-        Returns (best heading, nearest distance or None)."""
+    def _agent_args(self, offsets, out_fam):
         st = self._agent_state
         if st is None or st[0] is not offsets or st[1] is not out_fam:
             if not (out_fam.flags.c_contiguous and out_fam.dtype == np.float64 and out_fam.shape == (len(offsets),)):
@@ -249,7 +253,14 @@ class FamiliarityEngine(object):
             best, nearest, have = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_int32(0)
             st = self._agent_state = (offsets, out_fam, off, N.f64ptr(off), len(off), N.f64ptr(out_fam), best, ctypes.byref(best),
                                       nearest, ctypes.byref(nearest), have, ctypes.byref(have))
-        _, _, _, offp, A, famp, best, bestp, nearest, nearestp, have, havep = st
+        return st
+
+    def agent_step(self, x, y, angle, offsets, out_fam, error_pos, reach):
+        """dv_agent_step: one agent step's device work and device-side book-keeping in one call.  The headings (angle + offsets)
+        mod 2 pi are sensed at (x, y) and scored, out_fam (float64[A], C-contiguous: the agent's angle_familiarity) is written in
+        place; error_pos = (ex, ey) asks for the error metrics of that position (or None), and an outstanding answer comes back.
+        Returns (best heading, nearest distance or None)."""
+        _, _, _, offp, A, famp, best, bestp, nearest, nearestp, have, havep = self._agent_args(offsets, out_fam)
         if error_pos is None:
             rc = self._lib.dv_agent_step(self._ctx, x, y, angle, offp, A, 0, 0.0, 0.0, 0.0, famp, bestp, nearestp, havep)
         else:
@@ -257,6 +268,32 @@ class FamiliarityEngine(object):
         if rc:
             self._check_sense(rc, "dv_agent_step")
         return best.value, (nearest.value if have.value else None)
+
+    def agent_step_begin(self, x, y, angle, offsets, out_fam, error_pos, reach):
+        """First half of agent_step (dv_agent_step_begin): collects an outstanding error answer, launches the step, returns at once
+        with that answer (or None).  agent_step_end() hands out the step's result -- unless anything else was asked of the engine in
+        between, which supersedes the begun step."""
+        _, _, _, offp, A, famp, best, bestp, nearest, nearestp, have, havep = self._agent_args(offsets, out_fam)
+        if error_pos is None:
+            rc = self._lib.dv_agent_step_begin(self._ctx, x, y, angle, offp, A, 0, 0.0, 0.0, 0.0, nearestp, havep)
+        else:
+            rc = self._lib.dv_agent_step_begin(self._ctx, x, y, angle, offp, A, 1, error_pos[0], error_pos[1], reach, nearestp, havep)
+        if rc:
+            self._check_sense(rc, "dv_agent_step_begin")
+        self._begun = True
+        return nearest.value if have.value else None
+
+    def agent_step_end(self):
+        """Second half: waits for the begun step, writes its per-heading maxima into the out_fam given to agent_step_begin and
+        returns the best heading; None when the begun step was superseded (the caller takes the step again)."""
+        if not self._begun:
+            return None
+        self._begun = False
+        st = self._agent_state
+        rc = self._lib.dv_agent_step_end(self._ctx_raw, st[5], st[7])
+        if rc:
+            self._check_sense(rc, "dv_agent_step_end")
+        return st[6].value
 
     def sense_step_batch(self, x, y, angles, force_resolve=False):
         """Ensemble step on the device: agent i at (x[i], y[i]) looking along angles[i][0..A) -> BatchResults (a sequence of result dicts)."""

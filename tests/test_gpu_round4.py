@@ -575,3 +575,82 @@ def test_ssd_f32_selection_bound_under_cancellation(A, scale, noise):
             assert r["n_candidates"] < 40 * A
     finally:
         e.close()
+
+
+# ------------------------------------------------------------------ the agent's next step begun before its book-keeping
+def _walk(pipeline, script):
+    land = synth.synth_landscape(12, 500, 4)
+    path = synth.sin_training_path(0.5, 80, 330, arclen=1.0)[:260]
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, n_test_angles=12, n_sensor_levels=5,
+                                           familiarity_model=navsim_amd.sads_familiarity(0.25), track_scene_familiarity=False)
+    nsf.pipeline_steps = pipeline
+    nsf.train_from_path(path)
+    nsf.position, nsf.angle = (path[3][0] + 0.4, path[3][1] - 0.2), 0.6
+    log, begun_used = [], 0
+    try:
+        for t in range(400):
+            what = script(t)
+            if what == "teleport":                                   # a pose nobody began a step for
+                nsf.position, nsf.angle = (path[40][0] - 0.3, path[40][1] + 0.5), 1.1
+            elif what == "engine":                                   # something else asked of the engine between two steps
+                nsf._engine.library_info()
+            elif what == "metrics":                                  # a metric read in mid-run (collects outstanding answers)
+                log.append(("rmsd", float(nsf.navigation_error), float(nsf.percent_recapitulated)))
+            elif what == "sense":
+                log.append(("mat", nsf.get_sensor_mat(nsf.position, nsf.angle).tobytes()))
+            had = nsf._spec is not None and nsf._engine._begun
+            nsf.step_forward(fake=(what == "fake"))
+            begun_used += int(had)
+            log.append((nsf.last_best_idex, nsf.position, nsf.angle, nsf.angle_familiarity.tobytes(), nsf.navigated_for_frames))
+    except navsim_amd.StopNavigationException as e:
+        log.append(("stop", e.get_code()))
+    log.append(("end", float(nsf.navigation_error), float(nsf.percent_recapitulated), nsf.percent_recapitulated_forgiving(),
+                nsf.n_captures(), nsf.navigated_for_frames))
+    nsf.clear_training()
+    return log, begun_used
+
+
+def test_pipelined_agent_steps_equal_call_per_step():
+    """dv_agent_step_begin / _end: the agent begins its next step as soon as the new pose is known and ends it in the next
+    step_forward().  Same decisions, poses, per-heading maxima, error metrics and stop as one call per step -- also when the pose
+    is changed between steps, when other engine calls come in between (the begun step is superseded), with fake steps mixed
+    in, and at the end of the path (a begun step nobody ends)."""
+    def script(t):
+        return {17: "teleport", 30: "engine", 31: "fake", 32: "fake", 50: "metrics", 51: "sense", 90: "teleport"}.get(t)
+    piped, used = _walk(True, script)
+    plain, used0 = _walk(False, script)
+    assert used0 == 0 and used > len(piped) * 0.9, (used, len(piped))    # the pipelined run did end begun steps almost every time
+    assert len(piped) == len(plain)
+    for k, (a, b) in enumerate(zip(piped, plain)):
+        assert a == b, k
+    assert piped[-2][0] == "stop" or len(piped) > 400                    # (the walk reaches the end of the path)
+
+
+def test_begun_agent_step_is_superseded_by_any_other_call():
+    land = synth.synth_landscape(3, 300, 4)
+    agent = None
+    try:
+        agent = navsim_amd.NavBySceneFamiliarity(land, (8, 8), 1.0, n_test_angles=6, n_sensor_levels=5,
+                                                 familiarity_model=navsim_amd.sads_familiarity(0.0))
+        agent.train_from_path(synth.sin_training_path(0.5, 60, 200, arclen=1.0)[:100])
+        e2 = agent._engine
+        fam = np.empty(6)
+        offs = agent.angle_offsets
+        assert e2.agent_step_end() is None                               # nothing begun
+        assert e2.agent_step_begin(100.0, 130.0, 0.3, offs, fam, None, 0.0) is None
+        best = e2.agent_step_end()
+        want, _ = e2.agent_step(100.0, 130.0, 0.3, offs, np.empty(6), None, 0.0)
+        assert best == want
+        e2.agent_step_begin(100.0, 130.0, 0.3, offs, fam, None, 0.0)
+        e2.library_info()
+        assert e2.agent_step_end() is None                               # superseded: the caller steps again
+        # the C ABI itself refuses an end with another step in between, and one without a begin
+        lib = e2._lib
+        best32 = ctypes.c_int32()
+        e2.agent_step_begin(100.0, 130.0, 0.3, offs, fam, None, 0.0)
+        e2.sense_step(100.0, 130.0, (0.3 + offs) % (2 * np.pi), want_scene=False)
+        assert lib.dv_agent_step_end(e2._ctx_raw, N.f64ptr(fam), ctypes.byref(best32)) == -3
+        assert lib.dv_agent_step_end(e2._ctx_raw, N.f64ptr(fam), ctypes.byref(best32)) == -3
+    finally:
+        if agent is not None:
+            agent.clear_training()
