@@ -400,6 +400,38 @@ int dv_merge_records(const double *records, int world, int n_headings, int64_t s
 int dv_merge_keys(const uint64_t *keys, int world, int n_headings, double delta, int signed_order, dv_merge_out *out);
 int dv_synchronize(dv_ctx *ctx);
 
+/* ---- one process, several devices ---------------------------------------- */
+/*
+ * SURVEY 8-b2 words the boundary as dv_create(ctx**, device_ids[], n): one caller thread that owns all GPUs of a node (the
+ * reference is a single Python process, navsim/NavBySceneFamiliarity.py:72,140,299).  A dv_group is that form: n contexts, member r
+ * on device_ids[r], behind one handle.  The library is cut into contiguous blocks of views in member order (first members take
+ * the extras), every member's step is enqueued before any is waited for, and the members' records are merged by the sharded
+ * step's rules (dv_merge_records; near-ties across members are re-scored exactly by the contending members, dv_resolve) -- the
+ * decision is the unsharded one, first occurrence included (:313-315).  The multi-PROCESS form (one rank per GPU, one RCCL
+ * all-reduce per step) is navsim_amd/sharded.py over dv_step_keys / dv_step_record.
+ *   dv_group_step        patches uint8[A, h, w, 3] go to every member; scene_fam (may be NULL) receives float64[F] in library order
+ *   dv_group_sense_step  every member senses the patches from its own copy of the landscape (dv_group_set_landscape,
+ *                        dv_group_configure_sensor): nothing but the pose goes up
+ *   dv_group_score       func(scene, fambuf) of the plug-in (util.pyx:14-20): fambuf[F]
+ *   result               best_heading / best_view (global index) / best_fam, angle_fam[A] and angle_view[A] (maxima over all
+ *                        members and their first views), flags DV_RES_RESOLVED when exact values decided; exact_* unused
+ * The same device id may be given more than once (independent contexts on one GPU).
+ */
+typedef struct dv_group dv_group;
+int dv_group_create(dv_group **out, const int *device_ids, int n_devices);
+void dv_group_destroy(dv_group *g);
+const char *dv_group_last_error(const dv_group *g);
+int dv_group_size(const dv_group *g);
+int dv_group_member(dv_group *g, int r, dv_ctx **ctx, int64_t *first_view, int64_t *n_views);
+int dv_group_set_library(dv_group *g, const uint8_t *views, int64_t n_views, int h, int w, int channels, double chem_weight);
+int dv_group_set_landscape(dv_group *g, const uint8_t *landscape, int rows, int cols, int channels);
+int dv_group_configure_sensor(dv_group *g, int sensor_w, int sensor_h, int pixel_w, int pixel_h, const uint8_t *level_lut,
+                              int mask_middle_n);
+int dv_group_score(dv_group *g, const uint8_t *patch, double *fambuf);
+int dv_group_step(dv_group *g, const uint8_t *patches, int n_headings, uint32_t flags, dv_step_result *result, double *scene_fam);
+int dv_group_sense_step(dv_group *g, double x, double y, const double *angles, int n_headings, uint32_t flags,
+                        dv_step_result *result, double *scene_fam);
+
 /* ---- measurement ------------------------------------------------------- */
 /* hipEvent pair on the context's stream around whatever is enqueued between the two calls. */
 int dv_timer_start(dv_ctx *ctx);

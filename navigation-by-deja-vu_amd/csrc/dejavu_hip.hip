@@ -3065,3 +3065,5 @@ extern "C" int dv_stream_read_gbps(dv_ctx* c, int64_t n_bytes, int iters, double
     *gbps = (double)n16 * 16.0 * iters / (ms * 1e-3) / 1e9;
     return DV_OK;
 }
+
+#include "dejavu_group.inl"     // dv_group_*: one process, several devices -- host logic above the C ABI

@@ -11,6 +11,7 @@ from .agent import (NavBySceneFamiliarity, StopNavigationException, ReachedEndOf
                     OutOfLandscapeBoundsException, fill_sensor_from, downscale_chem)
 from .util import sads_familiarity, hip_sads_familiarity, ssd_familiarity
 from .engine import FamiliarityEngine
+from .group import FamiliarityGroup
 from ._native import EngineError
 from . import synth
 from .experiment import run_experiment, run_ensemble, chop_path_to_len
@@ -19,6 +20,6 @@ from .ensemble import NavEnsemble
 __all__ = [
     "NavBySceneFamiliarity", "StopNavigationException", "ReachedEndOfTrainingPathException",
     "NavigatingFailedException", "TooFarFromTrainingPathException", "OutOfLandscapeBoundsException",
-    "sads_familiarity", "hip_sads_familiarity", "ssd_familiarity", "FamiliarityEngine", "EngineError",
+    "sads_familiarity", "hip_sads_familiarity", "ssd_familiarity", "FamiliarityEngine", "FamiliarityGroup", "EngineError",
     "fill_sensor_from", "downscale_chem", "synth", "run_experiment", "run_ensemble", "chop_path_to_len", "NavEnsemble",
 ]

@@ -183,6 +183,18 @@ PROTOTYPES = {
     "dv_mailbox_wait": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, _f64p, ctypes.c_int64, ctypes.c_int]),
     "dv_merge_records": (ctypes.c_int, [_f64p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                                         ctypes.POINTER(MergeOut)]),
+    "dv_group_create": (ctypes.c_int, [ctypes.POINTER(_ctx_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "dv_group_destroy": (None, [_ctx_p]),
+    "dv_group_last_error": (ctypes.c_char_p, [_ctx_p]),
+    "dv_group_size": (ctypes.c_int, [_ctx_p]),
+    "dv_group_member": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.POINTER(_ctx_p), _i64p, _i64p]),
+    "dv_group_set_library": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
+    "dv_group_set_landscape": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dv_group_configure_sensor": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u8p, ctypes.c_int]),
+    "dv_group_score": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
+    "dv_group_step": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
+    "dv_group_sense_step": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, _f64p, ctypes.c_int, ctypes.c_uint32,
+                                           ctypes.POINTER(StepResult), _f64p]),
     "dv_synchronize": (ctypes.c_int, [_ctx_p]),
     "dv_timer_start": (ctypes.c_int, [_ctx_p]),
     "dv_timer_stop": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_float)]),

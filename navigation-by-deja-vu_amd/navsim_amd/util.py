@@ -7,7 +7,7 @@ import numpy as np
 from .engine import FamiliarityEngine
 
 
-def sads_familiarity(chem_weight=0.0, device=0, exact=False):
+def sads_familiarity(chem_weight=0.0, device=0, exact=False, devices=None):
     """Two-stage factory with the reference's shape.
 
     stage 1  sads_familiarity(chem_weight)          binds the weight          (util.pyx:10)
@@ -18,7 +18,13 @@ def sads_familiarity(chem_weight=0.0, device=0, exact=False):
     Extras carried by `func` (used by the agent's fused step): func.engine, func.chem_weight.
     `exact=True` makes every fambuf value the reference's double bit for bit (slower fp64 kernel);
     the default integer-sum scores are within 1e-12 relative of it.
+    `devices=[d0, d1, ...]`: ONE process, the library cut into contiguous blocks over these devices
+    (navsim_amd.group.FamiliarityGroup over a dv_group); func.engine.step is then the merged, unsharded decision.  The agent
+    senses its patches with the host sensor model in that form.
     """
+    if devices is not None:
+        return _group_sads_familiarity(chem_weight, list(devices))
+
     def bind(engine, scenes):
         maxfam = scenes[0].shape[0] * scenes[0].shape[1]
 
@@ -44,6 +50,25 @@ def sads_familiarity(chem_weight=0.0, device=0, exact=False):
 
     sads_familiarity_internal.make_engine = make_engine
     sads_familiarity_internal.from_engine = bind
+    sads_familiarity_internal.chem_weight = chem_weight
+    return sads_familiarity_internal
+
+
+def _group_sads_familiarity(chem_weight, devices):
+    def sads_familiarity_internal(scenes):
+        assert 0 <= chem_weight <= 1
+        from .group import FamiliarityGroup
+        group = FamiliarityGroup(devices)
+        group.set_library(scenes, chem_weight)
+
+        def func(scene, fambuf):
+            group.score(scene, fambuf)
+
+        func.max_familiarity = scenes[0].shape[0] * scenes[0].shape[1]
+        func.engine = group
+        func.chem_weight = chem_weight
+        return func
+
     sads_familiarity_internal.chem_weight = chem_weight
     return sads_familiarity_internal
 
