@@ -429,6 +429,15 @@ def roofline_block(eng, info, shape, kern_ms, kern_n, F, h, w, A, cw, workload, 
         peak = 256 * 4 * 64 / 4.0 * CLOCK_PEAK_GHZ * 1e9
         out["valu"] = {"lane_ops_per_launch": lane_ops, "achieved": lane_ops / t, "peak": peak, "unit": "v_sad_u8 lane-ops/s",
                        "frac": lane_ops / t / peak, "clock_ghz_assumed": CLOCK_PEAK_GHZ}
+        if info["generic_hue"]:
+            # k_sad_generic selects |S_s - S_f| or S_s + S_f per byte by comparing the hue bytes: per library dword and heading the
+            # built kernel issues 13 full-rate vector instructions for the H, S pair (xor, 6 v_bitop3, shift, subtract, add, 3 v_sad_u8:
+            # llvm-objdump of the shipped code object) and one v_sad_u8 for V -- its instruction stream, not the byte count, is the bound
+            per_dword = 13.0 * (1 if info["n_planes"] >= 2 else 0) + (1.0 if info["has_value_plane"] else 0.0)
+            lane_ops = float(apad) * F * h * w * per_dword / 4.0
+            out["valu"] = {"lane_ops_per_launch": lane_ops, "achieved": lane_ops / t, "peak": peak, "unit": "full-rate VALU lane-ops/s",
+                           "frac": lane_ops / t / peak, "clock_ghz_assumed": CLOCK_PEAK_GHZ, "instructions_per_dword_and_heading": per_dword,
+                           "what": "k_sad_generic: hue compare + select + three v_sad_u8 per H, S dword and heading, one v_sad_u8 per V dword"}
     if with_ceiling:
         try:
             out["measured_read_ceiling"] = float(eng.stream_read_gbps(1 << 30, 10))
