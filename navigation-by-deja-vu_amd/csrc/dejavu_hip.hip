@@ -210,6 +210,7 @@ struct dv_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool defer_fold = false;                  // enqueue_step: a fused pass leaves its fold to the caller (run_batch launches them last)
     int deferred_force = 0, deferred_seq = 0; // ... with these arguments
+    int chain_order_env = -1;                 // DEJAVU_CHAIN_ORDER (A/B): how a chain of ensemble passes is laid out on its stream, see run_batch
     int chains_env = 2;                       // DEJAVU_CHAINS=1: ensemble passes one after the other on one stream, as in round 3 (A/B)
     StepResultDev* h_result = nullptr;        // pinned, mapped: the kernels write the result record into it
     StepResultDev* d_result = nullptr;        // device-side address of h_result
@@ -357,6 +358,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_TUNE_ALL", c->tune_all_env, 0, 1);
     env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 3);
     env_int("DEJAVU_CHAINS", c->chains_env, 1, 2);
+    env_int("DEJAVU_CHAIN_ORDER", c->chain_order_env, -1, 2);
     env_int("DEJAVU_NT", c->nt_env, 0, 1);
     env_int("DEJAVU_TEST_FAIL_ALLOC", c->fail_alloc_env, 0, 64);
     *out = c;
@@ -1484,7 +1486,7 @@ static int ensure_extra_sets(dv_ctx* c, int want) {
 // its own through the synchronous path, which handles all of that.  `stage(first, n)` makes agents [first, first + n) the resident
 // patches.
 template <class Stage>
-static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_result* results, Stage stage) {
+static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_result* results, Stage stage, bool stage_uploads) {
     struct Pass { int first, n, seq, slot; };
     const int per_pass = kMaxHeadings / A;
     int rc = DV_OK;
@@ -1520,19 +1522,34 @@ static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_res
             const int force = (flags & DV_STEP_FORCE_RESOLVE) ? 1 : 0;
             std::vector<int> seqs((size_t)ng, 0);
             // Pass j of the group lives on stream j & 1 from its preparation to its fold: two chains that share nothing but the
-            // library, each [its preparations][its scoring kernels][its folds] -- no event between the streams
+            // library -- no event between the streams.  A chain's layout (DEJAVU_CHAIN_ORDER, tools/runs/r4_chain.sh; 32 agents x 16
+            // headings, 100 000 views of 64x64, ms per ensemble step sensed / uploaded):
+            //   0  [its preparations][its scoring kernels][its folds]          0.867-0.881 / 1.057-1.082
+            //   1  [preparation, scoring kernel] per pass, [its folds]         0.892-0.920 / 0.999-1.021
+            //   2  [preparation, scoring kernel, fold] per pass                0.893-0.911 / 1.052-1.077
+            // A small kernel between two scoring kernels stalls its chain while the other chain's kernel has the chip to itself, and the
+            // round-filling overlap of the two kernels is lost for that time: sensed patches (nothing but a 10-us preparation per pass)
+            // keep layout 0; uploaded patches take layout 1, where a pass's host-to-device copy runs beside the pass before it.
             auto on = [&](int j) { use_set(c, j + 1); c->stream = (j & 1) ? c->batch_stream : c->own_stream; };
-            for (int j = 0; j < ng && rc == DV_OK; ++j) { on(j); rc = stage(sb + todo[k + j].first, todo[k + j].second); }
-            c->defer_fold = true;
+            const int order = c->chain_order_env >= 0 ? c->chain_order_env : (stage_uploads ? 1 : 0);
+            if (order == 0)
+                for (int j = 0; j < ng && rc == DV_OK; ++j) { on(j); rc = stage(sb + todo[k + j].first, todo[k + j].second); }
+            c->defer_fold = order != 2;
             for (int j = 0; j < ng && rc == DV_OK; ++j) {
                 on(j);
+                if (order != 0) rc = stage(sb + todo[k + j].first, todo[k + j].second);   // a pass's preparation right in front of its scoring kernel
+                if (rc) break;
                 c->result_slot = todo[k + j].first;
                 rc = enqueue_step(c, flags, false);
                 if (rc == DV_OK && !c->epilogue_fused) rc = fail(c, DV_ERR_STATE, "internal: an ensemble pass of a fused library did not fuse");
-                seqs[(size_t)j] = c->deferred_seq;
+                seqs[(size_t)j] = order != 2 ? c->deferred_seq : c->seq;
+                if (order == 2) passes.push_back(Pass{sb + todo[k + j].first, todo[k + j].second, seqs[(size_t)j], todo[k + j].first});
             }
             c->defer_fold = false;
-            for (int j = 0; j < ng && rc == DV_OK; ++j) {
+            // the folds, one per pass on the pass's own chain.  (ONE launch folding all passes of the group behind both chains' last
+            // kernels was measured and gave nothing: 0.856-0.859 against 0.847-0.852 ms per ensemble step -- the two chains' folds
+            // already run side by side, and the host collects the records in the order they arrive.)
+            for (int j = 0; j < ng && rc == DV_OK && order != 2; ++j) {
                 on(j);
                 const int slot = todo[k + j].first;
                 launch_fold(c, c->fused_nb, c->d_result + slot, c->d_record + (size_t)slot * (3 + 4 * kMaxHeadings), force, seqs[(size_t)j],
@@ -1597,7 +1614,7 @@ extern "C" int dv_sense_step_batch(dv_ctx* c, const double* x, const double* y, 
                 poses.p[ag * A + a] = make_pose(x[first + ag], y[first + ag], angles[(size_t)(first + ag) * A + a]);
         for (int a = n * A; a < kMaxHeadings; ++a) poses.p[a] = Pose{0., 0., 1., 0.};
         return sense_prep_launch(c, poses, n, A);
-    });
+    }, false);
 }
 
 // One full agent step's device work in one call: sense the heading patches at (x, y), score them, decide.
@@ -2667,7 +2684,7 @@ extern "C" int dv_step_batch(dv_ctx* c, const uint8_t* patches, int n_agents, in
         c->n_agents = n;
         c->A_agent = A;
         return (int)DV_OK;
-    });
+    }, true);
 }
 
 // Steps of any number of headings: passes of at most kMaxHeadings, merged by the rule of NavBySceneFamiliarity.py:313-315.
