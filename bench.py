@@ -192,7 +192,8 @@ def ensemble_comparisons_per_s(h, w, A, cw, seed, n_agents, n_views, n_steps):
     peak = FP4_MFMA_PEAK_TOPS if fp4 else I8_MFMA_PEAK_TOPS
     return dict(view_comparisons_per_s=best["view_comparisons_per_s"], agent_steps_per_s=n_agents / (best["ms_per_ensemble_step"] * 1e-3),
                 ms_per_ensemble_step=best["ms_per_ensemble_step"], sensed=out["sensed"], uploaded=out["uploaded"],
-                kernel="k_sad_mfma_dual", mfma_form="fp4" if fp4 else "int8", mfma_peak_tops=peak,
+                kernel="k_sad_lc22 (two view groups x two heading tiles per consumer; DEJAVU_LC22=0: k_sad_mfma_dual)",
+                mfma_form="fp4" if fp4 else "int8", mfma_peak_tops=peak,
                 mfma_frac_of_peak=2.0 * best["view_comparisons_per_s"] * k_elems / 1e12 / peak,
                 what="%d agents x %d headings against %d views (%dx%d): one GPU's share of BASELINE.json configs[4]; headline = "
                      "the sensed form; mfma_frac = 2 x comparisons x bit planes (%d) x pixels / s over the dense peak of the form that ran "

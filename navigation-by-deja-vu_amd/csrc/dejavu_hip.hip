@@ -210,6 +210,7 @@ struct dv_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool defer_fold = false;                  // enqueue_step: a fused pass leaves its fold to the caller (run_batch launches them last)
     int deferred_force = 0, deferred_seq = 0; // ... with these arguments
+    int lc22_env = 1;                         // DEJAVU_LC22=0: passes of 64 headings keep one view group per consumer (sad_lc_fp4 with two heading tiles; A/B)
     int chain_order_env = -1;                 // DEJAVU_CHAIN_ORDER (A/B): how a chain of ensemble passes is laid out on its stream, see run_batch
     int chains_env = 2;                       // DEJAVU_CHAINS=1: ensemble passes one after the other on one stream, as in round 3 (A/B)
     StepResultDev* h_result = nullptr;        // pinned, mapped: the kernels write the result record into it
@@ -359,6 +360,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 3);
     env_int("DEJAVU_CHAINS", c->chains_env, 1, 2);
     env_int("DEJAVU_CHAIN_ORDER", c->chain_order_env, -1, 2);
+    env_int("DEJAVU_LC22", c->lc22_env, 0, 1);
     env_int("DEJAVU_NT", c->nt_env, 0, 1);
     env_int("DEJAVU_TEST_FAIL_ALLOC", c->fail_alloc_env, 0, 64);
     *out = c;
@@ -2069,7 +2071,23 @@ static void launch_mfma_dual(dv_ctx* c, int nchunk, int has_hs) {
 // Work items of k_sad_mfma_dual = (chunk of K-steps, range of at most 8*TILES view groups of 32).  Two view groups per wave
 // halve the coefficient traffic (every A operand serves both) once the library is large enough to keep every CU busy that
 // way; very small libraries also cut the K-steps into chunks so that there are about as many items as CUs.
-struct MfmaPlan { bool use_lc, two_tiles; int tiles, nchunk; };
+struct MfmaPlan { bool use_lc, two_tiles, lc22; int tiles, nchunk; };
+// k_sad_lc22 (two view groups x two heading tiles per consumer, bit positions of one width sharing an accumulator) fits this library:
+// per segment the positions 1, 2, 3 that stand for something have one width, the saturation segment has one width altogether and
+// its counts fit the int16 they wait in (sad_lc22_fp4).
+static bool lc22_fits(const dv_ctx* c) {
+    if (!c->lc22_env || !c->fp4_ok || c->bcfg.vcode || c->mixed) return false;
+    for (int seg = 0; seg < 2; ++seg) {
+        int w = 0;
+        for (int bit = 1; bit < 4; ++bit) {
+            const int wb = c->bcfg.wacc[seg][bit];
+            if (wb && w && wb != w) return false;
+            if (wb) w = wb;
+        }
+        if (seg == 0 && c->bcfg.wacc[0][0] && w && c->bcfg.wacc[0][0] != w) return false;
+    }
+    return (long long)c->bcfg.NK[0] * 256 <= 32767;
+}
 // How a matrix-core pass over the resident library is cut for `apad` resident headings (what launch_mfma launches; run_batch asks
 // beforehand whether its passes will finish their scores themselves: one chunk).
 static MfmaPlan mfma_plan(dv_ctx* c, int apad, bool fuse_request) {
@@ -2091,7 +2109,8 @@ static MfmaPlan mfma_plan(dv_ctx* c, int apad, bool fuse_request) {
     }
     // DEJAVU_HT=1 (A/B): 64 resident headings as two passes over the library instead of two heading tiles per view group in one
     p.two_tiles = p.use_lc && apad == 64 && c->ht_env == 2;
-    const long long GQ = item_groups(G32, p.two_tiles ? 4 : 8 * p.tiles);
+    p.lc22 = p.two_tiles && fuse_request && c->fuse_env && !c->mfma_chunk_env && lc22_fits(c) && item_groups(G32, 8) >= 160;
+    const long long GQ = item_groups(G32, p.lc22 ? 8 : (p.two_tiles ? 4 : 8 * p.tiles));
     int nchunk = 1;
     if (c->mfma_chunk_env) {
         nchunk = c->mfma_chunk_env;
@@ -2105,7 +2124,32 @@ static MfmaPlan mfma_plan(dv_ctx* c, int apad, bool fuse_request) {
     if (nchunk > c->nchunk_cap) nchunk = c->nchunk_cap;
     if (nchunk < 1 || c->mixed) nchunk = 1;                              // (mixed layout: the byte pass shares the one-chunk rows of the partial sums)
     p.nchunk = nchunk;
+    if (nchunk != 1) p.lc22 = false;
     return p;
+}
+
+template <int SKL, int RDL>
+static void launch_lc22(dv_ctx* c, int has_hs) {
+    static bool attr_set = false;
+    size_t lds = (size_t)lc22_ring_bytes<SKL, RDL>() + kLc22ParkBytes;
+    const size_t lds8 = (size_t)2 * (4 * 8 + 8 * 4) * 1024;             // the int8 ring body's (off-level patches): <4, 1, 2>
+    if (lds8 > lds) lds = lds8;
+    lds += (size_t)kFuseScratchBytes + 512;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_sad_lc22<SKL, RDL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long long G32 = c->cfg.Fpad / 32;
+    const long long n_gq = item_groups(G32, 8);
+    const unsigned grid = (unsigned)(n_gq < 256 ? n_gq : 256);          // one 8-wave workgroup per CU, grid-stride
+    const int nkt = c->bcfg.NK[0] + c->bcfg.NK[1];
+    FuseArgs fz = fuse_args(c);
+    fz.nb = (int)grid;
+    for (int a_off = 0; a_off < c->APAD; a_off += 64)
+        hipLaunchKernelGGL((k_sad_lc22<SKL, RDL>), dim3(grid), dim3(512), lds, c->stream, c->d_btiles, c->d_coef + (size_t)(a_off / 32) * nkt * 512,
+                           c->d_coef4 + (size_t)(a_off / 32) * nkt * 256, offlevel_word(c), c->cfg, c->bcfg, c->APAD, a_off, has_hs, fz, (int)n_gq);
+    c->epilogue_fused = true;
+    c->fused_nb = (int)grid;
 }
 
 // An ensemble pass of `apad` resident headings would finish its scores inside the scoring kernel (fused epilogue: nothing shared is
@@ -2127,7 +2171,8 @@ static void launch_mfma(dv_ctx* c, int has_hs) {
     // round 2 (other ring shapes: DESIGN.md section 4): int8 500 000 views x 128x128 x 32 headings <1, 3> 1.29 ms, 50 000 views
     // x 64x64 x 16 headings <4, 2> 46.7 us; fp4 <2, 3> 0.95 ms and <2, 4> 34.5 us.
     const int ring = c->ring_env;                                                                   // A/B of ring shapes
-    if (two_tiles && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, true, 2>(c, nchunk, has_hs);
+    if (plan.lc22) launch_lc22<2, 3>(c, has_hs);
+    else if (two_tiles && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, true, 2>(c, nchunk, has_hs);
     else if (two_tiles) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, false, 2>(c, nchunk, has_hs);
     else if (use_lc && c->bcfg.vcode) launch_mfma_dual<4, 2, 2, 4, 1, 4, 3, true>(c, nchunk, has_hs);
     else if (use_lc && lc == 2) launch_mfma_dual<4, 2, 2, 4, 1, 2, 5>(c, nchunk, has_hs);

@@ -4165,6 +4165,306 @@ sad_lc_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, in
     DV_STAMP(5);
 }
 
+// ------------------------------------------------------------------ loader / consumer body, two view groups x two heading tiles
+// sad_lc_fp4 with two heading tiles (HT = 2: the ensemble passes of 64 headings) gives a consumer ONE view group: per K-step it reads
+// eight coefficient rows and one library row from LDS for eight MFMAs, and the CU's LDS moves 4 x 9 KB of reads + 12 KB of LDS-DMA =
+// 1.5 KB per MFMA where 128 B/cycle x 32 cycles / 4 SIMDs = 1 KB would keep the matrix pipe fed: the loop runs at ~626 cycles per
+// K-step against 256 of MFMA time, bound by LDS bandwidth (neither the matrix pipe nor HBM: 3.5 TB/s).  Here a consumer takes TWO
+// view groups and both tiles: the eight coefficient rows serve sixteen MFMAs, (8 + 2) KB of reads + 16 KB of DMA per 64 MFMAs =
+// 0.875 KB per MFMA.  Sixteen accumulators of 16 registers would not fit a wave (2 groups x 2 tiles x 4 bit positions), so the
+// bit positions of one gap width SHARE an accumulator: every position's library bit is moved to the 1.0 bit of its nibble (a shift
+// and a mask; sad_lc_fp4 leaves bits 0 / 1 / 2 where they stand for 0.5 / 1 / 2 and weights the four accumulators at the end), and
+// the sums of +-1 of positions 1, 2, 3 -- whose widths must agree (the host checks: 63, 64, 64, 64 of the five sensor levels do) --
+// accumulate in one register block, position 0 in the other: 8 blocks = 128 registers.  The saturation segment's counts (one width:
+// the host checks) wait for the value segment in LDS as int16 (|count| <= K-elements of the segment <= 32767: the host checks),
+// 8 KB per consumer, so that nothing but the accumulators and the operands lives through the stage loop.
+// Same ring protocol as sad_lc_fp4 (stage = SK K-steps of 16 rows: 8 coefficient + 8 library; loaders 4 SK instructions per stage),
+// fused finishing per heading tile with both view groups (fused_finish<2>).  FUSE forms only, thermometer rows only.
+template <int SK, int RD>
+constexpr int lc22_ring_bytes() { return RD * SK * 16 * 1024; }
+constexpr int kLc22ParkBytes = 4 * 64 * 64 * 2;                         // 4 consumers x [2 groups][2 tiles][16] counts x 64 lanes x int16
+
+template <int SK, int RD>
+__device__ __forceinline__ void
+sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, const LibCfg& c, const BitCfg& b, int apad_total, int a_off,
+             int has_hs_sum, const FuseArgs& fz, int n_gq) {
+    extern __shared__ uint4 lds_ring[];
+    constexpr int HT = 2, TL = 2;
+    constexpr int NW = 8, NC = 4, NL = 4;
+    constexpr int KCOEF = 4 * HT, KLIB = NC * TL;
+    constexpr int COEF_ROWS = SK * KCOEF, ROWS = SK * (KCOEF + KLIB);
+    constexpr int SLOTB = ROWS * 1024;
+    constexpr int PER = ROWS / NL;                                      // LDS-DMA instructions per loader wave and stage
+    constexpr int RING = RD * SLOTB;
+    constexpr int NU = SK * HT;                                         // pipeline units per stage: (K-step, heading tile)
+    static_assert(PER == SK * (HT + TL) && PER * (RD - 1) < 64 && RD >= 3, "ring shape");
+    static_assert(RING + kLc22ParkBytes + kFuseScratchBytes + 512 <= 160 * 1024, "LDS");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= NC;
+    const long long G32 = c.Fpad / 32, GQ = n_gq;
+    const int NKT = b.NK[0] + b.NK[1];
+    const int nst = (NKT + SK - 1) / SK;
+    const int NK0 = b.NK[0];
+    const long long gbytes = (long long)b.GS * 1024;                    // between view groups
+    const long long pass16 = (long long)NKT * 256;                      // uint4 between the coefficient images of two heading tiles
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)lds_ring;
+    unsigned char* lds_bytes = reinterpret_cast<unsigned char*>(lds_ring);
+    short* park = reinterpret_cast<short*>(lds_bytes + RING) + (wave & 3) * (64 * 64);     // this consumer's saturation counts
+    unsigned long long* scratch0 = reinterpret_cast<unsigned long long*>(lds_bytes + RING + kLc22ParkBytes);
+    const unsigned char* lib_bytes = reinterpret_cast<const unsigned char*>(ftiles);
+#pragma unroll
+    for (int h = 0; h < HT; ++h) fused_block_begin(scratch0 + h * 64, h == 0);
+    const long long n_mine = GQ > (long long)blockIdx.x ? (GQ - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;       // items of this workgroup
+
+    if (loader) {
+        // ---- loaders: the stage they issue next, (li, lst) = (item of this workgroup, stage), into ring slot lslot
+        const int lw = wave - NC;
+        long long li = 0;
+        int lst = 0, lslot = 0;
+        const unsigned char* lp[TL];
+        bool llive[TL];
+#pragma unroll
+        for (int t = 0; t < TL; ++t) { lp[t] = lib_bytes; llive[t] = false; }
+        auto loader_item = [&]() {
+#pragma unroll
+            for (int t = 0; t < TL; ++t) llive[t] = false;
+            if (li < n_mine) {
+                const long long item = blockIdx.x + li * gridDim.x;
+                const long long g0 = (item * G32) / GQ, g1 = ((item + 1) * G32) / GQ;
+#pragma unroll
+                for (int t = 0; t < TL; ++t) {
+                    const long long g = g0 + lw + 4 * t;                // slot lw + 4 t of the item's 8: consumer (lw + 4 t) / 2, its group (lw + 4 t) % 2
+                    llive[t] = g < g1;
+                    lp[t] = lib_bytes + (llive[t] ? g : g0) * gbytes + lane * 16;
+                }
+            }
+        };
+        const bool nt_rows = b.nt != 0;
+        auto issue_stage = [&]() {
+            const unsigned slot = lds_base + (unsigned)lslot * (unsigned)SLOTB;
+            const int kb = lst * SK;
+            const uint4* hot = coef4 + lw * 64 + lane;                  // re-read where there is nothing to fetch (hot in L2)
+#pragma unroll
+            for (int i = 0; i < SK * HT; ++i) {                         // coefficient row (K-step kb + kk, heading tile h, bit position lw)
+                const int kk = i / HT, h = i % HT;
+                int k = kb + kk;
+                k = k < NKT ? k : NKT - 1;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((kk * KCOEF + h * 4 + lw) * 1024));
+                lds_dma_16(li < n_mine ? coef4 + h * pass16 + ((long long)k * 4 + lw) * 64 + lane : hot, dst);
+            }
+#pragma unroll
+            for (int i = 0; i < SK * TL; ++i) {                         // library row (K-step kb + kk, slot lw + 4 t)
+                const int kk = i / TL, t = i % TL;
+                int k = kb + kk;
+                k = k < NKT ? k : NKT - 1;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((COEF_ROWS + kk * KLIB + lw + 4 * t) * 1024));
+                if (!llive[t]) lds_dma_16(hot, dst);
+                else if (nt_rows) lds_dma_16_nt(reinterpret_cast<const uint4*>(lp[t] + (long long)k * 1024), dst);
+                else lds_dma_16(reinterpret_cast<const uint4*>(lp[t] + (long long)k * 1024), dst);
+            }
+            lslot = lslot + 1 == RD ? 0 : lslot + 1;
+            if (++lst == nst) { lst = 0; ++li; loader_item(); }
+        };
+        loader_item();
+#pragma unroll
+        for (int r = 0; r < RD - 1; ++r) issue_stage();
+        for (long long j = 0; j < n_mine; ++j) {
+            for (int st = 0; st < nst; ++st) {
+                wait_vmcnt_le<PER * (RD - 2)>();                        // this wave's rows of stage (j, st) have landed ...
+                __builtin_amdgcn_s_barrier();                           // ... everybody's have; nobody still reads the slot before it
+                issue_stage();                                          // (may belong to the next item: its pipeline fill)
+            }
+#pragma unroll
+            for (int h = 0; h < HT; ++h)                                // the barriers of the consumers' finishing (three per call)
+                if (a_off + 32 * h < fz.A_real) fused_finish_idle();
+        }
+        wait_vmcnt_le<0>();                                             // the re-reads past the last item
+    } else {
+        // ---- consumers
+        int cslot = 0;                                                  // ring slot of the current stage
+        int nfin = 0;                                                   // fused_finish calls so far (their parity)
+        int hconst[HT][2];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            const int a = a_off + 32 * h + (lane & 31), ac = a < fz.A_real ? a : fz.A_real - 1;
+            hconst[h][0] = acc_sum(fz.hsconst, ac);
+            hconst[h][1] = fz.vconst ? acc_sum(fz.vconst, ac) : 0;
+        }
+        // widths of the two accumulator classes, per segment: position 0 | positions 1, 2, 3 (equal where they stand for something)
+        auto w_of = [&](int seg, int cls) -> int {
+            if (cls == 0) return b.wacc[seg][0];
+            const int w1 = b.wacc[seg][1], w2 = b.wacc[seg][2], w3 = b.wacc[seg][3];
+            return w1 ? w1 : (w2 ? w2 : w3);
+        };
+        const int whs = w_of(0, 0) ? w_of(0, 0) : w_of(0, 1);          // the saturation segment's one width
+        for (long long j = 0; j < n_mine; ++j) {
+            const long long item = blockIdx.x + j * gridDim.x;
+            const long long g0 = (item * G32) / GQ, g1 = ((item + 1) * G32) / GQ;
+            long long gidx[TL];
+            bool live[TL];
+#pragma unroll
+            for (int t = 0; t < TL; ++t) {
+                const long long g = g0 + wave * TL + t;
+                live[t] = g < g1;
+                gidx[t] = live[t] ? g : g0;
+            }
+            int tot_v[TL][HT][16];
+            {
+                v16f_t acc[TL][HT][2];
+                auto clear = [&]() {
+#pragma unroll
+                    for (int t = 0; t < TL; ++t)
+#pragma unroll
+                        for (int h = 0; h < HT; ++h)
+#pragma unroll
+                            for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[t][h][cl][r] = 0.f;
+                };
+                clear();
+                // operand registers: unit q = (K-step q / 2, heading tile q % 2) reads its four coefficient rows into a[q & 1]; the
+                // two library rows of a K-step arrive with its first unit in xl[k & 1], and their masked operands bo are made once
+                v4u_t a[2][4], xl[2][TL];
+                auto fetch = [&](int slot_i, auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    constexpr int k = q / HT, h = q % HT;
+                    const unsigned sad = lds_base + (unsigned)slot_i * (unsigned)SLOTB + (unsigned)lane * 16u;
+                    static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * KCOEF + h * 4 + s_) * 1024>(a[q & 1][s_], sad); });
+                    if constexpr (h == 0) {
+                        const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * TL * 1024);
+                        static_for<TL>([&](auto tc) { constexpr int t_ = decltype(tc)::value; lds_read16<(k * KLIB + t_) * 1024>(xl[k & 1][t_], lad); });
+                    }
+                };
+                __builtin_amdgcn_s_barrier();                           // stage (j, 0) is in LDS
+                fetch(cslot, IntC<0>{});
+                auto run_stages = [&](int s0, int s1) {
+                    for (int st = s0; st < s1; ++st) {
+                        const int kb = st * SK;
+                        const int nslot = cslot + 1 == RD ? 0 : cslot + 1;
+                        unsigned bo[TL][4][4];                          // the K-step's masked library operands, made once for both heading tiles
+                        static_for<NU>([&](auto qc) {
+                            constexpr int q = decltype(qc)::value;
+                            constexpr int k = q / HT, h = q % HT;
+                            if constexpr (q + 1 < NU) {
+                                fetch(cslot, IntC<q + 1>{});            // one unit ahead
+                                constexpr int h1 = (q + 1) % HT;
+                                lds_wait<4 + (h1 == 0 ? TL : 0)>();     // all but the newest unit's reads have landed
+                            } else {
+                                lds_wait<0>();                          // everything this wave will use of the slot is in registers
+                                if (st + 1 < nst) {
+                                    __builtin_amdgcn_s_barrier();       // stage st + 1 is in LDS; the loaders may refill slot st - 1 ... and,
+                                    fetch(nslot, IntC<0>{});            //   one barrier later, this one
+                                }
+                            }
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) lds_tie(a[q & 1][s]);
+                            if constexpr (h == 0) {
+#pragma unroll
+                                for (int t = 0; t < TL; ++t) lds_tie(xl[k & 1][t]);
+                                // every position's bit to the 1.0 bit of its nibble (E2M1 0010): positions 0 / 2 / 3 by a shift
+                                const unsigned m = kb + k < NKT ? 0x22222222u : 0u;
+#pragma unroll
+                                for (int t = 0; t < TL; ++t) {
+                                    const unsigned x[4] = {xl[k & 1][t].x, xl[k & 1][t].y, xl[k & 1][t].z, xl[k & 1][t].w};
+#pragma unroll
+                                    for (int d = 0; d < 4; ++d) {
+                                        bo[t][0][d] = (x[d] << 1) & m;
+                                        bo[t][1][d] = x[d] & m;
+                                        bo[t][2][d] = (x[d] >> 1) & m;
+                                        bo[t][3][d] = (x[d] >> 2) & m;
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const v4u_t& av = a[q & 1][s];
+                                const v8i_t ao = v8i_t{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+#pragma unroll
+                                for (int t = 0; t < TL; ++t) {
+                                    const v8i_t bv = v8i_t{(int)bo[t][s][0], (int)bo[t][s][1], (int)bo[t][s][2], (int)bo[t][s][3], 0, 0, 0, 0};
+                                    acc[t][h][s ? 1 : 0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bv, ao, acc[t][h][s ? 1 : 0], 4, 4, 0, 0, 0, 0);   // views x headings
+                                }
+                            }
+                        });
+                        cslot = nslot;
+                    }
+                };
+                // saturation stages (when the library has that segment), then the value stages; the accumulators change hands at the boundary
+                const int nst0 = has_hs_sum ? (NK0 / SK < nst ? NK0 / SK : nst) : 0;     // (NK0 is a whole number of stages)
+                const int hs_end = (has_hs_sum && !(c.hasv && b.NK[1] > 0)) ? nst : nst0;
+                run_stages(0, hs_end);
+                if (hs_end > 0) {
+                    if (hs_end < nst) {                                 // the next stage's first operands are on their way: let them land
+                        lds_wait<0>();                                  // before any compiler-made LDS traffic (once per item)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) lds_tie(a[0][s]);
+#pragma unroll
+                        for (int t = 0; t < TL; ++t) lds_tie(xl[0][t]);
+                    }
+                    // the segment's counts (one width) into this consumer's LDS block: [t][h][r][lane]
+#pragma unroll
+                    for (int t = 0; t < TL; ++t)
+#pragma unroll
+                        for (int h = 0; h < HT; ++h)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                park[((t * HT + h) * 16 + r) * 64 + lane] = (short)((int)acc[t][h][0][r] + (int)acc[t][h][1][r]);
+                    if (hs_end < nst) clear();
+                }
+                if (hs_end < nst) {
+                    run_stages(hs_end, nst);
+                    const int w0 = w_of(1, 0), w1 = w_of(1, 1);
+#pragma unroll
+                    for (int t = 0; t < TL; ++t)
+#pragma unroll
+                        for (int h = 0; h < HT; ++h)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) tot_v[t][h][r] = __mul24(w0, (int)acc[t][h][0][r]) + __mul24(w1, (int)acc[t][h][1][r]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TL; ++t)
+#pragma unroll
+                        for (int h = 0; h < HT; ++h)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) tot_v[t][h][r] = 0;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                auto of_hs = [&](int t, int r) -> int { return __mul24(whs, (int)park[((t * HT + h) * 16 + r) * 64 + lane]); };
+                auto of_v = [&](int t, int r) -> int { return tot_v[t][h][r]; };
+                if (a_off + 32 * h < fz.A_real)                         // (uniform: a heading tile without headings has nothing to finish)
+                    fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC,
+                                               hconst[h], scratch0 + kFuseBlk + h * 64);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HT; ++h)
+        if (a_off + 32 * h < fz.A_real) fused_block_end(scratch0 + h * 64, fz, c, a_off + 32 * h);
+    (void)apad_total;
+}
+
+// The pass of 64 headings with that body; off-level patches take the int8 ring body per heading tile, as in k_sad_mfma_dual (the
+// same ranges of eight view groups).  Fused finishing only: the passes of an ensemble step.
+template <int SKL, int RDL>
+__global__ void __launch_bounds__(512, 2)
+k_sad_lc22(const uint4* __restrict__ btiles, const uint4* __restrict__ coef, const uint4* __restrict__ coef4, const unsigned* __restrict__ offlevel,
+           LibCfg c, BitCfg b, int apad_total, int a_off, int has_hs_sum, FuseArgs fz, int n_gq) {
+    const bool fp4 = __builtin_amdgcn_readfirstlane(*offlevel) == 0u;
+    if (fp4) {
+        sad_lc22_fp4<SKL, RDL>(btiles, coef4, c, b, apad_total, a_off, has_hs_sum, fz, n_gq);
+        return;
+    }
+    const int NKT = b.NK[0] + b.NK[1];
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if (h > 0 && a_off + 32 * h >= apad_total) break;
+        sad_ring_i8<4, 1, 2, true>(btiles, coef + (long long)h * NKT * 512, nullptr, c, b, 1, apad_total, a_off + 32 * h, has_hs_sum, fz, n_gq);
+    }
+}
+
 // One launch, both forms: `offlevel` (k_patch_prep) says whether this step's patches allow the fp4 coefficients.  The loader /
 // consumer body of the fp4 form reads ftiles (the code tiles when the library has them, else the bit tiles), everything else the
 // bit tiles.

@@ -654,3 +654,46 @@ def test_begun_agent_step_is_superseded_by_any_other_call():
     finally:
         if agent is not None:
             agent.clear_training()
+
+
+# ------------------------------------------------------------------ passes of 64 headings: two view groups x two heading tiles per consumer
+@pytest.mark.parametrize("cw", [0.25, 0.0, 1.0])
+def test_passes_of_64_headings_with_shared_accumulators_match_the_oracle(cw):
+    """k_sad_lc22 (ensemble passes of 64 headings on libraries of >= 1280 view-group ranges: two view groups and two heading tiles per
+    consumer, the bit positions of one gap width in one accumulator, the saturation counts parked in LDS) against the oracle on EVERY
+    view: agents on the library's levels (fp4 form), agents with off-level value bytes (the kernel's int8 body for the whole pass),
+    exact duplicates across view groups (resolver), a short last pass -- and the records of the one-view-group body (DEJAVU_LC22=0)."""
+    F, h, w, A, n_agents, seed = 41500, 16, 16, 16, 11, 77          # 11 agents x 16 headings: passes of 64, 64 and 48 headings
+    lib = synth.synth_views(seed, F, h, w)
+    lib[40000] = lib[123]                                            # duplicates in different ranges of view groups
+    on = synth.synth_patches(seed + 3, n_agents * A, h, w).reshape(n_agents, A, h, w, 3)
+    on[2, 5] = lib[123]
+    on[7, 0] = synth.near_match_patch(lib[31000], 5, fraction=0.02)
+    on[10, 15] = lib[41499]
+    off = on.copy()
+    off[..., 2] = synth.random_hsv(seed + 9, off.shape[:-1])         # value bytes between the levels: every pass takes the int8 body
+    off[4, 3] = lib[777]
+    got = {}
+    for knob in ("1", "0"):
+        eng = _engine({"DEJAVU_LC22": knob})
+        try:
+            eng.set_library(lib, cw)
+            for name, patches in (("on", on), ("off", off)):
+                eng.step_batch(patches)                                  # (the first call times the kernel forms)
+                got[knob, name] = eng.step_batch(patches)
+                if knob == "1" and name == "on" and cw < 1.0:
+                    assert eng.scoring_form()["fp4"], eng.scoring_form()
+        finally:
+            eng.close()
+    for name, patches in (("on", on), ("off", off)):
+        res, ref = got["1", name], got["0", name]
+        for ag in range(n_agents):
+            want = oracle.step(lib, patches[ag], cw, want_scene=False)
+            assert res[ag]["best_idex"] == want["best_idex"], (name, ag, res[ag]["flags"], res[ag]["n_candidates"])
+            assert res[ag]["best_view"] == want["best_view"], (name, ag)
+            np.testing.assert_allclose(res[ag]["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+            np.testing.assert_allclose(res[ag]["step_familiarity"], want["step_familiarity"], rtol=RTOL)
+            assert (ref[ag]["best_idex"], ref[ag]["best_view"]) == (res[ag]["best_idex"], res[ag]["best_view"])
+            assert np.array_equal(ref[ag]["angle_familiarity"], res[ag]["angle_familiarity"])       # the same integer sums either way
+    if cw < 1.0:
+        assert (got["1", "on"][2]["best_idex"], got["1", "on"][2]["best_view"]) == (5, 123)      # the first of the two duplicates

@@ -193,7 +193,7 @@ def test_shipped_scoring_kernels_use_no_scratch():
     # the loader / consumer body that ships (fused and unfused, one and two heading tiles) and the SSD matrix-core kernels
     for name in ("k_sad_mfma_dual<4, 2, 2, 4, 1, true, 4, 3, false, 1>", "k_sad_mfma_dual<4, 2, 2, 4, 1, false, 4, 3, false, 1>",
                  "k_sad_mfma_dual<4, 2, 2, 4, 1, true, 4, 3, false, 2>", "k_sad_mfma_dual<4, 2, 2, 4, 1, false, 4, 3, false, 2>",
-                 "k_ssd_u8_mfma<1>", "k_ssd_u8_mfma<2>"):
+                 "k_sad_lc22<2, 3>", "k_ssd_u8_mfma<1>", "k_ssd_u8_mfma<2>"):
         row = [r for r in rows if r["name"] == name]
         assert row and row[0]["scratch"] == 0 and row[0]["vgpr"] <= 256, name
 

@@ -8,7 +8,7 @@ python3 - <<PY
 import csv, glob, os
 t = max(glob.glob("$OUT/**/*_kernel_trace.csv", recursive=True), key=os.path.getsize)
 rows = sorted(csv.DictReader(open(t)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_sad_mfma_dual" in r["Kernel_Name"] and "true, 4, 3, false, 2" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_sad_lc22" in r["Kernel_Name"] or ("k_sad_mfma_dual" in r["Kernel_Name"] and "true, 4, 3, false, 2" in r["Kernel_Name"])]
 i = idx[-12]
 t0 = int(rows[i]["Start_Timestamp"])
 for r in rows[i-2:i+40]:

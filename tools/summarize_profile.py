@@ -50,7 +50,7 @@ def main():
     d = sys.argv[1]
     ks = kernel_stats(d)
     out = dict(kernels=ks)
-    for kern in ("k_sad_mfma", "k_patch_prep", "k_fold", "k_sad_tiles", "k_sad_packed", "k_sad_generic", "k_ssd_tiles", "k_ssd_f32_mfma", "k_ssd_f32_bf16x2", "k_ssd_u8_mfma", "k_finish", "k_combine",
+    for kern in ("k_sad_mfma", "k_sad_lc22", "k_patch_prep", "k_fold", "k_sad_tiles", "k_sad_packed", "k_sad_generic", "k_ssd_tiles", "k_ssd_f32_mfma", "k_ssd_f32_bf16x2", "k_ssd_u8_mfma", "k_finish", "k_combine",
                  "k_tail", "k_resolve_f32", "k_cand_f32x"):
         c = {}
         for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst", "pmc_sqc"):
