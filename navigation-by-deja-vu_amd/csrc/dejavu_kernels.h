@@ -4213,6 +4213,7 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
     short* park = reinterpret_cast<short*>(lds_bytes + RING) + (wave & 3) * (64 * 64);     // this consumer's saturation counts
     unsigned long long* scratch0 = reinterpret_cast<unsigned long long*>(lds_bytes + RING + kLc22ParkBytes);
     const unsigned char* lib_bytes = reinterpret_cast<const unsigned char*>(ftiles);
+    DV_STAMP(0);
 #pragma unroll
     for (int h = 0; h < HT; ++h) fused_block_begin(scratch0 + h * 64, h == 0);
     const long long n_mine = GQ > (long long)blockIdx.x ? (GQ - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;       // items of this workgroup
@@ -4251,10 +4252,16 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
                 int k = kb + kk;
                 k = k < NKT ? k : NKT - 1;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)((kk * KCOEF + h * 4 + lw) * 1024));
+#ifdef DEJAVU_EXP22             // (timing experiments, tools/runs/r4_lc22_exp.sh: bit 2 leaves out the coefficient rows, bit 1 the library rows)
+                if (DEJAVU_EXP22 & 4) continue;
+#endif
                 lds_dma_16(li < n_mine ? coef4 + h * pass16 + ((long long)k * 4 + lw) * 64 + lane : hot, dst);
             }
 #pragma unroll
             for (int i = 0; i < SK * TL; ++i) {                         // library row (K-step kb + kk, slot lw + 4 t)
+#ifdef DEJAVU_EXP22
+                if (DEJAVU_EXP22 & 2) continue;
+#endif
                 const int kk = i / TL, t = i % TL;
                 int k = kb + kk;
                 k = k < NKT ? k : NKT - 1;
@@ -4271,7 +4278,11 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
         for (int r = 0; r < RD - 1; ++r) issue_stage();
         for (long long j = 0; j < n_mine; ++j) {
             for (int st = 0; st < nst; ++st) {
+#ifdef DEJAVU_EXP22
+                wait_vmcnt_le<(((DEJAVU_EXP22 & 4) ? 0 : SK * HT) + ((DEJAVU_EXP22 & 2) ? 0 : SK * TL)) * (RD - 2)>();
+#else
                 wait_vmcnt_le<PER * (RD - 2)>();                        // this wave's rows of stage (j, st) have landed ...
+#endif
                 __builtin_amdgcn_s_barrier();                           // ... everybody's have; nobody still reads the slot before it
                 issue_stage();                                          // (may belong to the next item: its pipeline fill)
             }
@@ -4330,6 +4341,9 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
                     constexpr int q = decltype(qc)::value;
                     constexpr int k = q / HT, h = q % HT;
                     const unsigned sad = lds_base + (unsigned)slot_i * (unsigned)SLOTB + (unsigned)lane * 16u;
+#ifdef DEJAVU_EXP22
+                    if ((DEJAVU_EXP22 & 16) && q > 0) return;                     // bit 4: only the stage's first unit reads its operands
+#endif
                     static_for<4>([&](auto sc) { constexpr int s_ = decltype(sc)::value; lds_read16<(k * KCOEF + h * 4 + s_) * 1024>(a[q & 1][s_], sad); });
                     if constexpr (h == 0) {
                         const unsigned lad = sad + (unsigned)(COEF_ROWS * 1024 + wave * TL * 1024);
@@ -4337,6 +4351,7 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
                     }
                 };
                 __builtin_amdgcn_s_barrier();                           // stage (j, 0) is in LDS
+                if (j == 0) DV_STAMP(1);
                 fetch(cslot, IntC<0>{});
                 auto run_stages = [&](int s0, int s1) {
                     for (int st = s0; st < s1; ++st) {
@@ -4369,6 +4384,9 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
                                     const unsigned x[4] = {xl[k & 1][t].x, xl[k & 1][t].y, xl[k & 1][t].z, xl[k & 1][t].w};
 #pragma unroll
                                     for (int d = 0; d < 4; ++d) {
+#ifdef DEJAVU_EXP22
+                                        if (DEJAVU_EXP22 & 8) { bo[t][0][d] = bo[t][1][d] = bo[t][2][d] = bo[t][3][d] = x[d]; continue; }   // bit 3: no masks
+#endif
                                         bo[t][0][d] = (x[d] << 1) & m;
                                         bo[t][1][d] = x[d] & m;
                                         bo[t][2][d] = (x[d] >> 1) & m;
@@ -4383,6 +4401,12 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
 #pragma unroll
                                 for (int t = 0; t < TL; ++t) {
                                     const v8i_t bv = v8i_t{(int)bo[t][s][0], (int)bo[t][s][1], (int)bo[t][s][2], (int)bo[t][s][3], 0, 0, 0, 0};
+#ifdef DEJAVU_EXP22
+                                    if (DEJAVU_EXP22 & 1) {                       // bit 0: no MFMA (the operands are consumed by one vector operation each)
+                                        acc[t][h][s ? 1 : 0][0] += __int_as_float(bv[0] ^ ao[0] ^ bv[1] ^ ao[1] ^ bv[2] ^ ao[2] ^ bv[3] ^ ao[3]);
+                                        continue;
+                                    }
+#endif
                                     acc[t][h][s ? 1 : 0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bv, ao, acc[t][h][s ? 1 : 0], 4, 4, 0, 0, 0, 0);   // views x headings
                                 }
                             }
@@ -4430,14 +4454,26 @@ sad_lc22_fp4(const uint4* __restrict__ ftiles, const uint4* __restrict__ coef4, 
                             for (int r = 0; r < 16; ++r) tot_v[t][h][r] = 0;
                 }
             }
+            if (j == 0) DV_STAMP(2);                                   // (diagnostic builds: the first item's loop, sums and parking are done)
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
+                if (j == 0) DV_STAMP(3 + h);                            // 3, 4: in front of the first / second heading tile's finishing
                 auto of_hs = [&](int t, int r) -> int { return __mul24(whs, (int)park[((t * HT + h) * 16 + r) * 64 + lane]); };
                 auto of_v = [&](int t, int r) -> int { return tot_v[t][h][r]; };
+#ifdef DEJAVU_EXP22             // bit 5: the finishing's barriers only (the timing builds' sums are not worth finishing)
+                if (DEJAVU_EXP22 & 32) {
+                    if (a_off + 32 * h < fz.A_real) {
+                        if (of_hs(0, 0) + of_v(1, 15) == 0x7fffffff) park[lane] = 1;       // (the sums stay live)
+                        fused_finish_idle();
+                    }
+                    continue;
+                }
+#endif
                 if (a_off + 32 * h < fz.A_real)                         // (uniform: a heading tile without headings has nothing to finish)
                     fused_finish<TL, NW, true>(of_hs, of_v, gidx, live, scratch0, c, fz, a_off + 32 * h, has_hs_sum, j, lane, wave, nfin++ & 1, NC,
                                                hconst[h], scratch0 + kFuseBlk + h * 64);
             }
+            if (j == 0) DV_STAMP(5);                                    // behind both
         }
     }
 #pragma unroll
