@@ -207,6 +207,7 @@ struct dv_ctx {
     int n_extra = 0;                          // extra sets allocated (at the first ensemble call on this library that wants them)
     int cur_set = 0;                          // which set is in the fields
     hipStream_t batch_stream = nullptr;       // the second hardware queue of the scoring kernels
+    hipStream_t batch_stream3 = nullptr;      // a third one (DEJAVU_CHAINS=3, A/B)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool defer_fold = false;                  // enqueue_step: a fused pass leaves its fold to the caller (run_batch launches them last)
     int deferred_force = 0, deferred_seq = 0; // ... with these arguments
@@ -358,7 +359,7 @@ extern "C" int dv_create(dv_ctx** out, int device_id) {
     env_int("DEJAVU_MIXED", c->mixed_env, 0, 1);
     env_int("DEJAVU_TUNE_ALL", c->tune_all_env, 0, 1);
     env_int("DEJAVU_SSD_MFMA", c->ssd_mfma_env, 0, 3);
-    env_int("DEJAVU_CHAINS", c->chains_env, 1, 2);
+    env_int("DEJAVU_CHAINS", c->chains_env, 1, 3);
     env_int("DEJAVU_CHAIN_ORDER", c->chain_order_env, -1, 2);
     env_int("DEJAVU_LC22", c->lc22_env, 0, 1);
     env_int("DEJAVU_NT", c->nt_env, 0, 1);
@@ -388,6 +389,7 @@ extern "C" void dv_destroy(dv_ctx* c) {
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->batch_stream) { (void)hipStreamSynchronize(c->batch_stream); (void)hipStreamDestroy(c->batch_stream); }
+    if (c->batch_stream3) { (void)hipStreamSynchronize(c->batch_stream3); (void)hipStreamDestroy(c->batch_stream3); }
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1442,6 +1444,7 @@ static int ensure_extra_sets(dv_ctx* c, int want) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&c->batch_stream, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); c->batch_stream = nullptr; return 0; }
+        if (c->chains_env == 3 && hipStreamCreateWithPriority(&c->batch_stream3, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); c->batch_stream3 = nullptr; }
     }
     if (!c->ev_a && hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->ev_a = nullptr; return 0; }
     if (!c->ev_b && hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->ev_b = nullptr; return 0; }
@@ -1495,7 +1498,11 @@ static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_res
     const int full_total = per_pass * A;                                // resident headings of a full pass
     const int full_apad = full_total <= 8 ? 8 : (full_total <= 16 ? 16 : (full_total <= 32 ? 32 : 64));
     bool first_pass_seen = false;
-    auto sync_both = [&]() { (void)hipStreamSynchronize(c->stream); if (c->batch_stream) (void)hipStreamSynchronize(c->batch_stream); };
+    auto sync_both = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->batch_stream) (void)hipStreamSynchronize(c->batch_stream);
+        if (c->batch_stream3) (void)hipStreamSynchronize(c->batch_stream3);
+    };
     for (int sb = 0; sb < n_agents && rc == DV_OK; sb += kMaxHeadings) {
         const int cnt = (n_agents - sb < kMaxHeadings) ? n_agents - sb : kMaxHeadings;
         std::vector<Pass> passes;
@@ -1532,7 +1539,8 @@ static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_res
             // A small kernel between two scoring kernels stalls its chain while the other chain's kernel has the chip to itself, and the
             // round-filling overlap of the two kernels is lost for that time: sensed patches (nothing but a 10-us preparation per pass)
             // keep layout 0; uploaded patches take layout 1, where a pass's host-to-device copy runs beside the pass before it.
-            auto on = [&](int j) { use_set(c, j + 1); c->stream = (j & 1) ? c->batch_stream : c->own_stream; };
+            const int nch = c->batch_stream3 ? 3 : 2;
+            auto on = [&](int j) { use_set(c, j + 1); const int ch = j % nch; c->stream = ch == 0 ? c->own_stream : (ch == 1 ? c->batch_stream : c->batch_stream3); };
             const int order = c->chain_order_env >= 0 ? c->chain_order_env : (stage_uploads ? 1 : 0);
             if (order == 0)
                 for (int j = 0; j < ng && rc == DV_OK; ++j) { on(j); rc = stage(sb + todo[k + j].first, todo[k + j].second); }
@@ -1574,6 +1582,7 @@ static int run_batch(dv_ctx* c, int n_agents, int A, uint32_t flags, dv_step_res
         if (!polled) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->batch_stream) HIP_TRY(c, hipStreamSynchronize(c->batch_stream));
+            if (c->batch_stream3) HIP_TRY(c, hipStreamSynchronize(c->batch_stream3));
         }
         std::vector<Pass> again;
         for (const Pass& p : passes) {

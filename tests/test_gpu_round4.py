@@ -697,3 +697,18 @@ def test_passes_of_64_headings_with_shared_accumulators_match_the_oracle(cw):
             assert np.array_equal(ref[ag]["angle_familiarity"], res[ag]["angle_familiarity"])       # the same integer sums either way
     if cw < 1.0:
         assert (got["1", "on"][2]["best_idex"], got["1", "on"][2]["best_view"]) == (5, 123)      # the first of the two duplicates
+    # the reference's default n_test_angles = 60 (NavBySceneFamiliarity.py:62) is ONE pass of 64 resident headings: a single agent's
+    # step takes the same kernel
+    eng = _engine()
+    try:
+        eng.set_library(lib, cw)
+        p60 = on.reshape(-1, h, w, 3)[:60].copy()
+        p60[41] = lib[40000 - 1]
+        for _ in range(2):
+            r = eng.step(p60, want_scene=False)
+        want = oracle.step(lib, p60, cw, want_scene=False)
+        assert (r["best_idex"], r["best_view"]) == (want["best_idex"], want["best_view"])
+        np.testing.assert_allclose(r["angle_familiarity"], want["angle_familiarity"], rtol=RTOL)
+        assert r["step_familiarity"] == pytest.approx(want["step_familiarity"], rel=RTOL)
+    finally:
+        eng.close()
