@@ -712,3 +712,44 @@ def test_passes_of_64_headings_with_shared_accumulators_match_the_oracle(cw):
         assert r["step_familiarity"] == pytest.approx(want["step_familiarity"], rel=RTOL)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("h,w,n_agents,A,F,cw,levels", [
+    (8, 8, 4, 16, 41000, 0.25, None), (12, 20, 8, 8, 47001, 0.5, None), (32, 32, 2, 32, 41011, 0.1, None), (16, 16, 1, 64, 52000, 0.25, None),
+    (16, 16, 3, 20, 41000, 0.0, None), (64, 64, 4, 16, 41000, 0.25, None),
+    (16, 16, 4, 16, 41000, 0.25, (0, 50, 100, 150, 255)),               # value gaps 50, 50, 50, 105: the shared accumulator does not fit
+    (16, 16, 4, 16, 41000, 0.25, (0, 100, 150, 200, 250)),              # 100, 50, 50, 50: it does (position 0 has its own)
+    (16, 16, 4, 16, 41000, 0.25, (0, 85, 170, 255))])                   # three equal gaps
+def test_two_group_body_equals_one_group_body(h, w, n_agents, A, F, cw, levels):
+    """The records of passes of 64 headings are the same numbers whichever body scored them (DEJAVU_LC22=1 / 0): shapes, agents per
+    pass, a last pixel block that is not whole, value level sets the shared accumulators fit and do not fit (lc22_fits decides)."""
+    lib = synth.synth_views(5, F, h, w)
+    patches = synth.synth_patches(6, n_agents * A, h, w).reshape(n_agents, A, h, w, 3)
+    if levels is not None:                                           # re-map the five synthetic value levels
+        lut = np.zeros(256, np.uint8)
+        src = (0, 63, 127, 191, 255)
+        for k, v in enumerate(src):
+            lut[v] = levels[min(k, len(levels) - 1)]
+        lib[..., 2] = lut[lib[..., 2]]
+        patches[..., 2] = lut[patches[..., 2]]
+    patches[n_agents // 2, A // 2] = lib[F - 7]
+    recs = {}
+    for knob in ("1", "0"):
+        eng = _engine({"DEJAVU_LC22": knob})
+        try:
+            eng.set_library(lib, cw)
+            eng.step_batch(patches)
+            r = eng.step_batch(patches)
+            recs[knob] = [(x["best_idex"], x["best_view"], x["step_familiarity"], x["angle_familiarity"].tobytes(), x["angle_view"].tobytes()) for x in r]
+        finally:
+            eng.close()
+    assert recs["1"] == recs["0"]
+    assert recs["1"][n_agents // 2][:2] == (A // 2, F - 7)
+    want = oracle.step(lib[F - 300:], patches[0], cw, want_scene=False)      # and a slice of the oracle for good measure
+    got = _engine()
+    try:
+        got.set_library(lib[F - 300:], cw)
+        r0 = got.step(patches[0], want_scene=False)
+        assert r0["best_view"] == want["best_view"]
+    finally:
+        got.close()
