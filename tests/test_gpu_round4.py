@@ -753,3 +753,27 @@ def test_two_group_body_equals_one_group_body(h, w, n_agents, A, F, cw, levels):
         assert r0["best_view"] == want["best_view"]
     finally:
         got.close()
+
+
+@pytest.mark.parametrize("env", [{"DEJAVU_CHAIN_ORDER": "1"}, {"DEJAVU_CHAIN_ORDER": "2"}, {"DEJAVU_CHAINS": "3"}, {"DEJAVU_CHAINS": "1"},
+                                 {"DEJAVU_CHAINS": "3", "DEJAVU_LC22": "0"}])
+def test_ensemble_chain_knobs_leave_the_records_alone(env):
+    """However the passes of an ensemble step are laid out on their streams (DEJAVU_CHAIN_ORDER, DEJAVU_CHAINS), every agent's record is
+    the same -- uploaded and device-sensed patches, eight passes and a short ninth."""
+    F, h, w, A, n_agents = 41000, 16, 16, 16, 34
+    lib = synth.synth_views(9, F, h, w)
+    patches = synth.synth_patches(10, n_agents * A, h, w).reshape(n_agents, A, h, w, 3)
+    patches[33, 2] = lib[40999]
+    patches[17, 9] = synth.near_match_patch(lib[12345], 4, fraction=0.02)
+    recs = []
+    for e in ({}, env):
+        eng = _engine(e)
+        try:
+            eng.set_library(lib, 0.25)
+            eng.step_batch(patches)
+            r = eng.step_batch(patches)
+            recs.append([(x["best_idex"], x["best_view"], x["step_familiarity"], x["angle_familiarity"].tobytes()) for x in r])
+        finally:
+            eng.close()
+    assert recs[0] == recs[1]
+    assert recs[0][33][:2] == (2, 40999) and recs[0][17][:2] == (9, 12345)
