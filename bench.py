@@ -217,6 +217,12 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
     nsf.position = path[1] + np.array([1.0, -1.0])
     rates = {}
     outliers = {}
+    # The interpreter's cyclic collector stays ON during the timed loops; what is taken out of its reach is the object graph that
+    # exists before them (gc.freeze: this process imports torch, ~10^6 container objects that a full collection walks in ~45 ms --
+    # one such pause inside a 3000-step loop is 25 % of it and says nothing about the step)
+    import gc
+    gc.collect()
+    gc.freeze()
     for fake in (True, False):
         nsf.position = path[1] + np.array([1.0, -1.0])
         nsf.angle = float(np.arctan2(d[1], d[0]) % (2 * np.pi))
@@ -237,6 +243,7 @@ def agent_steps_per_s(h, w, A, cw, n_views, seed, n_steps):
                                   steps=[(i, int(x * 1e6)) for i, x in enumerate(durs) if x > 4 * float(np.median(durs))][:8])
         except navsim_amd.StopNavigationException:              # left the path before n_steps: rate over what ran
             rates[fake] = done / max(time.perf_counter() - t0, 1e-9) if done else None
+    gc.unfreeze()
     n_lib = len(path)
     # the same agent as the first of an ensemble of 32 stepping in lockstep (sensing and scoring batched, 64/A agents
     # per library pass; navsim_amd.NavEnsemble): agent-steps per second of the whole ensemble

@@ -211,6 +211,17 @@ int dv_agent_step(dv_ctx *ctx, double x, double y, double angle, const double *o
 int dv_agent_step_begin(dv_ctx *ctx, double x, double y, double angle, const double *offsets, int n_headings,
                         int do_error, double ex, double ey, double reach, double *nearest, int32_t *have_nearest);
 int dv_agent_step_end(dv_ctx *ctx, double *angle_fam, int32_t *best_heading);
+/*
+ * _end and the next _begin in one call.  The caller has worked out, while the device was busy, where every candidate heading would
+ * take the agent (cand_angle[a] = (angle + offsets[a]) mod 2 pi, cand_x / cand_y[a] = position + step_size (cos, sin), :317-321); the
+ * call waits for the record and begins the next step at candidate *best_heading without returning in between -- unless that
+ * position fails the reference's bounds test (:153-158; bounds = {r, cols - r, rows - r}), where the next step would stop before it
+ * senses: *begun = 0.  do_error != 0 asks for the error metrics of the new position with the step begun (reach as in
+ * dv_agent_step); nearest / have_nearest as in dv_agent_step_begin.
+ */
+int dv_agent_step_end_begin(dv_ctx *ctx, double *angle_fam, int32_t *best_heading, const double *cand_x, const double *cand_y,
+                            const double *cand_angle, const double *offsets, int n_headings, const double *bounds, int do_error,
+                            double reach, int32_t *begun, double *nearest, int32_t *have_nearest);
 /* train_from_path (:118-140) on the device: sense n poses and ingest them as the library; out_views
  * (uint8[n, sensor_h, sensor_w, 3], may be NULL) receives familiar_scenes. */
 int dv_set_library_from_poses(dv_ctx *ctx, const double *x, const double *y, const double *angle, int64_t n,

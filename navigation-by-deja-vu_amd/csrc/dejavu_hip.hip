@@ -1711,6 +1711,31 @@ extern "C" int dv_agent_step_end(dv_ctx* c, double* angle_fam, int32_t* best_hea
     return DV_OK;
 }
 
+// The end of one agent step and the beginning of the next in ONE call: the record is waited for, and the step for the pose the chosen
+// heading leads to -- cand_x / cand_y / cand_angle[best], worked out by the caller for every heading while the device was busy -- is
+// begun at once, without a trip through the caller in between (include/dejavu.h).
+extern "C" int dv_agent_step_end_begin(dv_ctx* c, double* angle_fam, int32_t* best_heading, const double* cand_x, const double* cand_y,
+                                       const double* cand_angle, const double* offsets, int A, const double* bounds, int do_error, double reach,
+                                       int32_t* begun, double* nearest, int32_t* have_nearest) {
+    if (!c) return DV_ERR_INVALID;
+    if (!cand_x || !cand_y || !cand_angle || !bounds || !begun || !nearest || !have_nearest)
+        return fail(c, DV_ERR_INVALID, "dv_agent_step_end_begin: NULL argument");
+    *begun = 0;
+    *have_nearest = 0;
+    if (c->agent_pending && c->agent_pending != A) return fail(c, DV_ERR_INVALID, "dv_agent_step_end_begin: %d headings begun, %d asked for", c->agent_pending, A);
+    int rc = dv_agent_step_end(c, angle_fam, best_heading);
+    if (rc) return rc;
+    const int b = *best_heading;
+    if (b < 0 || b >= A) return fail(c, DV_ERR_STATE, "dv_agent_step_end_begin: heading %d of %d", b, A);
+    const double x = cand_x[b], y = cand_y[b];
+    // the reference's bounds test (NavBySceneFamiliarity.py:153-158): out of bounds, the next step stops before it senses -- nothing is begun
+    if ((x <= bounds[0]) || (y <= bounds[0]) || (x >= bounds[1]) || (y >= bounds[2])) return DV_OK;
+    rc = dv_agent_step_begin(c, x, y, cand_angle[b], offsets, A, do_error, x, y, reach, nearest, have_nearest);
+    if (rc) return rc;
+    *begun = 1;
+    return DV_OK;
+}
+
 extern "C" int dv_agent_step(dv_ctx* c, double x, double y, double angle, const double* offsets, int A, int do_error, double ex,
                              double ey, double reach, double* angle_fam, int32_t* best_heading, double* nearest, int32_t* have_nearest) {
     if (c && (!angle_fam || !best_heading)) return fail(c, DV_ERR_INVALID, "dv_agent_step: NULL argument");

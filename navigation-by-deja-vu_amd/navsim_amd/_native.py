@@ -139,6 +139,8 @@ PROTOTYPES = {
     "dv_agent_step_begin": (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, _f64p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, _f64p, ctypes.POINTER(ctypes.c_int32)]),
     "dv_agent_step_end": (ctypes.c_int, [_ctx_p, _f64p, ctypes.POINTER(ctypes.c_int32)]),
+    "dv_agent_step_end_begin": (ctypes.c_int, [_ctx_p, _f64p, ctypes.POINTER(ctypes.c_int32), _f64p, _f64p, _f64p, _f64p, ctypes.c_int, _f64p,
+                                               ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int32), _f64p, ctypes.POINTER(ctypes.c_int32)]),
     "dv_set_library_from_poses": (ctypes.c_int, [_ctx_p, _f64p, _f64p, _f64p, ctypes.c_int64, ctypes.c_double,
                                                  ctypes.c_int64, _u8p]),
     "dv_set_training_path": (ctypes.c_int, [_ctx_p, _f64p, ctypes.c_int64]),

@@ -161,6 +161,7 @@ class NavBySceneFamiliarity(object):
         assert np.all(extent % 2 == 0)
         self._sensor_r = np.max(extent / 2)
         self._bounds = None
+        self._bounds_arr = None
         self._roundbuf = np.empty((self.sensor_dimensions[1], self.sensor_dimensions[0]), dtype=np.float32)
         self._end_buf = np.empty(2, dtype=np.float64)
         self._spec = None                      # the pose and offsets the engine was asked to begin the next step for (_move)
@@ -213,6 +214,7 @@ class NavBySceneFamiliarity(object):
             r = self._sensor_r
             ldims = self.landscape.shape
             b = self._bounds = (float(r), float(ldims[1] - r), float(ldims[0] - r))
+            self._bounds_arr = np.array(b, dtype=np.float64)
         if (position[0] <= b[0]) or (position[1] <= b[0]) or (position[0] >= b[1]) or (position[1] >= b[2]):
             raise OutOfLandscapeBoundsException()
 
@@ -453,6 +455,8 @@ class NavBySceneFamiliarity(object):
         engine = getattr(func, "engine", None)
         defer_error = False
         begin_next = False
+        cand = None
+        begun_next = None                      # (the next step was begun by the call that ended this one, an error answer it collected)
         if engine is not None and str(getattr(func, "metric", "")).startswith("ssd"):
             self._step_ssd(func, engine, position)
             best_idex = self.last_scored_idex
@@ -470,9 +474,26 @@ class NavBySceneFamiliarity(object):
                         # that its book-keeping, the caller's loop and this call's preamble ran beside the device's work.  It counts
                         # only if it was begun for exactly this pose and these offsets and nothing else was asked of the engine since.
                         best_idex = None
+                        cand = None
                         spec, self._spec = self._spec, None
                         if spec is not None and spec == (position[0], position[1], self.angle, self.angle_offsets.tobytes()):
-                            best_idex = engine.agent_step_end()
+                            # while the device works: where each candidate heading would take the agent (:317-321 for every heading
+                            # at once -- NumPy's elementwise loops give an element what they give the scalar), so that the pose of
+                            # the heading chosen is three look-ups away when the record arrives
+                            cand_angle = (self.angle + self.angle_offsets) % (2 * np.pi)
+                            cand = (cand_angle, position[0] + self.step_size * np.cos(cand_angle),
+                                    position[1] + self.step_size * np.sin(cand_angle))
+                            lean_error = self._metrics_on_device and not math.isfinite(self.max_distance_to_training_path)
+                            if self.pipeline_steps and (fake or lean_error) and self._error_pos is None:
+                                # ... and the next step begun by the same call that hands this one's record out
+                                # (dv_agent_step_end_begin): nothing of this interpreter between the record and the launch
+                                got = engine.agent_step_end_begin(cand, self._bounds_arr, not fake, self.coverage_threshold_factor * self.step_size)
+                                if got is not None:
+                                    best_idex, begun_next = got[0], (got[1], got[2])
+                            else:
+                                best_idex = engine.agent_step_end()
+                            if best_idex is None:
+                                cand = None
                         if best_idex is None:
                             epos = self._error_pos
                             best_idex, nearest = engine.agent_step(position[0], position[1], self.angle, self.angle_offsets,
@@ -528,7 +549,7 @@ class NavBySceneFamiliarity(object):
                 self.angle_familiarity[a_idex] = np.max(temp_fam)
             best_idex = np.argmax(self.angle_familiarity)
 
-        self._move(best_idex, fake, defer_error, begin_next)
+        self._move(best_idex, fake, defer_error, begin_next, cand, begun_next)
 
     def _step_ssd(self, func, engine, position):
         """The heading loop (:289-315) with the SSD plug-in (util.ssd_familiarity): ONE device step -- sense, score on the matrix
@@ -559,18 +580,34 @@ class NavBySceneFamiliarity(object):
             self._scene_is_inf = True
         self.last_scored_idex = res["best_idex"]
 
-    def _move(self, best_idex, fake=False, defer_error=False, begin_next=False):
-        """The part of a step after the heading is chosen (:316-329): turn, advance, book-keeping, stop conditions."""
+    def _move(self, best_idex, fake=False, defer_error=False, begin_next=False, cand=None, begun_next=None):
+        """The part of a step after the heading is chosen (:316-329): turn, advance, book-keeping, stop conditions.
+        `cand`: (angles, xs, ys) of every candidate heading, worked out beforehand with the same operations."""
         position = self.position
         self.step_familiarity = self.angle_familiarity[best_idex]
-        angle = (self.angle + self.angle_offsets[best_idex]) % (2 * np.pi)
-        self.position = (position[0] + self.step_size * np.cos(angle),
-                         position[1] + self.step_size * np.sin(angle))
+        if cand is not None:
+            angle = cand[0][best_idex]
+            self.position = (cand[1][best_idex], cand[2][best_idex])
+        else:
+            angle = (self.angle + self.angle_offsets[best_idex]) % (2 * np.pi)
+            self.position = (position[0] + self.step_size * np.cos(angle),
+                             position[1] + self.step_size * np.sin(angle))
         self.angle = angle
         self.last_best_idex = int(best_idex)
 
         begun = False
-        if begin_next and (fake or defer_error):
+        if begun_next is not None and begun_next[0]:
+            # the device already has the next step (dv_agent_step_end_begin took the pose from the same candidates): the book-keeping
+            # of agent_step_begin below, nothing else
+            if not fake:
+                self.navigated_for_frames += 1
+                self._pending_errors += 1
+            if begun_next[1] is not None:
+                self._pending_errors -= 1
+                self._take_error(begun_next[1])
+            self._spec = (self.position[0], self.position[1], angle, self.angle_offsets.tobytes())
+            begun = True
+        elif begin_next and (fake or defer_error):
             # the lean step on the agent's own engine: the NEXT step's device work starts now, for the pose just computed (the
             # heading update is all that serialises two steps, :317-323) -- unless that pose is out of bounds, where the next call
             # stops before it senses (:153-158).  The position's error metrics (update_error, :324) ride in the same launch.

@@ -295,6 +295,22 @@ class FamiliarityEngine(object):
             self._check_sense(rc, "dv_agent_step_end")
         return st[6].value
 
+    def agent_step_end_begin(self, cand, bounds, do_error, reach):
+        """agent_step_end and the next agent_step_begin in one call (dv_agent_step_end_begin): cand = (angles[A], xs[A], ys[A]) of every
+        candidate heading (float64, C-contiguous), bounds = float64[3] of the reference's bounds test.  Returns None when the begun step
+        was superseded, else (best heading, whether the next step was begun, an outstanding error answer or None)."""
+        if not self._begun:
+            return None
+        self._begun = False
+        st = self._agent_state
+        begun = ctypes.c_int32(0)
+        rc = self._lib.dv_agent_step_end_begin(self._ctx_raw, st[5], st[7], N.f64ptr(cand[1]), N.f64ptr(cand[2]), N.f64ptr(cand[0]), st[3], st[4],
+                                               N.f64ptr(bounds), 1 if do_error else 0, reach, ctypes.byref(begun), st[9], st[11])
+        if rc:
+            self._check_sense(rc, "dv_agent_step_end_begin")
+        self._begun = bool(begun.value)
+        return st[6].value, self._begun, (st[8].value if st[10].value else None)
+
     def sense_step_batch(self, x, y, angles, force_resolve=False):
         """Ensemble step on the device: agent i at (x[i], y[i]) looking along angles[i][0..A) -> BatchResults (a sequence of result dicts)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)

@@ -644,6 +644,20 @@ def test_begun_agent_step_is_superseded_by_any_other_call():
         e2.agent_step_begin(100.0, 130.0, 0.3, offs, fam, None, 0.0)
         e2.library_info()
         assert e2.agent_step_end() is None                               # superseded: the caller steps again
+        # end and the next begin in one call: nothing is begun for a pose the bounds test refuses; otherwise the step begun is the
+        # one for the candidate of the heading chosen
+        cand_angle = (0.3 + offs) % (2 * np.pi)
+        bounds = np.array([4.0, 296.0, 296.0])
+        e2.agent_step_begin(100.0, 130.0, 0.3, offs, fam, None, 0.0)
+        got = e2.agent_step_end_begin((cand_angle, np.full(6, 1e6), np.full(6, 130.0)), bounds, False, 0.0)
+        assert got == (want, False, None) and e2.agent_step_end() is None
+        e2.agent_step_begin(100.0, 130.0, 0.3, offs, fam, None, 0.0)
+        got = e2.agent_step_end_begin((cand_angle, np.full(6, 120.0), np.full(6, 131.0)), bounds, False, 0.0)
+        assert got == (want, True, None)
+        nxt = e2.agent_step_end()
+        chk, _ = e2.agent_step(120.0, 131.0, cand_angle[want], offs, np.empty(6), None, 0.0)
+        assert nxt == chk
+        assert e2.agent_step_end_begin((cand_angle, np.full(6, 120.0), np.full(6, 131.0)), bounds, False, 0.0) is None      # nothing begun
         # the C ABI itself refuses an end with another step in between, and one without a begin
         lib = e2._lib
         best32 = ctypes.c_int32()
@@ -777,3 +791,32 @@ def test_ensemble_chain_knobs_leave_the_records_alone(env):
             eng.close()
     assert recs[0] == recs[1]
     assert recs[0][33][:2] == (2, 40999) and recs[0][17][:2] == (9, 12345)
+
+
+def test_pipelined_agent_walks_out_of_the_landscape_like_the_plain_one():
+    """The call that ends a step begins the next one only where the reference's bounds test lets it sense (dv_agent_step_end_begin): an
+    agent heading for the edge stops at the same step, in the same state, as with one call per step -- fake and real steps."""
+    land = synth.synth_landscape(3, 260, 4)
+    path = np.stack([np.linspace(60, 200, 120), np.full(120, 130.0)], axis=1)
+    logs = {}
+    for pipe in (True, False):
+        for fake in (True, False):
+            nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 2.0, n_test_angles=8, n_sensor_levels=5, saccade_degrees=30.,
+                                                   familiarity_model=navsim_amd.sads_familiarity(0.25), track_scene_familiarity=False)
+            nsf.pipeline_steps = pipe
+            nsf.train_from_path(path)
+            nsf.position, nsf.angle = (150.0, 131.0), 0.02
+            log = []
+            try:
+                for t in range(200):
+                    nsf.step_forward(fake=fake)
+                    log.append((nsf.last_best_idex, nsf.position, nsf.angle, nsf.navigated_for_frames))
+            except (navsim_amd.StopNavigationException, IndexError) as e:      # (the rotated sensor's corners reach past the bounds test: the
+                log.append(("stop", type(e).__name__, nsf.position, nsf.navigated_for_frames))      #  reference's trial may end in an IndexError first)
+            if not fake:
+                log.append(("rmsd", float(nsf.navigation_error), nsf.percent_recapitulated_forgiving()))
+            logs[pipe, fake] = log
+            nsf.clear_training()
+    for fake in (True, False):
+        assert logs[True, fake] == logs[False, fake], fake
+    assert logs[True, True][-1][0] == "stop" and logs[True, True][-1][1] in ("OutOfLandscapeBoundsException", "IndexError")
