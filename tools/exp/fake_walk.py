@@ -38,6 +38,10 @@ for fake in (True, False):
     a = walk(True, n=N, fake=fake)
     print("fake", fake, "collections during the piped walk (gen, us) over 200 us:", [(g, int(us)) for _, g, us in gc_log if us and us > 200][:10], "of", len(gc_log))
     b = walk(False, n=N, fake=fake)
+    idx = np.array([x[0] for x in a])
+    same = float(np.mean(idx[1:] == idx[:-1]))
+    vals, counts = np.unique(idx, return_counts=True)
+    print("best heading repeats the last one in %.1f %% of the steps; histogram:" % (100 * same), dict(zip(vals.tolist(), counts.tolist())))
     diff = [i for i, (x, y) in enumerate(zip(a, b)) if x[:4] != y[:4]]
     print("fake", fake, "first difference:", diff[:3], " slow steps piped:", [(i, int(x[4])) for i, x in enumerate(a) if x[4] > 500][:6],
           " plain:", [(i, int(x[4])) for i, x in enumerate(b) if x[4] > 500][:6])
