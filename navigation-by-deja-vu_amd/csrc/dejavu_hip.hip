@@ -1644,8 +1644,10 @@ constexpr int kErrRing = 8;             // answers of the error metrics that may
 static PathErrArgs path_err_args(dv_ctx* c, double x, double y, double reach) {
     PathErrArgs pe{};
     const unsigned long long seq = ++c->err_enq;
-    long long nb = (c->n_path + 255) / 256;
-    if (nb > 512) nb = 512;
+    // blocks of 256 threads, 1024 points each: every block ends in two agent-scope atomics on ONE address (minimum, ticket), which the
+    // memory side takes one after the other -- 196 blocks for a 50 000-point path were the longest thing in the preparation launch
+    long long nb = (c->n_path + 1023) / 1024;
+    if (nb > 256) nb = 256;
     pe.xy = c->d_path; pe.n = (long long)c->n_path; pe.x = x; pe.y = y; pe.reach = reach; pe.cover = c->d_cover; pe.st = c->d_errstate;
     pe.out = c->d_errout + (seq % kErrRing); pe.seq = seq; pe.nblk = (int)nb;
     return pe;
