@@ -247,6 +247,17 @@ int dv_path_error_enqueue(dv_ctx *ctx, double x, double y, double reach);
 int dv_path_error_wait(dv_ctx *ctx, double *nearest);
 int dv_path_coverage(dv_ctx *ctx, uint8_t *out, int64_t n);
 int dv_path_reset(dv_ctx *ctx);
+/*
+ * The same metrics for the agents of an ensemble (navsim_amd.NavEnsemble; the reference farms its trials over MPI ranks, each with
+ * its own update_error): dv_path_slots gives every agent a coverage array of its own on the device (n_slots x n_path bytes, cleared;
+ * 0 frees them), dv_path_error_batch is update_error for n agents at once -- nearest[i] = agent i's distance to the nearest training
+ * point in the reference's double arithmetic, its slot's marks updated -- synchronous (one kernel of n x ceil(n_path / 1024) blocks
+ * per 64 agents).  dv_path_coverage_slot / dv_path_reset_slot (slot < 0: all) read / clear one agent's marks.
+ */
+int dv_path_slots(dv_ctx *ctx, int n_slots);
+int dv_path_error_batch(dv_ctx *ctx, const int32_t *slots, const double *x, const double *y, int n, double reach, double *nearest);
+int dv_path_coverage_slot(dv_ctx *ctx, int slot, uint8_t *out, int64_t n);
+int dv_path_reset_slot(dv_ctx *ctx, int slot);
 
 /* ---- scoring ----------------------------------------------------------- */
 /* func(scene, fambuf) of util.pyx:14-20: fambuf[f] for one patch uint8[h,w,3] against every local view. */

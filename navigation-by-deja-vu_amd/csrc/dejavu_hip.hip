@@ -251,6 +251,10 @@ struct dv_ctx {
     double* d_path = nullptr;                 // [n][2]
     int64_t n_path = 0;
     unsigned char* d_cover = nullptr;         // [n] coverage marks
+    unsigned char* d_cover_slots = nullptr;   // [n_cover_slots][n] coverage marks of an ensemble's agents (dv_path_slots)
+    int n_cover_slots = 0;
+    unsigned long long* d_minkeys = nullptr;  // [kPathBatch] dv_path_error_batch's minima
+    unsigned long long* h_minkeys = nullptr;  // pinned
     PathErrState* d_errstate = nullptr;
     PathErrOut* h_errout = nullptr;           // mapped ring of kErrRing answers
     PathErrOut* d_errout = nullptr;
@@ -380,6 +384,9 @@ extern "C" void dv_destroy(dv_ctx* c) {
     if (c->d_sense_err) (void)hipFree(c->d_sense_err);
     if (c->d_path) (void)hipFree(c->d_path);
     if (c->d_cover) (void)hipFree(c->d_cover);
+    if (c->d_cover_slots) (void)hipFree(c->d_cover_slots);
+    if (c->d_minkeys) (void)hipFree(c->d_minkeys);
+    if (c->h_minkeys) (void)hipHostFree(c->h_minkeys);
     if (c->d_errstate) (void)hipFree(c->d_errstate);
     if (c->h_errout) (void)hipHostFree(c->h_errout);
     if (c->h_pub) (void)hipHostFree(c->h_pub);
@@ -2993,6 +3000,8 @@ extern "C" int dv_set_training_path(dv_ctx* c, const double* xy, int64_t n) {
     HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     if (c->d_path) { (void)hipFree(c->d_path); c->d_path = nullptr; }
     if (c->d_cover) { (void)hipFree(c->d_cover); c->d_cover = nullptr; }
+    if (c->d_cover_slots) { (void)hipFree(c->d_cover_slots); c->d_cover_slots = nullptr; }
+    c->n_cover_slots = 0;
     c->n_path = 0;
     c->err_enq = c->err_deq = 0;
     if (!xy || n < 1) return DV_OK;                              // detach
@@ -3071,6 +3080,70 @@ extern "C" int dv_path_reset(dv_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     c->err_deq = c->err_enq;                                     // answers of the run being abandoned are dropped
     HIP_TRY(c, hipMemsetAsync(c->d_cover, 0, (size_t)c->n_path, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DV_OK;
+}
+
+// update_error for the agents of an ensemble (include/dejavu.h): every agent has its own coverage marks on the device (a slot).
+extern "C" int dv_path_slots(dv_ctx* c, int n_slots) {
+    if (!c || n_slots < 0) return DV_ERR_INVALID;
+    if (c->n_path < 1) return fail(c, DV_ERR_STATE, "no training path set (dv_set_training_path)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_cover_slots) { (void)hipFree(c->d_cover_slots); c->d_cover_slots = nullptr; }
+    c->n_cover_slots = 0;
+    if (n_slots == 0) return DV_OK;
+    HIP_TRY(c, hipMalloc(&c->d_cover_slots, (size_t)n_slots * (size_t)c->n_path));
+    HIP_TRY(c, hipMemsetAsync(c->d_cover_slots, 0, (size_t)n_slots * (size_t)c->n_path, c->stream));
+    if (!c->d_minkeys) {
+        HIP_TRY(c, hipMalloc(&c->d_minkeys, kPathBatch * sizeof(unsigned long long)));
+        HIP_TRY(c, hipHostMalloc(&c->h_minkeys, kPathBatch * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_cover_slots = n_slots;
+    return DV_OK;
+}
+
+extern "C" int dv_path_error_batch(dv_ctx* c, const int32_t* slots, const double* x, const double* y, int n, double reach, double* nearest) {
+    if (!c || !slots || !x || !y || !nearest || n < 0) return DV_ERR_INVALID;
+    if (c->n_path < 1 || c->n_cover_slots < 1) return fail(c, DV_ERR_STATE, "no coverage slots (dv_set_training_path, dv_path_slots)");
+    for (int i = 0; i < n; ++i)
+        if (slots[i] < 0 || slots[i] >= c->n_cover_slots) return fail(c, DV_ERR_INVALID, "dv_path_error_batch: slot %d of %d", slots[i], c->n_cover_slots);
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long nb = (c->n_path + 1023) / 1024;                         // 1024 points per block of 256 threads (path_err_args)
+    if (nb > 256) nb = 256;
+    for (int first = 0; first < n; first += kPathBatch) {
+        const int cnt = n - first < kPathBatch ? n - first : kPathBatch;
+        PathBatchArgs pa{};
+        pa.xy = c->d_path; pa.n = (long long)c->n_path; pa.reach = reach; pa.cover = c->d_cover_slots; pa.cover_stride = (long long)c->n_path;
+        pa.minkey = c->d_minkeys;
+        for (int i = 0; i < cnt; ++i) { pa.x[i] = x[first + i]; pa.y[i] = y[first + i]; pa.slot[i] = slots[first + i]; }
+        HIP_TRY(c, hipMemsetAsync(c->d_minkeys, 0xff, kPathBatch * sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_path_error_batch, dim3((unsigned)nb, (unsigned)cnt), dim3(256), 0, c->stream, pa);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(c->h_minkeys, c->d_minkeys, (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < cnt; ++i) memcpy(&nearest[first + i], &c->h_minkeys[i], sizeof(double));
+    }
+    return DV_OK;
+}
+
+extern "C" int dv_path_coverage_slot(dv_ctx* c, int slot, uint8_t* out, int64_t n) {
+    if (!c || !out) return DV_ERR_INVALID;
+    if (c->n_path < 1 || n != c->n_path || slot < 0 || slot >= c->n_cover_slots) return fail(c, DV_ERR_STATE, "no coverage slot %d of %lld points", slot, (long long)n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_cover_slots + (size_t)slot * (size_t)c->n_path, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DV_OK;
+}
+
+extern "C" int dv_path_reset_slot(dv_ctx* c, int slot) {
+    if (!c) return DV_ERR_INVALID;
+    if (c->n_cover_slots < 1) return DV_OK;
+    if (slot >= c->n_cover_slots) return fail(c, DV_ERR_INVALID, "dv_path_reset_slot: slot %d of %d", slot, c->n_cover_slots);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (slot < 0) HIP_TRY(c, hipMemsetAsync(c->d_cover_slots, 0, (size_t)c->n_cover_slots * (size_t)c->n_path, c->stream));
+    else HIP_TRY(c, hipMemsetAsync(c->d_cover_slots + (size_t)slot * (size_t)c->n_path, 0, (size_t)c->n_path, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DV_OK;
 }

@@ -2620,6 +2620,45 @@ __device__ __forceinline__ void path_error_block(const PathErrArgs& pe, int blk)
 __global__ void __launch_bounds__(256)
 k_path_error(PathErrArgs pe) { path_error_block(pe, (int)blockIdx.x); }
 
+// update_error for the agents of an ensemble at once: block (b, j) walks its share of the training points for agent j -- the same
+// arithmetic as path_error_block -- marks agent j's OWN coverage array (slot) and folds the minimum into minkey[j] with one atomic
+// per block; the host reads the minima behind the kernel (dv_path_error_batch is synchronous: an ensemble step is ~1 ms).
+constexpr int kPathBatch = 64;
+struct PathBatchArgs {
+    const double* xy; long long n; double reach; unsigned char* cover; long long cover_stride; unsigned long long* minkey;
+    double x[kPathBatch], y[kPathBatch]; int slot[kPathBatch];
+};
+__global__ void __launch_bounds__(256)
+k_path_error_batch(PathBatchArgs pa) {
+    __shared__ unsigned long long wmin[4];
+    const int j = blockIdx.y;
+    const double x = pa.x[j], y = pa.y[j], reach = pa.reach;
+    const double* __restrict__ xy = pa.xy;
+    unsigned char* __restrict__ cover = pa.cover + (long long)pa.slot[j] * pa.cover_stride;
+    unsigned long long key = ~0ull;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pa.n; i += (long long)gridDim.x * blockDim.x) {
+        double dx = xy[2 * i] - x, dy = xy[2 * i + 1] - y;
+        dx *= dx;
+        dy *= dy;
+        const double dist = sqrt(dx + dy);
+        if (dist <= reach) cover[i] = 1;
+        const unsigned long long k = (unsigned long long)__double_as_longlong(dist);     // dist >= 0: bit order = value order
+        key = k < key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wmin[0];
+        for (int i = 1; i < 4; ++i) m = wmin[i] < m ? wmin[i] : m;
+        atomicMin(&pa.minkey[j], m);
+    }
+}
+
 struct PoseSet { Pose p[kMaxHeadings]; };
 
 template <int MODE>

@@ -148,6 +148,10 @@ PROTOTYPES = {
     "dv_path_error_wait": (ctypes.c_int, [_ctx_p, _f64p]),
     "dv_path_coverage": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int64]),
     "dv_path_reset": (ctypes.c_int, [_ctx_p]),
+    "dv_path_slots": (ctypes.c_int, [_ctx_p, ctypes.c_int]),
+    "dv_path_error_batch": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int32), _f64p, _f64p, ctypes.c_int, ctypes.c_double, _f64p]),
+    "dv_path_coverage_slot": (ctypes.c_int, [_ctx_p, ctypes.c_int, _u8p, ctypes.c_int64]),
+    "dv_path_reset_slot": (ctypes.c_int, [_ctx_p, ctypes.c_int]),
     "dv_score": (ctypes.c_int, [_ctx_p, _u8p, _f64p]),
     "dv_step": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(StepResult), _f64p]),
     "dv_step_batch": (ctypes.c_int, [_ctx_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,

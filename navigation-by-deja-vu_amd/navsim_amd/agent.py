@@ -165,6 +165,8 @@ class NavBySceneFamiliarity(object):
         self._roundbuf = np.empty((self.sensor_dimensions[1], self.sensor_dimensions[0]), dtype=np.float32)
         self._end_buf = np.empty(2, dtype=np.float64)
         self._spec = None                      # the pose and offsets the engine was asked to begin the next step for (_move)
+        self._metric_slot = None               # member of an ensemble: its coverage marks' slot on the device (NavEnsemble)
+        self._ens = None
         self.pipeline_steps = os.environ.get("DEJAVU_AGENT_PIPELINE", "1") != "0"
         self._landscape_glimpse_buf = np.empty((extent[1], extent[0], 3), dtype=np.uint8)
         self.n_sensor_pixels = np.prod(self.sensor_dimensions)
@@ -356,7 +358,10 @@ class NavBySceneFamiliarity(object):
         self._host_coverage = None
         if self.training_path is not None:
             self._host_coverage = np.zeros(len(self.training_path), dtype=bool)
-            if getattr(self, "_metrics_on_device", False):
+            if getattr(self, "_metric_slot", None) is not None:
+                self._ens._drop_errors(self)
+                self._engine.path_reset_slot(self._metric_slot)
+            elif getattr(self, "_metrics_on_device", False):
                 self._engine.path_reset()
 
     # The metrics of update_error (:252-276) run on the device when the agent owns its engine: a step asks for them
@@ -384,6 +389,9 @@ class NavBySceneFamiliarity(object):
 
     @property
     def _coverage_array(self):
+        if getattr(self, "_metric_slot", None) is not None and self.training_path is not None:
+            self._ens._flush_errors()
+            return self._engine.path_coverage_slot(self._metric_slot, len(self.training_path))
         if getattr(self, "_metrics_on_device", False) and self.training_path is not None:
             self._collect_errors()
             return self._engine.path_coverage(len(self.training_path))
@@ -391,7 +399,9 @@ class NavBySceneFamiliarity(object):
 
     @property
     def navigation_error(self):
-        if getattr(self, "_metrics_on_device", False):
+        if getattr(self, "_metric_slot", None) is not None:
+            self._ens._flush_errors()
+        elif getattr(self, "_metrics_on_device", False):
             self._collect_errors()
         return np.sqrt(self._navigation_error / self._n_navigation_error)
 
@@ -425,6 +435,13 @@ class NavBySceneFamiliarity(object):
 
     def update_error(self):
         self.navigated_for_frames += 1
+        if getattr(self, "_metric_slot", None) is not None:
+            # a member of an ensemble: its position goes on the ensemble's list, and the metrics of all members are taken in one
+            # device call at the end of the ensemble's step (NavEnsemble._flush_errors) -- at once when the agent steps on its own
+            self._ens._want_error(self)
+            if not self._ens._stepping:
+                self._ens._flush_errors(raise_for=self)
+            return
         if getattr(self, "_metrics_on_device", False):
             self._collect_errors()                               # the previous step's answer: ready by now (and a deferred position first)
             self._engine.path_error_enqueue(self.position[0], self.position[1],
@@ -660,6 +677,7 @@ class NavBySceneFamiliarity(object):
         other.scene_familiarity = None if self.track_scene_familiarity is False else np.zeros_like(self.scene_familiarity)
         other.position, other.angle = None, None
         other._spec = None
+        other._metric_slot = None
         other.step_familiarity = None
         other.reset_error()
         return other

@@ -660,6 +660,28 @@ class FamiliarityEngine(object):
     def path_reset(self):
         self._check(self._lib.dv_path_reset(self._ctx), "dv_path_reset")
 
+    # update_error for the agents of an ensemble: a coverage array per agent (slot) on the device
+    def path_slots(self, n_slots):
+        self._check(self._lib.dv_path_slots(self._ctx, int(n_slots)), "dv_path_slots")
+
+    def path_error_batch(self, slots, xs, ys, reach):
+        """nearest[i] of agent slots[i] at (xs[i], ys[i]) (NavBySceneFamiliarity.py:252-276 for all of them at once); its marks updated."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        out = np.empty(len(slots), dtype=np.float64)
+        self._check(self._lib.dv_path_error_batch(self._ctx, slots.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), N.f64ptr(xs), N.f64ptr(ys),
+                                                  len(slots), float(reach), N.f64ptr(out)), "dv_path_error_batch")
+        return out
+
+    def path_coverage_slot(self, slot, n):
+        out = np.empty(int(n), dtype=np.uint8)
+        self._check(self._lib.dv_path_coverage_slot(self._ctx, int(slot), N.u8ptr(out), int(n)), "dv_path_coverage_slot")
+        return out.astype(bool)
+
+    def path_reset_slot(self, slot=-1):
+        self._check(self._lib.dv_path_reset_slot(self._ctx, int(slot)), "dv_path_reset_slot")
+
     def stream_read_gbps(self, n_bytes=1 << 30, iters=10):
         g = ctypes.c_double(0)
         self._check(self._lib.dv_stream_read_gbps(self._ctx, int(n_bytes), int(iters), ctypes.byref(g)),

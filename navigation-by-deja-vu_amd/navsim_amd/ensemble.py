@@ -23,6 +23,46 @@ class NavEnsemble(object):
         self.agents = list(agents)
         self.engine = eng
         self.stop_status = [0] * len(agents)                      # the reference's codes: 0 running / 1 / -1 / -2
+        # update_error (:252-276) of all members in ONE device call per ensemble step: every member gets a coverage array of its own on
+        # the device (dv_path_slots) and hands its position in; 32 members x a NumPy pass over 50 000 training points each were
+        # ~10 ms of host time beside a 0.85 ms device step
+        self._stepping = False
+        self._pending = []                                        # members whose position awaits its metrics
+        self._too_far = {}
+        if agents[0].training_path is not None and hasattr(eng, "path_slots") and all(a.training_path is agents[0].training_path for a in agents):
+            for a in self.agents:
+                if getattr(a, "_metrics_on_device", False):
+                    a._collect_errors()                           # (answers still outstanding from steps it took on its own)
+            if not any(getattr(a, "_metrics_on_device", False) for a in self.agents):
+                eng.set_training_path(agents[0].training_path)    # (the engine holds the path already where an agent's metrics ran on it)
+            eng.path_slots(len(agents))
+            for j, a in enumerate(self.agents):
+                a._metric_slot, a._ens = j, self
+                a._metrics_on_device = False
+
+    def _want_error(self, agent):
+        self._pending.append((agent, agent.position[0], agent.position[1]))
+
+    def _drop_errors(self, agent):
+        self._pending = [p for p in self._pending if p[0] is not agent]
+
+    def _flush_errors(self, raise_for=None):
+        """The metrics of every position handed in since the last flush; a member too far from the path is remembered (_too_far) for
+        the ensemble's step to stop it as the reference's update_error would have (:264) -- or raised at once for `raise_for`, a
+        member stepping on its own."""
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, []
+        a0 = pend[0][0]
+        nearest = self.engine.path_error_batch([a._metric_slot for a, _, _ in pend], [x for _, x, _ in pend], [y for _, _, y in pend],
+                                               a0.coverage_threshold_factor * a0.step_size)
+        for (a, _, _), d in zip(pend, nearest.tolist()):
+            try:
+                a._take_error(d)
+            except StopNavigationException as e:
+                if a is raise_for:
+                    raise
+                self._too_far[id(a)] = e
 
     @classmethod
     def from_agent(cls, agent, poses):
@@ -47,6 +87,13 @@ class NavEnsemble(object):
 
     def step_forward(self, fake=False):
         """One step of every running agent; returns the indices that are still running afterwards."""
+        self._stepping = True
+        try:
+            return self._step_forward(fake)
+        finally:
+            self._stepping = False
+
+    def _step_forward(self, fake):
         idx, xs, ys, angs = [], [], [], []
         for i in self.active:
             try:
@@ -56,6 +103,7 @@ class NavEnsemble(object):
                 continue
             idx.append(i); xs.append(x); ys.append(y); angs.append(a)
         if idx:
+            stops = {}
             results = self.engine.sense_step_batch(xs, ys, np.stack(angs))
             # the records as arrays when the engine offers them (engine.BatchResults): no dictionary per agent and step
             lean = hasattr(results, "angle_familiarity")
@@ -73,6 +121,13 @@ class NavEnsemble(object):
                     else:
                         self.agents[i].apply_step_result(results[k], fake)
                 except StopNavigationException as e:
+                    stops[i] = e
+            # the members' error metrics, all in one device call; the reference takes them BEFORE its end-of-path test (:324-328), so
+            # "too far from the path" wins where both would stop a member
+            self._flush_errors()
+            for i in idx:
+                e = self._too_far.pop(id(self.agents[i]), None) or stops.get(i)
+                if e is not None and self.stop_status[i] == 0:
                     self._stop(i, e)
         return self.active
 

@@ -820,3 +820,53 @@ def test_pipelined_agent_walks_out_of_the_landscape_like_the_plain_one():
     for fake in (True, False):
         assert logs[True, fake] == logs[False, fake], fake
     assert logs[True, True][-1][0] == "stop" and logs[True, True][-1][1] in ("OutOfLandscapeBoundsException", "IndexError")
+
+
+@pytest.mark.parametrize("max_dist", [np.inf, 3.0])
+def test_ensemble_metrics_on_the_device_equal_the_host_arithmetic(max_dist):
+    """update_error (NavBySceneFamiliarity.py:252-276) of all members of an ensemble in one device call per step (dv_path_error_batch,
+    a coverage array per member): RMSD, coverage, forgiving coverage, captures, frames and stop codes equal those of the same agents
+    stepping one by one with the reference's NumPy arithmetic -- also where members stop for being too far from the path."""
+    land = synth.synth_landscape(21, 500, 4)
+    path = synth.sin_training_path(0.5, 80, 330, arclen=1.0)[:300]
+    def trained():
+        nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, n_test_angles=8, n_sensor_levels=5, max_distance_to_training_path=max_dist,
+                                               familiarity_model=navsim_amd.sads_familiarity(0.25), track_scene_familiarity=False)
+        nsf.train_from_path(path)
+        return nsf
+    rng = np.random.default_rng(8)
+    poses = []
+    for i in (3, 40, 90, 150, 220, 280):
+        d = path[i + 1] - path[i]
+        poses.append((path[i] + rng.uniform(-1.5, 1.5, 2), float((np.arctan2(d[1], d[0]) + rng.uniform(-0.3, 0.3)) % (2 * np.pi))))
+    ens = navsim_amd.NavEnsemble.from_agent(trained(), poses)
+    assert all(a._metric_slot == j for j, a in enumerate(ens.agents))
+    done = ens.run(260)
+    rows = []
+    for j, a in enumerate(ens.agents):
+        rows.append((done[j], ens.stop_status[j], a.navigated_for_frames, float(a.navigation_error) if a._n_navigation_error else None,
+                     float(a.percent_recapitulated), a.percent_recapitulated_forgiving(), a.n_captures(), a.position, a.angle))
+    ens.engine.close()
+    # the same agents one by one, metrics on the host (the reference's NumPy expression)
+    want = []
+    for pos, ang in poses:
+        nsf = trained()
+        nsf._metrics_on_device = False
+        nsf.pipeline_steps = False
+        nsf.reset_error()
+        nsf.position, nsf.angle = (float(pos[0]), float(pos[1])), float(ang)
+        steps, code = 0, 0
+        try:
+            for _ in range(260):
+                nsf.step_forward()
+                steps += 1
+        except navsim_amd.StopNavigationException as e:
+            code = e.get_code()
+        except IndexError:
+            code = navsim_amd.NavEnsemble.SENSE_ERROR_STATUS
+        want.append((steps, code, nsf.navigated_for_frames, float(nsf.navigation_error) if nsf._n_navigation_error else None,
+                     float(nsf.percent_recapitulated), nsf.percent_recapitulated_forgiving(), nsf.n_captures(), nsf.position, nsf.angle))
+        nsf._engine.close()
+    assert rows == want
+    if np.isfinite(max_dist):
+        assert any(r[1] == navsim_amd.TooFarFromTrainingPathException().get_code() for r in rows)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""An ensemble of 32 agents stepping with the error metrics on (fake=False): all members' update_error in one device call per step
+(dv_path_error_batch) against the reference's NumPy arithmetic per member on the host."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "navigation-by-deja-vu_amd"))
+import numpy as np
+import navsim_amd
+from navsim_amd import synth
+L, n_views = 2000, 50000
+land = synth.synth_landscape(20261004, L, 4)
+path = synth.sin_training_path(0.5, 0.2 * L, 0.6 * L, arclen=0.6 * L * 1.4 / n_views)[:n_views]
+for device_metrics in (True, False):
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (64, 64), 0.5, n_test_angles=16, n_sensor_levels=5, familiarity_model=navsim_amd.sads_familiarity(0.25),
+                                           track_scene_familiarity=False)
+    nsf.train_from_path(path)
+    idx = np.linspace(5, len(path) - 50, 32).astype(int)
+    poses = []
+    for i in idx:
+        dd = path[i + 1] - path[i]
+        poses.append((path[i] + np.array([1.0, -1.0]), float(np.arctan2(dd[1], dd[0]) % (2 * np.pi))))
+    ens = navsim_amd.NavEnsemble.from_agent(nsf, poses)
+    if not device_metrics:
+        for a in ens.agents:
+            a._metric_slot = None
+            a._metrics_on_device = False
+            a.reset_error()
+    for _ in range(3):
+        ens.step_forward()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ens.step_forward()
+    dt = (time.perf_counter() - t0) / 20
+    print("metrics on the %s: %.3f ms per ensemble step of 32 agents (%.0f agent-steps/s); RMSD of member 5: %.6f" %
+          ("device" if device_metrics else "host", dt * 1e3, 32 / dt, float(ens.agents[5].navigation_error)))
+    nsf._engine.close()
