@@ -121,7 +121,8 @@ class NavBySceneFamiliarity(object):
     `familiarity_model` is the reference's plug-in point: any `model(scenes) -> func(scene, fambuf)`
     with `func.max_familiarity` works (:72,140,299).  The default is the HIP engine; when the model's
     `func` carries an `.engine`, `step_forward` scores all headings with one fused device step.
-    `track_scene_familiarity=False` skips the per-view minimum the reference only plots (:301-303).
+    `track_scene_familiarity=False` skips the per-view minimum the reference only plots (:301-303); with True (the reference's
+    default) the lean device step is kept and the minimum of the last step is worked out when `scene_familiarity` is read.
     """
 
     def __init__(self,
@@ -168,6 +169,7 @@ class NavBySceneFamiliarity(object):
         self._metric_slot = None               # member of an ensemble: its coverage marks' slot on the device (NavEnsemble)
         self._ens = None
         self.pipeline_steps = os.environ.get("DEJAVU_AGENT_PIPELINE", "1") != "0"
+        self.lazy_scene = os.environ.get("DEJAVU_LAZY_SCENE", "1") != "0"      # track_scene_familiarity=True: the minimum is worked out when read
         self._landscape_glimpse_buf = np.empty((extent[1], extent[0], 3), dtype=np.uint8)
         self.n_sensor_pixels = np.prod(self.sensor_dimensions)
 
@@ -462,17 +464,40 @@ class NavBySceneFamiliarity(object):
         if nearest <= reach:
             self._host_coverage |= (dist <= reach)
 
+    # ---- scene_familiarity: kept every step, or worked out when it is read ----------------------
+    _scene_fam = None
+    _scene_stale = None
+
+    @property
+    def scene_familiarity(self):
+        """float64[F]: min over the headings of the last step's per-view scores (:287,301-303).  With the lean device step
+        (`lazy_scene`, the default) a step only notes its pose; the first read senses that pose again and takes the minimum then --
+        the same patches, the same numbers, paid by whoever reads them."""
+        st = self._scene_stale
+        if st is not None:
+            self._scene_stale = None
+            res = self._engine.sense_step(st[0], st[1], (st[2] + self.angle_offsets) % (2 * np.pi), want_scene=True)
+            self._scene_fam[:] = res["scene_familiarity"]
+        return self._scene_fam
+
+    @scene_familiarity.setter
+    def scene_familiarity(self, value):
+        self._scene_stale = None
+        self._scene_fam = value
+
     # ---- the step (:279-329) -------------------------------------------------------------------
     def step_forward(self, fake=False):
         position = self.position
         self.angle_familiarity[:] = np.nan
-        assert len(self.familiar_scenes) == len(self.scene_familiarity)
+        assert len(self.familiar_scenes) == len(self._scene_fam)
 
         func = self._familiarity_func
         engine = getattr(func, "engine", None)
         defer_error = False
         begin_next = False
         cand = None
+        scene_stale = None
+        self._scene_stale = None               # (whatever was left to work out belonged to the step before)
         begun_next = None                      # (the next step was begun by the call that ended this one, an error answer it collected)
         if engine is not None and str(getattr(func, "metric", "")).startswith("ssd"):
             self._step_ssd(func, engine, position)
@@ -483,7 +508,8 @@ class NavBySceneFamiliarity(object):
                 if engine is self._engine:
                     # patches are sensed on the GPU, straight into the scoring kernel's operand layout
                     self._check_bounds(position)
-                    if not self.track_scene_familiarity and hasattr(engine, "agent_step") and self.n_test_angles <= 64:
+                    lazy = self.track_scene_familiarity and self.lazy_scene
+                    if (lazy or not self.track_scene_familiarity) and hasattr(engine, "agent_step") and self.n_test_angles <= 64:
                         # the lean form of the same device step (dv_agent_step): ONE call does the sensing, the scoring and the
                         # device side of the error metrics -- the answer asked for at the last step is collected, the position
                         # the last step ended at is handed in -- and writes the per-heading maxima straight into angle_familiarity
@@ -525,6 +551,10 @@ class NavBySceneFamiliarity(object):
                         res = None
                         defer_error = self._metrics_on_device and not math.isfinite(self.max_distance_to_training_path)
                         begin_next = self.pipeline_steps
+                        if lazy:
+                            # the per-view minimum of THIS step (:301-303) is worked out when scene_familiarity is read: the
+                            # reference only plots it (:540,630), and keeping it every step halves the agent's rate
+                            scene_stale = (position[0], position[1], self.angle)
                     elif not self.track_scene_familiarity and hasattr(engine, "sense_step_into"):
                         # (the same device step through the engine's lean binding: no per-step record, views or dictionary)
                         best_idex = engine.sense_step_into(position[0], position[1], self.angle, self.angle_offsets,
@@ -541,28 +571,31 @@ class NavBySceneFamiliarity(object):
             except Exception:
                 # the reference resets scene_familiarity to +inf before it senses (:287); a step that stops here
                 # leaves it so.  (A completed step overwrites every entry, so the fill is not paid per step.)
-                self.scene_familiarity[:] = np.inf
+                self._scene_fam[:] = np.inf
                 self._scene_is_inf = True
                 raise
             if res is not None:
                 self.angle_familiarity[:] = res["angle_familiarity"]
                 best_idex = res["best_idex"]
-            if self.track_scene_familiarity:
-                self.scene_familiarity[:] = res["scene_familiarity"]
+            if scene_stale is not None:
+                self._scene_stale = scene_stale
+                self._scene_is_inf = False
+            elif self.track_scene_familiarity:
+                self._scene_fam[:] = res["scene_familiarity"]
                 self._scene_is_inf = False
             elif not self._scene_is_inf:
-                self.scene_familiarity[:] = np.inf              # not tracked: stays at the reference's reset value
+                self._scene_fam[:] = np.inf              # not tracked: stays at the reference's reset value
                 self._scene_is_inf = True
         else:
             # any other plug-in: the reference's loop, one model call per heading
-            self.scene_familiarity[:] = np.inf
+            self._scene_fam[:] = np.inf
             self._scene_is_inf = False
-            temp_fam = np.empty_like(self.scene_familiarity)
+            temp_fam = np.empty_like(self._scene_fam)
             for a_idex, angle_offset in enumerate(self.angle_offsets):
                 smat = self.get_sensor_mat(position, (self.angle + angle_offset) % (2 * np.pi))
                 temp_fam[:] = np.nan
                 func(smat, temp_fam)
-                np.minimum(self.scene_familiarity, temp_fam, out=self.scene_familiarity)
+                np.minimum(self._scene_fam, temp_fam, out=self._scene_fam)
                 self.angle_familiarity[a_idex] = np.max(temp_fam)
             best_idex = np.argmax(self.angle_familiarity)
 
@@ -585,15 +618,15 @@ class NavBySceneFamiliarity(object):
                 else:
                     res = engine.step_f32(planes, want_scene=self.track_scene_familiarity)
         except Exception:
-            self.scene_familiarity[:] = np.inf
+            self._scene_fam[:] = np.inf
             self._scene_is_inf = True
             raise
         np.negative(res["angle_ssd"], out=self.angle_familiarity)
         if self.track_scene_familiarity:
-            np.negative(res["scene_ssd"], out=self.scene_familiarity)     # min over headings of -SSD = -(max over headings of SSD)
+            np.negative(res["scene_ssd"], out=self._scene_fam)     # min over headings of -SSD = -(max over headings of SSD)
             self._scene_is_inf = False
         elif not self._scene_is_inf:
-            self.scene_familiarity[:] = np.inf
+            self._scene_fam[:] = np.inf
             self._scene_is_inf = True
         self.last_scored_idex = res["best_idex"]
 
@@ -674,7 +707,7 @@ class NavBySceneFamiliarity(object):
         other._metrics_on_device = False                          # the device holds ONE agent's coverage marks: clones keep
                                                                   # theirs on the host (same arithmetic)
         other.angle_familiarity = np.full_like(self.angle_familiarity, np.nan)
-        other.scene_familiarity = None if self.track_scene_familiarity is False else np.zeros_like(self.scene_familiarity)
+        other.scene_familiarity = None if self.track_scene_familiarity is False else np.zeros_like(self._scene_fam)
         other.position, other.angle = None, None
         other._spec = None
         other._metric_slot = None

@@ -870,3 +870,56 @@ def test_ensemble_metrics_on_the_device_equal_the_host_arithmetic(max_dist):
     assert rows == want
     if np.isfinite(max_dist):
         assert any(r[1] == navsim_amd.TooFarFromTrainingPathException().get_code() for r in rows)
+
+
+def test_scene_familiarity_worked_out_when_read_equals_the_one_kept_every_step():
+    """track_scene_familiarity=True (the reference's default): the agent takes its lean device step and works the per-view minimum of
+    the last step out when scene_familiarity is read (lazy_scene) -- the array the eager agent keeps every step, bit for bit, at any
+    step it is read, also right after the step that ends the run; in between, the two walk the same trajectory."""
+    land = synth.synth_landscape(12, 500, 4)
+    path = synth.sin_training_path(0.5, 80, 330, arclen=1.0)[:200]
+    agents = []
+    for lazy in (True, False):
+        nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, n_test_angles=12, n_sensor_levels=5, familiarity_model=navsim_amd.sads_familiarity(0.25))
+        nsf.lazy_scene = lazy
+        nsf.train_from_path(path)
+        nsf.position, nsf.angle = (path[3][0] + 0.4, path[3][1] - 0.2), 0.6
+        agents.append(nsf)
+    lazy_a, eager_a = agents
+    assert lazy_a.track_scene_familiarity and np.array_equal(lazy_a.scene_familiarity, eager_a.scene_familiarity)      # zeros after training (:134)
+    stopped = [None, None]
+    reads = 0
+    for t in range(400):
+        for k, a in enumerate(agents):
+            try:
+                a.step_forward()
+            except navsim_amd.StopNavigationException as e:
+                stopped[k] = type(e).__name__
+        assert lazy_a.position == eager_a.position and lazy_a.angle == eager_a.angle and stopped[0] == stopped[1], t
+        if t % 7 == 3 or stopped[0]:
+            reads += 1
+            assert lazy_a._scene_stale is not None
+            assert lazy_a.scene_familiarity.tobytes() == eager_a.scene_familiarity.tobytes(), t
+            assert lazy_a._scene_stale is None and lazy_a.scene_familiarity is lazy_a.scene_familiarity
+        if stopped[0]:
+            break
+    assert reads > 10
+    # ... and right after the step that ends a run: both agents set down just before the end of the path
+    d = path[-5] - path[-6]
+    for a in agents:
+        a.stopped_with_exception = None
+        a.position, a.angle = (float(path[-6][0]), float(path[-6][1])), float(np.arctan2(d[1], d[0]) % (2 * np.pi))
+    ended = [None, None]
+    for t in range(40):
+        for k, a in enumerate(agents):
+            if ended[k] is None:
+                try:
+                    a.step_forward()
+                except navsim_amd.StopNavigationException as e:
+                    ended[k] = type(e).__name__
+        if ended[0] or ended[1]:
+            break
+    assert ended[0] == ended[1] == "ReachedEndOfTrainingPathException"
+    assert lazy_a._scene_stale is not None and lazy_a.scene_familiarity.tobytes() == eager_a.scene_familiarity.tobytes()
+    for a in agents:
+        a.clear_training()
