@@ -356,6 +356,8 @@ class NavBySceneFamiliarity(object):
         self._navigation_error = 0.0
         self._n_navigation_error = 0
         self._pending_errors = 0
+        self._err_positions = []               # positions whose metrics are outstanding, in the order asked
+        self._last_nearest = None              # (distance, position) of the last answer (the bound of _can_defer_error)
         self._error_pos = None                 # a position whose metrics are still to be asked for (the lean step defers them by one call)
         self._host_coverage = None
         if self.training_path is not None:
@@ -373,8 +375,8 @@ class NavBySceneFamiliarity(object):
     def _flush_error_pos(self):
         if self._error_pos is not None:
             self._engine.path_error_enqueue(self._error_pos[0], self._error_pos[1], self.coverage_threshold_factor * self.step_size)
+            self._error_asked(self._error_pos)
             self._error_pos = None
-            self._pending_errors += 1
 
     def _take_error(self, nearest):
         if nearest > self.max_distance_to_training_path:
@@ -382,12 +384,36 @@ class NavBySceneFamiliarity(object):
         self._navigation_error += nearest * nearest
         self._n_navigation_error += 1
 
+    def _error_asked(self, pos):
+        """A position's metrics were asked of the device; the answers come back in the order asked."""
+        self._pending_errors += 1
+        self._err_positions.append((float(pos[0]), float(pos[1])))
+
+    def _error_answer(self, nearest):
+        self._pending_errors -= 1
+        pos = self._err_positions.pop(0) if self._err_positions else None
+        self._take_error(nearest)
+        self._last_nearest = (nearest, pos)
+
+    def _can_defer_error(self, position):
+        """May the metrics of the position the coming step ends at be collected one step late?  Always with an infinite
+        max_distance_to_training_path.  With a finite one the reference stops the run inside update_error (:264), in the very step that
+        gets too far -- so only while that cannot happen: the new position is at most step_size from `position`, and a point's
+        distance to the path is at most the last known one plus the way from where that was measured (triangle inequality)."""
+        if not self._metrics_on_device:
+            return False
+        m = self.max_distance_to_training_path
+        if not math.isfinite(m):
+            return True
+        ln = self._last_nearest
+        if ln is None or ln[1] is None:
+            return False
+        return ln[0] + math.hypot(position[0] - ln[1][0], position[1] - ln[1][1]) + self.step_size <= m * (1.0 - 1e-9) - 1e-9
+
     def _collect_errors(self, keep=0):
         self._flush_error_pos()
         while self._pending_errors > keep:
-            nearest = self._engine.path_error_wait()
-            self._pending_errors -= 1
-            self._take_error(nearest)
+            self._error_answer(self._engine.path_error_wait())
 
     @property
     def _coverage_array(self):
@@ -448,7 +474,7 @@ class NavBySceneFamiliarity(object):
             self._collect_errors()                               # the previous step's answer: ready by now (and a deferred position first)
             self._engine.path_error_enqueue(self.position[0], self.position[1],
                                             self.coverage_threshold_factor * self.step_size)
-            self._pending_errors += 1
+            self._error_asked(self.position)
             if math.isfinite(self.max_distance_to_training_path):
                 self._collect_errors()                           # may raise TooFarFromTrainingPathException here (:264)
             return
@@ -526,7 +552,7 @@ class NavBySceneFamiliarity(object):
                             cand_angle = (self.angle + self.angle_offsets) % (2 * np.pi)
                             cand = (cand_angle, position[0] + self.step_size * np.cos(cand_angle),
                                     position[1] + self.step_size * np.sin(cand_angle))
-                            lean_error = self._metrics_on_device and not math.isfinite(self.max_distance_to_training_path)
+                            lean_error = self._can_defer_error(position)
                             if self.pipeline_steps and (fake or lean_error) and self._error_pos is None:
                                 # ... and the next step begun by the same call that hands this one's record out
                                 # (dv_agent_step_end_begin): nothing of this interpreter between the record and the launch
@@ -544,12 +570,11 @@ class NavBySceneFamiliarity(object):
                                                                    self.coverage_threshold_factor * self.step_size)
                             if epos is not None:
                                 self._error_pos = None
-                                self._pending_errors += 1
+                                self._error_asked(epos)
                             if nearest is not None:
-                                self._pending_errors -= 1
-                                self._take_error(nearest)
+                                self._error_answer(nearest)
                         res = None
-                        defer_error = self._metrics_on_device and not math.isfinite(self.max_distance_to_training_path)
+                        defer_error = self._can_defer_error(position)
                         begin_next = self.pipeline_steps
                         if lazy:
                             # the per-view minimum of THIS step (:301-303) is worked out when scene_familiarity is read: the
@@ -651,10 +676,9 @@ class NavBySceneFamiliarity(object):
             # of agent_step_begin below, nothing else
             if not fake:
                 self.navigated_for_frames += 1
-                self._pending_errors += 1
+                self._error_asked(self.position)
             if begun_next[1] is not None:
-                self._pending_errors -= 1
-                self._take_error(begun_next[1])
+                self._error_answer(begun_next[1])
             self._spec = (self.position[0], self.position[1], angle, self.angle_offsets.tobytes())
             begun = True
         elif begin_next and (fake or defer_error):
@@ -672,10 +696,9 @@ class NavBySceneFamiliarity(object):
                 nearest = self._engine.agent_step_begin(npos[0], npos[1], angle, self.angle_offsets, self.angle_familiarity, epos,
                                                         self.coverage_threshold_factor * self.step_size)
                 if epos is not None:
-                    self._pending_errors += 1
+                    self._error_asked(epos)
                 if nearest is not None:
-                    self._pending_errors -= 1
-                    self._take_error(nearest)
+                    self._error_answer(nearest)
                 self._spec = (npos[0], npos[1], angle, self.angle_offsets.tobytes())
                 begun = True
 

@@ -923,3 +923,41 @@ def test_scene_familiarity_worked_out_when_read_equals_the_one_kept_every_step()
     assert lazy_a._scene_stale is not None and lazy_a.scene_familiarity.tobytes() == eager_a.scene_familiarity.tobytes()
     for a in agents:
         a.clear_training()
+
+
+@pytest.mark.parametrize("max_dist,start", [(2.5, (0.5, 1.8)), (3.0, (1.0, -2.0)), (6.0, (2.0, 3.0)), (450.0, (1.0, -1.0))])
+def test_deferred_error_metrics_with_a_finite_max_distance_stop_in_the_very_step(max_dist, start):
+    """With a finite max_distance_to_training_path the reference stops the run inside the step that gets too far (:264).  The lean agent
+    collects a position's distance one step late only while the triangle inequality says that cannot happen, and waits for it at once
+    otherwise: the step, exception and state at the stop -- and every metric -- equal those of an agent with the metrics in NumPy."""
+    land = synth.synth_landscape(31, 500, 4)
+    path = synth.sin_training_path(0.5, 80, 330, arclen=1.0)[:220]
+    out = []
+    deferred = 0
+    for device in (True, False):
+        nsf = navsim_amd.NavBySceneFamiliarity(land, (16, 16), 1.0, n_test_angles=8, n_sensor_levels=5, max_distance_to_training_path=max_dist,
+                                               familiarity_model=navsim_amd.sads_familiarity(0.25), track_scene_familiarity=False)
+        nsf.train_from_path(path)
+        if not device:
+            nsf._metrics_on_device = False
+            nsf.pipeline_steps = False
+            nsf.reset_error()
+        nsf.position, nsf.angle = (path[5][0] + start[0], path[5][1] + start[1]), 0.9
+        log = []
+        try:
+            for t in range(400):
+                nsf.step_forward()
+                if device:
+                    deferred += int(nsf._pending_errors > 0)
+                log.append((nsf.last_best_idex, nsf.position, nsf.angle))
+        except navsim_amd.StopNavigationException as e:
+            log.append(("stop", type(e).__name__, nsf.position, nsf.angle, nsf.navigated_for_frames))
+        log.append((nsf.navigated_for_frames, float(nsf.navigation_error) if nsf._n_navigation_error else None, float(nsf.percent_recapitulated),
+                    nsf.percent_recapitulated_forgiving(), nsf.n_captures()))
+        out.append(log)
+        nsf.clear_training()
+    assert out[0] == out[1]
+    if max_dist >= 6.0:
+        assert deferred > 50                                            # far from the limit the answers did come a step late
+    if max_dist <= 3.0:
+        assert out[0][-2][0] == "stop"
