@@ -212,13 +212,17 @@ class NavBySceneFamiliarity(object):
             lut[ch] = buf          # truncating float32 -> uint8 cast
         return lut
 
-    def _check_bounds(self, position):
+    def _bounds_tuple(self):
         b = self._bounds
         if b is None:                          # the four limits of :153-158 as Python floats (same comparisons, no NumPy scalars per step)
             r = self._sensor_r
             ldims = self.landscape.shape
             b = self._bounds = (float(r), float(ldims[1] - r), float(ldims[0] - r))
             self._bounds_arr = np.array(b, dtype=np.float64)
+        return b
+
+    def _check_bounds(self, position):
+        b = self._bounds_tuple()
         if (position[0] <= b[0]) or (position[1] <= b[0]) or (position[0] >= b[1]) or (position[1] >= b[2]):
             raise OutOfLandscapeBoundsException()
 
@@ -748,6 +752,7 @@ class NavBySceneFamiliarity(object):
         """Finish a step whose device work was done elsewhere (an ensemble pass): same state changes as step_forward."""
         self.apply_step_arrays(res["angle_familiarity"], res["best_idex"], fake)
 
-    def apply_step_arrays(self, angle_familiarity, best_idex, fake=False):
+    def apply_step_arrays(self, angle_familiarity, best_idex, fake=False, cand=None):
+        """`cand`: (angles, xs, ys) of this agent's candidate headings, worked out for all members at once (NavEnsemble)."""
         self.angle_familiarity[:] = angle_familiarity
-        self._move(best_idex, fake)
+        self._move(best_idex, fake, cand=cand)

@@ -8,7 +8,7 @@ and no longer takes part.
 """
 import numpy as np
 
-from .agent import StopNavigationException
+from .agent import StopNavigationException, OutOfLandscapeBoundsException
 
 
 class NavEnsemble(object):
@@ -26,6 +26,11 @@ class NavEnsemble(object):
         # update_error (:252-276) of all members in ONE device call per ensemble step: every member gets a coverage array of its own on
         # the device (dv_path_slots) and hands its position in; 32 members x a NumPy pass over 50 000 training points each were
         # ~10 ms of host time beside a 0.85 ms device step
+        # members made alike (from_agent: clones) have their candidate headings and the poses those lead to worked out as arrays for
+        # all members at once (NumPy's elementwise loops give an element what they give the scalar)
+        a0 = agents[0]
+        self._uniform = all(a.step_size == a0.step_size and a.landscape is a0.landscape and a._sensor_r == a0._sensor_r and
+                            np.array_equal(a.angle_offsets, a0.angle_offsets) for a in agents)
         self._stepping = False
         self._pending = []                                        # members whose position awaits its metrics
         self._too_far = {}
@@ -95,16 +100,38 @@ class NavEnsemble(object):
 
     def _step_forward(self, fake):
         idx, xs, ys, angs = [], [], [], []
-        for i in self.active:
-            try:
-                x, y, a = self.agents[i].headings_to_test()
-            except StopNavigationException as e:                  # out of the landscape before anything is sensed
-                self._stop(i, e)
-                continue
-            idx.append(i); xs.append(x); ys.append(y); angs.append(a)
+        cands = None
+        act = self.active
+        if self._uniform and act:
+            a0 = self.agents[act[0]]
+            b = a0._bounds_tuple()
+            px = np.array([self.agents[i].position[0] for i in act], dtype=np.float64)
+            py = np.array([self.agents[i].position[1] for i in act], dtype=np.float64)
+            ang = np.array([self.agents[i].angle for i in act], dtype=np.float64)
+            out = (px <= b[0]) | (py <= b[0]) | (px >= b[1]) | (py >= b[2])        # the bounds test of :153-158, before anything is sensed
+            for k in np.nonzero(out)[0].tolist():
+                self.agents[act[k]].angle_familiarity[:] = np.nan
+                self._stop(act[k], OutOfLandscapeBoundsException())
+            keep = np.nonzero(~out)[0]
+            idx = [act[k] for k in keep.tolist()]
+            if idx:
+                xs, ys = px[keep], py[keep]
+                cand_angle = (ang[keep][:, None] + a0.angle_offsets[None, :]) % (2 * np.pi)
+                angs = cand_angle
+                cands = (cand_angle, xs[:, None] + a0.step_size * np.cos(cand_angle), ys[:, None] + a0.step_size * np.sin(cand_angle))
+        else:
+            for i in act:
+                try:
+                    x, y, a = self.agents[i].headings_to_test()
+                except StopNavigationException as e:              # out of the landscape before anything is sensed
+                    self._stop(i, e)
+                    continue
+                idx.append(i); xs.append(x); ys.append(y); angs.append(a)
+            if idx:
+                angs = np.stack(angs)
         if idx:
             stops = {}
-            results = self.engine.sense_step_batch(xs, ys, np.stack(angs))
+            results = self.engine.sense_step_batch(xs, ys, angs)
             # the records as arrays when the engine offers them (engine.BatchResults): no dictionary per agent and step
             lean = hasattr(results, "angle_familiarity")
             flags = results.flags.tolist() if lean else [r["flags"] for r in results]
@@ -113,11 +140,14 @@ class NavEnsemble(object):
                 if flags[k] & 16:                                 # DV_RES_SENSE_ERROR: this agent's footprint left the
                     # landscape (a corner reaches r*sqrt(2) > r past the bounds test); the reference's trial ends in an
                     # IndexError, the other trials go on
+                    if cands is not None:
+                        self.agents[i].angle_familiarity[:] = np.nan      # (headings_to_test's reset, :285)
                     self._stop(i, IndexError("sensor footprint reaches past the end of the landscape (index out of bounds)"))
                     continue
                 try:
                     if lean:
-                        self.agents[i].apply_step_arrays(results.angle_familiarity[k], best[k], fake)
+                        self.agents[i].apply_step_arrays(results.angle_familiarity[k], best[k], fake,
+                                                         None if cands is None else (cands[0][k], cands[1][k], cands[2][k]))
                     else:
                         self.agents[i].apply_step_result(results[k], fake)
                 except StopNavigationException as e:
