@@ -191,6 +191,7 @@ class NavBySceneFamiliarity(object):
         # With the HIP model the landscape and the sensor model live on the GPU as well: patches are sensed where
         # they are scored.  Any other plug-in keeps the host sensor model below (same bytes, pinned by the fixtures).
         self._engine = None
+        self.use_gpu_sensor = bool(use_gpu_sensor)
         make_engine = getattr(self.familiarity_model, "make_engine", None)
         if make_engine is not None and use_gpu_sensor and self.landscape.dtype == np.uint8:
             self._engine = make_engine()
@@ -266,6 +267,11 @@ class NavBySceneFamiliarity(object):
             self._familiarity_func = self.familiarity_model.from_engine(self._engine, self.familiar_scenes)
         else:
             self._familiarity_func = self.familiarity_model(self.familiar_scenes)
+            # a plug-in over several devices (util.sads_familiarity(cw, devices=[...]) -> group.FamiliarityGroup) takes a copy of the
+            # landscape and the sensor's tables on every member, so that a step senses on the devices: nothing but the pose goes up
+            eng = getattr(self._familiarity_func, "engine", None)
+            if self.use_gpu_sensor and hasattr(eng, "attach_sensor") and self.landscape.dtype == np.uint8:
+                eng.attach_sensor(self.landscape, self.sensor_dimensions, self.sensor_pixel_dimensions, self._level_tables(), self.mask_middle_n)
 
     def train_additional_path(self, points):
         """A further training path behind the first (the reference's experiment script anticipates several per
@@ -591,6 +597,10 @@ class NavBySceneFamiliarity(object):
                         res = None
                     else:
                         res = engine.sense_step(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi),
+                                            want_scene=self.track_scene_familiarity)
+                elif getattr(engine, "sensor_attached", False) and self.n_test_angles <= 64:
+                    self._check_bounds(position)
+                    res = engine.sense_step(position[0], position[1], (self.angle + self.angle_offsets) % (2 * np.pi),
                                             want_scene=self.track_scene_familiarity)
                 else:
                     patches = np.empty((self.n_test_angles,) + self.familiar_scenes.shape[1:], dtype=np.uint8)

@@ -30,6 +30,7 @@ class FamiliarityGroup(object):
         self.devices = devices
         self.n_views = 0
         self.shape = None
+        self.sensor_attached = False
 
     def _check(self, rc, what):
         if rc == 0:
@@ -82,6 +83,13 @@ class FamiliarityGroup(object):
         self._check(self._lib.dv_group_configure_sensor(self._g, int(sensor_dimensions[0]), int(sensor_dimensions[1]),
                                                         int(sensor_pixel_dimensions[0]), int(sensor_pixel_dimensions[1]),
                                                         N.u8ptr(lut), int(mask_middle_n)), "dv_group_configure_sensor")
+
+    def attach_sensor(self, landscape, sensor_dimensions, sensor_pixel_dimensions, lut, mask_middle_n):
+        """Landscape and sensor model on every member (what navsim_amd.NavBySceneFamiliarity hands over after training): sense_step
+        then needs nothing but the pose."""
+        self.set_landscape(landscape)
+        self.configure_sensor(sensor_dimensions, sensor_pixel_dimensions, lut, mask_middle_n)
+        self.sensor_attached = True
 
     # -- scoring --------------------------------------------------------------------------------
     def score(self, scene, fambuf):

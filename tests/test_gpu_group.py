@@ -115,6 +115,7 @@ def test_agent_with_the_plugin_made_from_a_device_list():
         nsf.train_from_path(path)
         nsf.position, nsf.angle = (path[2][0] + 0.6, path[2][1] - 0.3), 0.8
     assert isinstance(dev._familiarity_func.engine, navsim_amd.FamiliarityGroup)
+    assert dev._familiarity_func.engine.sensor_attached          # the members sense the patches themselves: only the pose goes up
     for t in range(60):
         dev.step_forward()
         ref.step_forward()
