@@ -423,3 +423,25 @@ def test_batch_results_arrays_are_the_records():
     assert res[-1]["best_view"] == 1000 + n - 1
     with pytest.raises(IndexError):
         res[n]
+
+
+def test_deferring_the_error_metrics_is_bounded_by_the_triangle_inequality():
+    """agent._can_defer_error: with a finite max_distance_to_training_path the distance of the position a step ends at may be collected
+    a step late only while (last known distance) + (way since it was measured) + step_size cannot exceed the limit."""
+    land = synth.synth_landscape(1, 120, 4)
+    nsf = navsim_amd.NavBySceneFamiliarity(land, (8, 8), 1.0, n_test_angles=4, familiarity_model=oracle.sads_familiarity(0.0),
+                                           use_gpu_sensor=False, max_distance_to_training_path=10.0)
+    nsf.train_from_path(np.stack([np.linspace(30, 90, 40), np.full(40, 60.0)], axis=1))
+    assert not nsf._metrics_on_device and not nsf._can_defer_error((50.0, 60.0))      # host metrics: nothing to defer
+    nsf._metrics_on_device = True
+    assert not nsf._can_defer_error((50.0, 60.0))                                       # no distance known yet
+    nsf._last_nearest = (3.0, (50.0, 60.0))
+    assert nsf._can_defer_error((55.0, 60.0))                                           # 3 + 5 + 1 <= 10
+    assert nsf._can_defer_error((53.0, 64.0))                                           # 3 + 5 + 1 (a 3-4-5 way)
+    assert not nsf._can_defer_error((56.5, 60.0))                                       # 3 + 6.5 + 1 > 10
+    assert not nsf._can_defer_error((56.0, 60.0))                                       # exactly 10: the margin decides against
+    nsf._last_nearest = (3.0, None)
+    assert not nsf._can_defer_error((50.0, 60.0))
+    nsf.max_distance_to_training_path = np.inf
+    assert nsf._can_defer_error((1e9, 1e9))
+    nsf._metrics_on_device = False
