@@ -27,10 +27,18 @@ for device_metrics in (True, False):
             a.reset_error()
     for _ in range(3):
         ens.step_forward()
+    eng = ens.engine
+    spent = {"batch": 0.0, "metrics": 0.0}
+    orig_b, orig_m = eng.sense_step_batch, eng.path_error_batch
+    def tb(*a, **k):
+        t = time.perf_counter(); r = orig_b(*a, **k); spent["batch"] += time.perf_counter() - t; return r
+    def tm(*a, **k):
+        t = time.perf_counter(); r = orig_m(*a, **k); spent["metrics"] += time.perf_counter() - t; return r
+    eng.sense_step_batch, eng.path_error_batch = tb, tm
     t0 = time.perf_counter()
     for _ in range(20):
         ens.step_forward()
     dt = (time.perf_counter() - t0) / 20
-    print("metrics on the %s: %.3f ms per ensemble step of 32 agents (%.0f agent-steps/s); RMSD of member 5: %.6f" %
-          ("device" if device_metrics else "host", dt * 1e3, 32 / dt, float(ens.agents[5].navigation_error)))
+    print("metrics on the %s: %.3f ms per ensemble step of 32 agents (%.0f agent-steps/s); RMSD of member 5: %.6f; in sense_step_batch %.3f ms, in path_error_batch %.3f ms" %
+          ("device" if device_metrics else "host", dt * 1e3, 32 / dt, float(ens.agents[5].navigation_error), spent["batch"] / 20 * 1e3, spent["metrics"] / 20 * 1e3))
     nsf._engine.close()
