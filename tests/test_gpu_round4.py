@@ -695,8 +695,8 @@ def test_passes_of_64_headings_with_shared_accumulators_match_the_oracle(cw):
             for name, patches in (("on", on), ("off", off)):
                 eng.step_batch(patches)                                  # (the first call times the kernel forms)
                 got[knob, name] = eng.step_batch(patches)
-                if knob == "1" and name == "on" and cw < 1.0:
-                    assert eng.scoring_form()["fp4"], eng.scoring_form()
+                if knob == "1" and name == "on" and cw < 1.0 and eng.scoring_form()["matrix_cores"]:      # (a knob of the suite's A/B runs may
+                    assert eng.scoring_form()["fp4"], eng.scoring_form()                                    #  have the timing pick a byte kernel here)
         finally:
             eng.close()
     for name, patches in (("on", on), ("off", off)):
