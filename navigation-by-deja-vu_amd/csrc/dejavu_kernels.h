@@ -2743,6 +2743,20 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
         for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 |= __shfl_xor(s3, o); }
         if ((tid & 63) == 0) { s_red[tid >> 6][0] = s0; s_red[tid >> 6][1] = s1; s_red[tid >> 6][2] = s2; s_red[tid >> 6][3] = s3; }
     }
+    // the block's sums, one integer atomic each (after a barrier behind the s_red stores above)
+    auto publish = [&]() {
+        if (tid == 0 && all) {
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s0 += s_red[w][0]; s1 += s_red[w][1]; s2 += s_red[w][2]; s3 |= s_red[w][3]; }
+            const int slot = ((blk & (kAccWays - 1)) * kMaxHeadings + a) * kAccStride;
+            if (s0) atomicAdd(&acc->hs[slot], s0);
+            if (s1) atomicAdd(&acc->bhs[slot], s1);
+            if (s2) atomicAdd(&acc->bv[slot], s2);
+            if (s3 & 1) atomicOr(&acc->off, 1u);
+            if (s3 & 2) atomicOr(&acc->err, 1ull << (a / A_agent));      // bit = agent of the pass
+        }
+    };
     // ---- phase 2: out of LDS.  Raw bytes and the byte path's operand dwords first
     const long long rbase = ((long long)a * c.P + (long long)blk * 256) * 3;
     const int npx = c.P - blk * 256 < 256 ? c.P - blk * 256 : 256;      // real pixels of this block
@@ -2788,6 +2802,7 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
             reinterpret_cast<unsigned char*>(s_img8)[(((kidx * 8 + (beta & 7)) * 2 + half) * 4 + j) * 4 + (beta >> 3)] = real ? (unsigned char)((wd - 2 * alpha) & 0xff) : (unsigned char)0;
         }
         __syncthreads();
+        publish();                                         // (the block's sums: their atomics are under way while the entries are stored)
         const int n4 = pb.fp4 ? 8 : 0;                     // entries per K-step: 4 bit positions x 2 halves (fp4), 8 slices x 2 halves (int8)
         const int per_k = n4 + 16;
         const int total = TT * per_k;
@@ -2804,17 +2819,9 @@ k_patch_prep(const unsigned char* __restrict__ land, const PoseSet poses, int A,
             else coef[(ks * 8 + sub) * 64 + al + 32 * half] = reinterpret_cast<const uint4*>(s_img8)[(kidx * 8 + sub) * 2 + half];
         }
     }
-    __syncthreads();
-    if (tid == 0 && all) {
-        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { s0 += s_red[w][0]; s1 += s_red[w][1]; s2 += s_red[w][2]; s3 |= s_red[w][3]; }
-        const int slot = ((blk & (kAccWays - 1)) * kMaxHeadings + a) * kAccStride;
-        if (s0) atomicAdd(&acc->hs[slot], s0);
-        if (s1) atomicAdd(&acc->bhs[slot], s1);
-        if (s2) atomicAdd(&acc->bv[slot], s2);
-        if (s3 & 1) atomicOr(&acc->off, 1u);
-        if (s3 & 2) atomicOr(&acc->err, 1ull << (a / A_agent));      // bit = agent of the pass
+    if (!(pb.enabled && all)) {                            // (with bit planes the sums left in front of the entries' stores)
+        __syncthreads();
+        publish();
     }
 }
 
