@@ -2610,6 +2610,8 @@ static int enqueue_step(dv_ctx* c, uint32_t flags, bool want_scene) {
         if (c->A_agent <= 16) launch_finish<1>(c, scene_on, force);
         else launch_finish<2>(c, scene_on, force);
     } else {
+        // (one view per thread: with 64 blocks walking the views block-stride -- fewer arrival tickets on the one word -- k_tail took
+        // 18.5 us instead of 14.9 at 50 000 views x 16 headings: its time is the scores' read, not the tickets)
         hipLaunchKernelGGL(k_tail, dim3((unsigned)((g.F + 255) / 256), (unsigned)c->n_agents), dim3(256), 0, c->stream, c->d_fam,
                            c->d_pmax, c->n_partial, c->d_state, c->d_cand, c->d_scene, c->d_result + c->result_slot,
                            c->d_record + (size_t)c->result_slot * (3 + 4 * kMaxHeadings), c->cfg,

@@ -975,7 +975,6 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     rec += (long long)agent * (3 + 4 * kMaxHeadings);
     fam += (long long)a0 * c.Fpad;
     pmax += (long long)a0 * n_partial;
-    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     // amax[a], redundantly in every block (no grid-wide sync, no global atomics).  Many partial maxima (one per view
     // group after k_exact_all): wave w folds headings w, w+4, ...; lanes stride over them with eight loads in flight
     if (A * n_partial <= 4096) {
@@ -1005,11 +1004,12 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     }
     __syncthreads();
 
-    if (f < c.F) {
-        unsigned long long gkey = 0;
-        for (int a = 0; a < A; ++a) gkey = s_amax[a] > gkey ? s_amax[a] : gkey;
-        const double gbest = key_to_double(gkey);
-        const double thr = gbest - delta - delta_rel * fabs(gbest);
+    // (views block-stride; the host launches one view per thread)
+    unsigned long long gkey = 0;
+    for (int a = 0; a < A; ++a) gkey = s_amax[a] > gkey ? s_amax[a] : gkey;
+    const double gbest = key_to_double(gkey);
+    const double thr = gbest - delta - delta_rel * fabs(gbest);
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < c.F; f += (long long)gridDim.x * blockDim.x) {
         double smin = __longlong_as_double(0x7ff0000000000000ll);
         for (int a0 = 0; a0 < A; a0 += 16) {
             double v[16];                                   // all loads of a tile issued before the first use
@@ -2156,28 +2156,36 @@ k_take_channel(const unsigned char* __restrict__ hsv, unsigned char* __restrict_
 // u8prep and pnorm of the resident patches (pnorm zeroed by the caller).  grid = ceil(passes * K * 64 / 256).
 __global__ void __launch_bounds__(256)
 k_prep_u8(const unsigned char* __restrict__ raw, uint4* __restrict__ prep, unsigned long long* __restrict__ pnorm, LibCfg c, int K, int A, int passes) {
+    // (the norms meet in LDS first: one atomic per heading and block -- a thread's own atomic on its heading's word queued 256 deep
+    // behind the others' at 64x64 x 16 headings, half of this kernel's 7.7 us)
+    __shared__ unsigned long long s_nrm[kMaxHeadings];
+    if (threadIdx.x < kMaxHeadings) s_nrm[threadIdx.x] = 0;
+    __syncthreads();
     const long long total = (long long)passes * K * 64;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int lane = (int)(t & 63);
-    const long long r = t >> 6;
-    const int k = (int)(r % K);
-    const int a = (int)(r / K) * 32 + (lane & 31);
-    unsigned w[4] = {0u, 0u, 0u, 0u};
-    unsigned long long nrm = 0;
-    if (a < A) {
-        const int px0 = 32 * k + 16 * (lane >> 5);
-        for (int i = 0; i < 16; ++i) {
-            if (px0 + i < c.P) {
-                const unsigned x = raw[(long long)a * c.P + px0 + i];
-                const int d = (int)x - 128;
-                nrm += (unsigned long long)(d * d);
-                w[i >> 2] |= (x ^ 0x80u) << (8 * (i & 3));
+    if (t < total) {
+        const int lane = (int)(t & 63);
+        const long long r = t >> 6;
+        const int k = (int)(r % K);
+        const int a = (int)(r / K) * 32 + (lane & 31);
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        unsigned long long nrm = 0;
+        if (a < A) {
+            const int px0 = 32 * k + 16 * (lane >> 5);
+            for (int i = 0; i < 16; ++i) {
+                if (px0 + i < c.P) {
+                    const unsigned x = raw[(long long)a * c.P + px0 + i];
+                    const int d = (int)x - 128;
+                    nrm += (unsigned long long)(d * d);
+                    w[i >> 2] |= (x ^ 0x80u) << (8 * (i & 3));
+                }
             }
+            if (nrm) atomicAdd(&s_nrm[a], nrm);
         }
-        if (nrm) atomicAdd(&pnorm[a], nrm);
+        prep[t] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    prep[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    __syncthreads();
+    if (threadIdx.x < kMaxHeadings && s_nrm[threadIdx.x]) atomicAdd(&pnorm[threadIdx.x], s_nrm[threadIdx.x]);
 }
 
 // The cross terms of one pass (32 headings at a_off) over the library.  A workgroup of 8 waves keeps the pass's operand rows of a
