@@ -1064,20 +1064,20 @@ k_tail(const double* __restrict__ fam, const unsigned long long* __restrict__ pm
     if (threadIdx.x == 64) s_ncand = __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 128) s_serr = sense_err ? (int)((*sense_err >> agent) & 1ull) : 0;   // bit = agent of the pass
     __syncthreads();
-    if (threadIdx.x == 0) {
+    {
         const unsigned long long n_all = s_ncand;
         const bool overflow = n_all > (unsigned long long)kCandCap;
         const bool needs = !exact_all && !overflow && (n_all >= 2 || (force && n_all >= 1));
         // the integer-score decision is always filled in (the sharded exchange wants the per-heading maxima
-        // even when local near-ties still have to be re-scored); NEEDS_RESOLVE tells the host it is provisional
-        decide_core(s_amax, s_aview, n_all, false, nullptr, nullptr, &s_res, c, A, delta, exact_all);
-        if (needs) s_res.flags |= kResNeedsResolve;
-        if (s_serr) s_res.flags |= kResSenseError;     // patches came from k_sense and it ran off the landscape
-        s_res.reserved = seq;                           // the host may poll this instead of waiting for the stream
-        s_res.check = record_check(reinterpret_cast<const unsigned long long*>(&s_res), A);
-        __hip_atomic_store(&st->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // k_finish, which may run the next step, expects it clear
+        // even when local near-ties still have to be re-scored); NEEDS_RESOLVE tells the host it is provisional.
+        // Spread over the block like k_fold's (decide_block: the one-thread form was ~3 us at the end of every such step); the
+        // record's `reserved` word carries seq: the host may poll it instead of waiting for the stream.
+        __shared__ unsigned long long s_check;
+        decide_block(s_amax, s_aview, n_all, &s_res, &s_check, c, A, delta,
+                     (exact_all ? 2u : 0u) | (needs ? kResNeedsResolve : 0u) | (s_serr ? kResSenseError : 0u), seq);      // (patches from k_sense that ran off the landscape)
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&st->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // k_finish, which may run the next step, expects it clear
     }
-    __syncthreads();
     emit_record(&s_res, rec, A, threadIdx.x, blockDim.x);
     // The record goes to mapped host memory with wide coalesced stores and no fence: header (7 words), the first A
     // entries of each of the four per-heading arrays, and the check word (see record_check).
